@@ -1,0 +1,225 @@
+"""Seeded synthetic strain-mixture read simulator (SURVEY.md §8d input recipe).
+
+Not part of the reference: the reference ships no test data, so
+the synthetic workloads of BASELINE.json (C2..C5) and the small fixtures under
+tests/golden/ are generated here.  Deterministic for a given seed.
+
+Model: one uniform-random ACGT ancestor, `n_strains` strains = ancestor + SNPs
+(+ optional short indels), log-uniform abundances over one decade, reads with
+Gamma(k=4) lengths, per-base substitution / insertion / deletion errors and 50 %
+reverse-strand reads.  For every read the simulator keeps the genome coordinate
+of each base, so `truth_paf()` can emit the exact pairwise alignment (PAF with a
+`cg:Z:` =/X/I/D CIGAR, the format minimap2 `-c --eqx` writes).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_COMP = np.zeros(256, dtype=np.uint8)
+_COMP[:] = ord("N")
+for a, b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[a] = b
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+SEED_DEFAULT = 20241008
+
+
+class Read:
+    __slots__ = ("name", "seq", "gpos", "strain", "start", "end", "rev")
+
+    def __init__(self, name, seq, gpos, strain, start, end, rev):
+        self.name = name      # str
+        self.seq = seq        # np.uint8 array, read orientation
+        self.gpos = gpos      # np.int64 per read base (read orientation): strain coord or -1 (inserted)
+        self.strain = strain
+        self.start = start    # strain interval covered [start, end)
+        self.end = end
+        self.rev = rev        # True if read is the reverse complement of the strain
+
+
+def make_strains(rng, n_strains, genome_len, snp_rate, indel_rate=0.0):
+    """Return list of strain sequences (uint8 arrays).  Strain 0 is the ancestor."""
+    anc = _BASES[rng.integers(0, 4, size=genome_len)]
+    strains = [anc]
+    for _ in range(1, n_strains):
+        s = anc.copy()
+        n_snp = rng.binomial(genome_len, snp_rate)
+        pos = rng.choice(genome_len, size=n_snp, replace=False)
+        # substitute with a different base
+        shift = rng.integers(1, 4, size=n_snp)
+        code = np.searchsorted(_BASES, s[pos])
+        s[pos] = _BASES[(code + shift) % 4]
+        if indel_rate > 0:
+            n_id = rng.binomial(genome_len, indel_rate)
+            ipos = np.sort(rng.choice(genome_len, size=n_id, replace=False))[::-1]
+            lst = s.tolist()
+            for p in ipos:
+                if rng.random() < 0.5:
+                    del lst[p]
+                else:
+                    lst.insert(p, int(_BASES[rng.integers(0, 4)]))
+            s = np.array(lst, dtype=np.uint8)
+        strains.append(s)
+    return strains
+
+
+def simulate_reads(seed=SEED_DEFAULT, n_strains=5, genome_len=400_000, n_reads=10_000,
+                   mean_len=8_000, min_len=1_000, max_len=40_000,
+                   snp_rate=0.01, strain_indel_rate=0.0,
+                   err_sub=0.003, err_ins=0.001, err_del=0.001,
+                   rev_frac=0.5, name_prefix="r", keep_gpos=False):
+    """Generate reads.  Returns (reads, strains)."""
+    rng = np.random.default_rng(seed)
+    strains = make_strains(rng, n_strains, genome_len, snp_rate, strain_indel_rate)
+    ab = 10.0 ** rng.uniform(0.0, 1.0, size=n_strains)
+    ab = ab / ab.sum()
+    reads = []
+    strain_of = rng.choice(n_strains, size=n_reads, p=ab)
+    lens = np.clip(rng.gamma(4.0, mean_len / 4.0, size=n_reads).astype(np.int64), min_len, max_len)
+    for i in range(n_reads):
+        st = int(strain_of[i])
+        g = strains[st]
+        L = int(min(lens[i], len(g)))
+        s = int(rng.integers(0, len(g) - L + 1))
+        frag = g[s:s + L]
+        # errors
+        u = rng.random(L)
+        is_del = u < err_del
+        is_sub = (u >= err_del) & (u < err_del + err_sub)
+        frag2 = frag.copy()
+        nsub = int(is_sub.sum())
+        if nsub:
+            code = np.searchsorted(_BASES, frag2[is_sub])
+            frag2[is_sub] = _BASES[(code + rng.integers(1, 4, size=nsub)) % 4]
+        keep = ~is_del
+        # never delete the first/last base (keeps start/end exact)
+        keep[0] = keep[-1] = True
+        base = frag2[keep]
+        gp = (np.arange(s, s + L, dtype=np.int64))[keep]
+        n_ins = rng.binomial(len(base), err_ins)
+        if n_ins:
+            ipos = np.sort(rng.integers(1, len(base), size=n_ins))  # insert before index ipos (never at 0)
+            ibase = _BASES[rng.integers(0, 4, size=n_ins)]
+            base = np.insert(base, ipos, ibase)
+            gp = np.insert(gp, ipos, -1)
+        rev = bool(rng.random() < rev_frac)
+        if rev:
+            base = _COMP[base[::-1]]
+            gp = gp[::-1].copy()
+        reads.append(Read(f"{name_prefix}{i}", np.ascontiguousarray(base),
+                          np.ascontiguousarray(gp) if keep_gpos else None, st, s, s + L, rev))
+    return reads, strains
+
+
+def write_fasta(reads, path):
+    with open(path, "wb") as f:
+        for r in reads:
+            f.write(b">" + r.name.encode() + b"\n")
+            f.write(r.seq.tobytes() + b"\n")
+
+
+def write_fastq(reads, path, qual=b"I"):
+    with open(path, "wb") as f:
+        for r in reads:
+            f.write(b"@" + r.name.encode() + b"\n")
+            f.write(r.seq.tobytes() + b"\n+\n" + qual * len(r.seq) + b"\n")
+
+
+def revcomp(seq: np.ndarray) -> np.ndarray:
+    return _COMP[seq[::-1]]
+
+
+def _pair_alignment(q: Read, t: Read):
+    """Exact alignment of query read q against target read t (same strain coordinates).
+
+    Returns None when the reads share no genome column, else a PAF row tuple
+    (qs, qe, strand, ts, te, nmatch, blen, cigar_string)."""
+    if q.end <= t.start or t.end <= q.start:
+        return None
+    strand_rev = q.rev != t.rev
+    qseq = revcomp(q.seq) if strand_rev else q.seq
+    qgp = q.gpos[::-1] if strand_rev else q.gpos
+    tseq, tgp = t.seq, t.gpos
+    # both lists now traverse the genome in the same direction: ascending if t is forward
+    asc = not t.rev
+    i = j = 0
+    nq, nt = len(qseq), len(tseq)
+    cols = []  # (op, qi, tj)
+
+    def ahead(a, b):  # genome coordinate a comes before b in traversal order
+        return a < b if asc else a > b
+
+    while i < nq and j < nt:
+        a, b = qgp[i], tgp[j]
+        if a < 0:
+            cols.append(("I", i, j)); i += 1
+        elif b < 0:
+            cols.append(("D", i, j)); j += 1
+        elif a == b:
+            cols.append(("=" if qseq[i] == tseq[j] else "X", i, j)); i += 1; j += 1
+        elif ahead(a, b):
+            cols.append(("I", i, j)); i += 1
+        else:
+            cols.append(("D", i, j)); j += 1
+    # trim to first/last '=' column
+    first = next((k for k, c in enumerate(cols) if c[0] == "="), None)
+    if first is None:
+        return None
+    last = len(cols) - 1 - next(k for k, c in enumerate(reversed(cols)) if c[0] == "=")
+    cols = cols[first:last + 1]
+    qs_, ts_ = cols[0][1], cols[0][2]
+    qe_, te_ = cols[-1][1] + 1, cols[-1][2] + 1
+    # run-length encode
+    ops = []
+    for c in cols:
+        if ops and ops[-1][0] == c[0]:
+            ops[-1][1] += 1
+        else:
+            ops.append([c[0], 1])
+    nmatch = sum(n for o, n in ops if o == "=")
+    blen = sum(n for o, n in ops)
+    cigar = "".join(f"{n}{o}" for o, n in ops)
+    if strand_rev:
+        qs, qe = nq - qe_, nq - qs_
+    else:
+        qs, qe = qs_, qe_
+    return qs, qe, "-" if strand_rev else "+", ts_, te_, nmatch, blen, cigar
+
+
+def truth_paf(reads, min_cols=50, same_strain_only=False, pair_once=True, with_tags=True):
+    """All pairwise true alignments as PAF lines (query-major, file order).
+
+    Only valid for strains without indels relative to the ancestor (shared
+    coordinate system).  `pair_once` mimics minimap2's dual-skip: a pair is
+    reported only with strcmp(qname, tname) < 0."""
+    lines = []
+    order = sorted(range(len(reads)), key=lambda k: reads[k].start)
+    starts = np.array([reads[k].start for k in order])
+    for qi, q in enumerate(reads):
+        cands = []
+        hi = np.searchsorted(starts, q.end, side="left")
+        for oi in range(hi):
+            ti = order[oi]
+            t = reads[ti]
+            if ti == qi or t.end <= q.start:
+                continue
+            if same_strain_only and t.strain != q.strain:
+                continue
+            if pair_once and not (q.name < t.name):
+                continue
+            cands.append(ti)
+        for ti in sorted(cands):
+            t = reads[ti]
+            al = _pair_alignment(q, t)
+            if al is None:
+                continue
+            qs, qe, strand, ts, te, nmatch, blen, cigar = al
+            if blen < min_cols:
+                continue
+            row = [q.name, str(len(q.seq)), str(qs), str(qe), strand, t.name, str(len(t.seq)),
+                   str(ts), str(te), str(nmatch), str(blen), "0"]
+            if with_tags:
+                nm = blen - nmatch
+                row += [f"NM:i:{nm}", "tp:A:S", f"cg:Z:{cigar}"]
+            lines.append("\t".join(row))
+    return lines
