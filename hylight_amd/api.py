@@ -1,0 +1,176 @@
+"""ctypes binding of libhylight_mi.so (include/hylight_mi.h) - the product's only route to the
+hot path.  There is no CPU fallback: a missing library or a missing GPU raises."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhylight_mi.so")
+
+
+class HlmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libhylight_mi error {code}: {msg}")
+        self.code = code
+
+
+class AvaOpts(C.Structure):
+    _fields_ = [("k", C.c_int), ("w", C.c_int), ("hpc", C.c_int), ("min_chain_score", C.c_int),
+                ("max_gap", C.c_int), ("bandwidth", C.c_int), ("min_cnt", C.c_int),
+                ("min_mid_occ", C.c_int), ("mid_occ_frac", C.c_double),
+                ("match", C.c_int), ("mismatch", C.c_int), ("gap_open", C.c_int), ("gap_ext", C.c_int),
+                ("ambi", C.c_int)]
+
+
+# every symbol include/hylight_mi.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "hlmi_init": (C.c_int, [C.c_int, C.c_int]),
+    "hlmi_shutdown": (None, []),
+    "hlmi_last_error": (C.c_char_p, []),
+    "hlmi_version": (C.c_char_p, []),
+    "hlmi_split_reads2": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_double, C.c_int]),
+    "hlmi_split_reads2_shard": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int,
+                                          C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "hlmi_merge_scored_paf": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_char_p]),
+    "hlmi_filter_chunk": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                    C.c_int]),
+    "hlmi_paf_window_filter": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+    "hlmi_ava_opts_long": (None, [C.POINTER(AvaOpts)]),
+    "hlmi_ava": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(AvaOpts), C.c_char_p]),
+    "hlmi_miniasm": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+    "hlmi_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
+    "hlmi_job_open": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
+    "hlmi_job_close": (None, [C.c_void_p]),
+    "hlmi_job_num_queries": (C.c_int64, [C.c_void_p]),
+    "hlmi_job_num_chunks": (C.c_int64, [C.c_void_p]),
+    "hlmi_job_sketch_bound": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64]),
+    "hlmi_job_sketch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.POINTER(C.c_int64)]),
+    "hlmi_job_set_query_sketch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hlmi_job_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_char_p]),
+    "hlmi_last_stats_json": (C.c_int, [C.c_char_p, C.c_int64]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -m hylight_amd.build` "
+                              "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _b(s):
+    return None if s is None else os.fspath(s).encode()
+
+
+def _check(rc):
+    if rc != 0:
+        raise HlmiError(rc, load().hlmi_last_error().decode(errors="replace"))
+
+
+def init(device=-1, host_threads=0):
+    _check(load().hlmi_init(device, host_threads))
+
+
+def shutdown():
+    load().hlmi_shutdown()
+
+
+def version():
+    return load().hlmi_version().decode()
+
+
+def last_stats():
+    buf = C.create_string_buffer(1 << 16)
+    _check(load().hlmi_last_stats_json(buf, len(buf)))
+    return json.loads(buf.value.decode())
+
+
+def filter_chunk(paf_in, out_paf, len_over, mc, iden, thre=0.0025, min_o=4, long_mode=True):
+    _check(load().hlmi_filter_chunk(_b(paf_in), _b(out_paf), len_over, mc, iden, thre, min_o, int(long_mode)))
+
+
+def paf_window_filter(variant, in_paf, out_path, min_len=60, min_iden=-1.0, min_o=0, sfo=False):
+    _check(load().hlmi_paf_window_filter(variant, min_len, min_iden, min_o, int(sfo), _b(in_paf), _b(out_path)))
+
+
+def split_reads2(reads_fa, ref_fa, nsplit, out_dir, out_paf, threads=30, len_over=3000, mc=2, iden=0.95,
+                 long=False, rank=0, world=1):
+    _check(load().hlmi_split_reads2_shard(_b(reads_fa), _b(ref_fa), nsplit, _b(out_dir), _b(out_paf), threads,
+                                          len_over, mc, iden, int(long), rank, world))
+    return out_paf
+
+
+def merge_scored_paf(in_pafs, out_paf):
+    arr = (C.c_char_p * len(in_pafs))(*[_b(p) for p in in_pafs])
+    _check(load().hlmi_merge_scored_paf(arr, len(in_pafs), _b(out_paf)))
+
+
+def ava_opts_long():
+    o = AvaOpts()
+    load().hlmi_ava_opts_long(C.byref(o))
+    return o
+
+
+def ava(target_fa, query_fa, out_paf, opts=None):
+    _check(load().hlmi_ava(_b(target_fa), _b(query_fa), C.byref(opts) if opts is not None else None, _b(out_paf)))
+
+
+def miniasm(paf, reads_fa, out_path, bub_dist=10000, n_rounds_arg=1, max_ext=1, min_dp=1, outfmt="ug"):
+    _check(load().hlmi_miniasm(_b(paf), _b(reads_fa), bub_dist, n_rounds_arg, max_ext, min_dp, _b(outfmt),
+                               _b(out_path)))
+
+
+def sfo2overlaps(in_sfo, out_savage, num_singles, num_pairs=0):
+    _check(load().hlmi_sfo2overlaps(_b(in_sfo), _b(out_savage), num_singles, num_pairs))
+
+
+class Job:
+    """Staged stage run for the multi-GPU path (sketch shard -> all-gather -> run)."""
+
+    def __init__(self, reads_fa, ref_fa, nsplit, long_mode=True):
+        self._h = load().hlmi_job_open(_b(reads_fa), _b(ref_fa), nsplit, int(long_mode))
+        if not self._h:
+            raise HlmiError(-1, load().hlmi_last_error().decode(errors="replace"))
+
+    def close(self):
+        if self._h:
+            load().hlmi_job_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def num_queries(self):
+        return load().hlmi_job_num_queries(self._h)
+
+    @property
+    def num_chunks(self):
+        return load().hlmi_job_num_chunks(self._h)
+
+    def sketch_bound(self, lo, hi):
+        return load().hlmi_job_sketch_bound(self._h, lo, hi)
+
+    def sketch(self, lo, hi, dev_mz_ptr, cap, dev_counts_ptr):
+        n = C.c_int64(0)
+        _check(load().hlmi_job_sketch(self._h, lo, hi, dev_mz_ptr, cap, dev_counts_ptr, C.byref(n)))
+        return n.value
+
+    def set_query_sketch(self, dev_mz_ptr, n, dev_counts_ptr):
+        _check(load().hlmi_job_set_query_sketch(self._h, dev_mz_ptr, n, dev_counts_ptr))
+
+    def run(self, rank, world, len_over, mc, iden, out_paf):
+        _check(load().hlmi_job_run(self._h, rank, world, len_over, mc, iden, _b(out_paf)))

@@ -1,0 +1,135 @@
+// common.h - shared host-side plumbing for libhylight_mi.so (errors, device buffers, records).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/hylight_mi.h"
+
+namespace hlmi {
+
+// ------------------------------------------------------------------------------------------
+// errors: C++ exceptions inside, error codes + thread-local message at the C boundary
+// ------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+#define HIP_CHECK(expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            ::hlmi::fail(HLMI_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                           \
+    } while (0)
+
+void set_last_error(const std::string &m);
+void require_device();           // throws HLMI_ENODEV when no usable GPU
+hipStream_t stream();            // the library's compute stream
+int host_threads();
+
+// stats of the last stage (exported through hlmi_last_stats_json)
+void stat_reset();
+void stat_set(const std::string &k, double v);
+void stat_add(const std::string &k, double v);
+std::map<std::string, double> &stats();
+
+// ------------------------------------------------------------------------------------------
+// device buffer (RAII)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    explicit DBuf(size_t count) { alloc(count); }
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf &operator=(DBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    void zero() { if (n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), stream())); }
+    void fill_ff() { if (n) HIP_CHECK(hipMemsetAsync(p, 0xff, n * sizeof(T), stream())); }
+    void upload(const T *h, size_t count) {
+        if (count > n) alloc(count);
+        if (count) HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, stream()));
+    }
+    void upload(const std::vector<T> &h) { upload(h.data(), h.size()); }
+    std::vector<T> download(size_t count) const {
+        std::vector<T> h(count);
+        if (count) {
+            HIP_CHECK(hipMemcpyAsync(h.data(), p, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
+            HIP_CHECK(hipStreamSynchronize(stream()));
+        }
+        return h;
+    }
+    std::vector<T> download() const { return download(n); }
+};
+
+inline void sync() { HIP_CHECK(hipStreamSynchronize(stream())); }
+
+template <typename T>
+T download_one(const T *dev) {
+    T v;
+    HIP_CHECK(hipMemcpyAsync(&v, dev, sizeof(T), hipMemcpyDeviceToHost, stream()));
+    sync();
+    return v;
+}
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------
+// PAF row as the kernels see it (one 64-byte record; rows keep stream order by index)
+// ------------------------------------------------------------------------------------------
+// CIGAR ops are stored BAM-style in a separate uint32 array: len<<4 | code.
+enum : uint32_t { OP_EQ = 7, OP_X = 8, OP_I = 1, OP_D = 2, OP_OTHER = 15 };
+enum : uint32_t {
+    PF_REV = 1u,       // strand '-'
+    PF_STAR = 2u,      // last field is "*" (no CIGAR)
+    PF_BAD = 4u,       // row could not be parsed (kept only to preserve window positions)
+};
+
+struct PafRec {
+    uint32_t qid, tid;        // name ids: equal names <=> equal ids (query and target share one space)
+    uint32_t qlen, qs, qe;
+    uint32_t tlen, ts, te;
+    uint32_t nmatch, blen;    // PAF columns 10, 11
+    uint32_t flags;
+    uint32_t chunk;           // target chunk the row belongs to (per-chunk semantics, utils.py:54)
+    uint64_t cig_off;         // first op in the ops array
+    uint32_t cig_n;           // number of ops
+    uint32_t tie;             // last-resort rank of the row inside its chunk (whole-line byte order)
+};
+static_assert(sizeof(PafRec) == 64, "PafRec must stay 64 bytes");
+
+}  // namespace hlmi

@@ -1,0 +1,479 @@
+// filter_stage.hip - HIP kernels for the PAF filter chain.
+//
+//   a4/a17  window_filter_kernel     one workgroup per 1000-row window, window state in LDS
+//           (script/filter_trans_ovlp_inline_v4.py:31-85, _v3.py:39-80)
+//   a2      intermediate order       only the order INSIDE an unordered pair matters downstream
+//           (first row per pair, slr2:321-326 and :133-136); rows are grouped by (chunk, pair)
+//           with a radix sort and each group is ordered by the reference's comparator
+//           (slr2:57: numeric tlen, tstart, tend, then whole-line bytes = PafRec::tie)
+//   a5      snp_count/snp_fill       CIGAR walk of the selected rows -> X-run events
+//           (filter_overlap_slr2.py:289-367 long, :229-287 short)
+//   a6      snp_support_kernel       v >= mc supporters and >= mc further spanning reads
+//           (filter_overlap_slr2.py:370-405) -> per-pair disagreement counts
+//   a7      pass2_kernel             predicates + first surviving row per pair + X digit sum
+//           (filter_overlap_slr2.py:77-136,156-161)
+//
+// All of it is integer / byte work bounded by HBM traffic; no MFMA.
+#include "filter_stage.h"
+
+#include <algorithm>
+
+#include "dev_prims.h"
+
+namespace hlmi {
+
+namespace {
+
+constexpr int WINDOW = 1000;     // filter_trans_ovlp_inline_v4.py:33
+constexpr int QUERY_CAP = 60;    // filter_trans_ovlp_inline_v4.py:82
+constexpr int WG = 256;
+
+__device__ __forceinline__ uint64_t pair_key(uint32_t a, uint32_t b) {
+    return a <= b ? ((uint64_t)a << 32 | b) : ((uint64_t)b << 32 | a);
+}
+
+// overhang test shared by v3/v4/pass 2 (minimap Alg. 5; v4:52-66, slr2:116-131)
+__device__ __forceinline__ bool is_internal(const PafRec &r, int min_o) {
+    int64_t ql = r.qlen, qs = r.qs, qe = r.qe, tl = r.tlen, ts = r.ts, te = r.te;
+    if (r.flags & PF_REV) {
+        int64_t s2 = tl - te, e2 = tl - ts;
+        ts = s2; te = e2;
+    }
+    int64_t a = qs < ts ? qs : ts;
+    int64_t b = (ql - qe) < (tl - te) ? (ql - qe) : (tl - te);
+    int64_t overhang = a + b;
+    int64_t maplen = (qe - qs) > (te - ts) ? (qe - qs) : (te - ts);
+    double lim = (double)maplen * 0.8;
+    double thr = (double)min_o < lim ? (double)min_o : lim;
+    return (double)overhang > thr;
+}
+
+// ---------------------------------------------------------------------------------------
+// a4 / a17
+// ---------------------------------------------------------------------------------------
+template <int VARIANT>
+__global__ __launch_bounds__(WG) void window_filter_kernel(const PafRec *__restrict__ recs,
+                                                           const uint64_t *__restrict__ win_start,
+                                                           const uint32_t *__restrict__ win_len, int min_len,
+                                                           double min_iden, int min_o, uint8_t *__restrict__ keep) {
+    __shared__ uint64_t s_key[1024];
+    __shared__ uint32_t s_q[1024];
+    __shared__ uint8_t s_state[1024];   // bit0 candidate, bit1 internal, bit2 first of its pair
+    const uint64_t base = win_start[blockIdx.x];
+    const int m = (int)win_len[blockIdx.x];
+    for (int i = threadIdx.x; i < 1024; i += WG) {
+        uint64_t key = ~0ull;
+        uint32_t q = 0;
+        uint8_t st = 0;
+        if (i < m) {
+            PafRec r = recs[base + i];
+            bool p1 = !(r.flags & PF_BAD) && !((int64_t)r.blen < (int64_t)min_len) && r.qid != r.tid;
+            if (p1) p1 = !((double)r.nmatch / (double)r.blen < min_iden);
+            bool internal = is_internal(r, min_o);
+            bool cand = VARIANT == 4 ? (p1 && !internal) : p1;
+            if (cand) key = pair_key(r.qid, r.tid);
+            q = r.qid;
+            st = (cand ? 1 : 0) | (internal ? 2 : 0);
+        }
+        s_key[i] = key;
+        s_q[i] = q;
+        s_state[i] = st;
+    }
+    __syncthreads();
+    uint8_t first_bits[4];
+    for (int k = 0, i = threadIdx.x; i < 1024; i += WG, ++k) {
+        bool first = false;
+        if (i < m && (s_state[i] & 1)) {
+            first = true;
+            const uint64_t key = s_key[i];
+            for (int j = 0; j < i; ++j)
+                if (s_key[j] == key) { first = false; break; }
+        }
+        first_bits[k] = first;
+    }
+    __syncthreads();
+    for (int k = 0, i = threadIdx.x; i < 1024; i += WG, ++k)
+        if (first_bits[k]) s_state[i] |= 4;
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += WG) {
+        bool out = false;
+        if (s_state[i] & 4) {
+            if (VARIANT == 4) {
+                int cnt = 0;
+                const uint32_t q = s_q[i];
+                for (int j = 0; j < i; ++j) cnt += ((s_state[j] & 4) && s_q[j] == q) ? 1 : 0;
+                out = cnt < QUERY_CAP;
+            } else {
+                out = !(s_state[i] & 2);
+            }
+        }
+        keep[base + i] = out ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------
+__global__ void iota_kernel(uint32_t *a, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+__global__ void gather_u32_kernel(const uint32_t *src, const uint32_t *idx, uint32_t *dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void gather_u64_kernel(const uint64_t *src, const uint32_t *idx, uint64_t *dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void gather_rec_kernel(const PafRec *recs, const uint32_t *rows, PafRec *dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = recs[rows[i]];
+}
+__global__ void head_flags_kernel(const uint32_t *chunk, const uint64_t *key, uint8_t *head, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || chunk[i] != chunk[i - 1] || key[i] != key[i - 1]) ? 1 : 0;
+}
+
+inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
+
+// order (chunk[i], key[i]) lexicographically: returns the permutation and the sorted copies
+struct SortedCK {
+    DBuf<uint32_t> perm, chunk;
+    DBuf<uint64_t> key;
+};
+void sort_chunk_key(const uint32_t *d_chunk, const uint64_t *d_key, size_t n, uint32_t n_chunks, SortedCK &o) {
+    o.perm.alloc(n);
+    o.chunk.alloc(n);
+    o.key.alloc(n);
+    if (!n) return;
+    hipLaunchKernelGGL(iota_kernel, grid1(n), dim3(WG), 0, stream(), o.perm.p, n);
+    HIP_CHECK(hipMemcpyAsync(o.key.p, d_key, n * 8, hipMemcpyDeviceToDevice, stream()));
+    sort_pairs_u64_u32(o.key.p, o.perm.p, n);
+    if (n_chunks > 1) {
+        hipLaunchKernelGGL(gather_u32_kernel, grid1(n), dim3(WG), 0, stream(), d_chunk, o.perm.p, o.chunk.p, n);
+        sort_pairs_u32_u32(o.chunk.p, o.perm.p, n, 0, bits_for(n_chunks - 1));
+        hipLaunchKernelGGL(gather_u64_kernel, grid1(n), dim3(WG), 0, stream(), d_key, o.perm.p, o.key.p, n);
+    } else {
+        hipLaunchKernelGGL(gather_u32_kernel, grid1(n), dim3(WG), 0, stream(), d_chunk, o.perm.p, o.chunk.p, n);
+    }
+}
+
+// first index i in [0,n) with (chunk[i],key[i]) >= (c,k)
+__device__ __forceinline__ size_t lower_bound_ck(const uint32_t *chunk, const uint64_t *key, size_t n, uint32_t c,
+                                                 uint64_t k) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) >> 1;
+        bool less = chunk[mid] < c || (chunk[mid] == c && key[mid] < k);
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------
+// pair groups
+// ---------------------------------------------------------------------------------------
+__global__ void pair_keys_kernel(const PafRec *recs, const uint32_t *rows, size_t n, uint32_t *chunk, uint64_t *key) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PafRec &r = recs[rows[i]];
+    chunk[i] = r.chunk;
+    key[i] = pair_key(r.qid, r.tid);
+}
+
+// the reference's intermediate order restricted to one chunk (slr2:57)
+__device__ __forceinline__ bool row_less(const PafRec &a, const PafRec &b) {
+    if (a.tlen != b.tlen) return a.tlen < b.tlen;
+    if (a.ts != b.ts) return a.ts < b.ts;
+    if (a.te != b.te) return a.te < b.te;
+    return a.tie < b.tie;
+}
+
+// one thread per pair group: order the group's rows, select the rows that feed the pile-up
+__global__ void pair_order_select_kernel(const PafRec *recs, uint32_t *grows /* rows, grouped */,
+                                         const uint32_t *seg_start, size_t n_seg, size_t n_rows, int long_mode,
+                                         uint8_t *sel /* per grouped position */) {
+    size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    size_t b = seg_start[s], e = (s + 1 < n_seg) ? seg_start[s + 1] : n_rows;
+    for (size_t i = b + 1; i < e; ++i) {   // insertion sort, groups are tiny
+        uint32_t x = grows[i];
+        size_t j = i;
+        while (j > b && row_less(recs[x], recs[grows[j - 1]])) { grows[j] = grows[j - 1]; --j; }
+        grows[j] = x;
+    }
+    bool taken = false;
+    for (size_t i = b; i < e; ++i) {
+        const PafRec &r = recs[grows[i]];
+        bool s1 = false;
+        if (r.qid != r.tid) {
+            if (long_mode) {
+                if (!(r.flags & PF_STAR) && !taken) { s1 = true; taken = true; }
+            } else {
+                s1 = true;
+            }
+        }
+        sel[i] = s1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a5: events
+// ---------------------------------------------------------------------------------------
+__global__ void snp_count_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows, const uint8_t *sel,
+                                 size_t n, int long_mode, uint32_t *n_ev, uint32_t *n_iv) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ne = 0, ni = 0;
+    if (sel[i]) {
+        const PafRec &r = recs[grows[i]];
+        const uint32_t *o = ops + r.cig_off;
+        for (uint32_t k = 0; k < r.cig_n; ++k) ne += ((o[k] & 15u) == OP_X) ? 1u : 0u;
+        if (long_mode) ne *= 2;
+        ni = (r.ts < r.te ? 1u : 0u) + ((long_mode && r.qs < r.qe) ? 1u : 0u);
+    }
+    n_ev[i] = ne;
+    n_iv[i] = ni;
+}
+
+__global__ void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows, const uint8_t *sel,
+                                size_t n, int long_mode, const uint32_t *ev_off, const uint32_t *iv_off,
+                                uint32_t *ev_chunk, uint64_t *ev_key, uint32_t *ev_partner, uint32_t *iv_chunk,
+                                uint64_t *iv_skey, uint64_t *iv_ekey) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n || !sel[i]) return;
+    const PafRec &r = recs[grows[i]];
+    uint32_t w = iv_off[i];
+    if (r.ts < r.te) {
+        iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.tid << 32 | r.ts; iv_ekey[w] = (uint64_t)r.tid << 32 | r.te; ++w;
+    }
+    if (long_mode && r.qs < r.qe) {
+        iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.qid << 32 | r.qs; iv_ekey[w] = (uint64_t)r.qid << 32 | r.qe;
+    }
+    const bool rev = r.flags & PF_REV;
+    uint32_t p1 = rev ? r.qlen - r.qe : r.qs;   // slr2:334
+    uint32_t p2 = r.ts;                         // slr2:336
+    uint32_t e = ev_off[i];
+    const uint32_t *o = ops + r.cig_off;
+    for (uint32_t k = 0; k < r.cig_n; ++k) {
+        uint32_t len = o[k] >> 4, code = o[k] & 15u;
+        if (code == OP_EQ) { p1 += len; p2 += len; }
+        else if (code == OP_I) p1 += len;
+        else if (code == OP_D) p2 += len;
+        else if (code == OP_X) {
+            p1 += len; p2 += len;
+            if (long_mode) {
+                uint32_t qp = rev ? r.qlen - p1 + 1 : p1;   // slr2:357
+                ev_chunk[e] = r.chunk; ev_key[e] = (uint64_t)r.qid << 32 | qp; ev_partner[e] = r.tid; ++e;
+            }
+            ev_chunk[e] = r.chunk; ev_key[e] = (uint64_t)r.tid << 32 | p2; ev_partner[e] = r.qid; ++e;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a6: support test per SNP key, then per-pair counts
+// ---------------------------------------------------------------------------------------
+__global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_key, const uint32_t *ev_partner,
+                                   const uint32_t *ev_perm, const uint32_t *kseg_start, size_t n_kseg, size_t n_ev,
+                                   const uint32_t *ivs_chunk, const uint64_t *ivs_key, const uint32_t *ive_chunk,
+                                   const uint64_t *ive_key, size_t n_iv, const uint32_t *pseg_chunk,
+                                   const uint64_t *pseg_key, size_t n_pseg, int mc, uint32_t *pair_mut) {
+    size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (s >= n_kseg) return;
+    size_t b = kseg_start[s], e = (s + 1 < n_kseg) ? kseg_start[s + 1] : n_ev;
+    int64_t v = (int64_t)(e - b);
+    if (v < mc) return;
+    const uint32_t c = ev_chunk[b];
+    const uint64_t key = ev_key[b];
+    const uint64_t read0 = key & 0xffffffff00000000ull;
+    // #intervals of this read with start < pos  minus  #with end <= pos   (start < end holds for all)
+    int64_t n_start_lt = (int64_t)lower_bound_ck(ivs_chunk, ivs_key, n_iv, c, key) -
+                         (int64_t)lower_bound_ck(ivs_chunk, ivs_key, n_iv, c, read0);
+    int64_t n_end_le = (int64_t)lower_bound_ck(ive_chunk, ive_key, n_iv, c, key + 1) -
+                       (int64_t)lower_bound_ck(ive_chunk, ive_key, n_iv, c, read0);
+    int64_t con = n_start_lt - n_end_le;
+    if (con - v < mc) return;
+    const uint32_t read = (uint32_t)(key >> 32);
+    for (size_t i = b; i < e; ++i) {
+        uint32_t other = ev_partner[ev_perm[i]];
+        uint64_t pk = pair_key(read, other);
+        size_t p = lower_bound_ck(pseg_chunk, pseg_key, n_pseg, c, pk);
+        if (p < n_pseg && pseg_chunk[p] == c && pseg_key[p] == pk) atomicAdd(&pair_mut[p], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a7: pass 2
+// ---------------------------------------------------------------------------------------
+__global__ void pass2_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
+                             const uint32_t *seg_start, size_t n_seg, size_t n_rows, const uint32_t *pair_mut,
+                             int long_mode, int len_over, double thre, int min_o, uint8_t *keep, uint32_t *xdig) {
+    size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    size_t b = seg_start[s], e = (s + 1 < n_seg) ? seg_start[s + 1] : n_rows;
+    const uint32_t mut = pair_mut[s];
+    bool done = false;
+    for (size_t i = b; i < e; ++i) {
+        keep[i] = 0;
+        if (done) continue;
+        const PafRec &r = recs[grows[i]];
+        if (mut > 0) {                                             // slr2:90-100
+            if (!long_mode) continue;
+            if ((double)mut / (double)r.nmatch > thre) continue;
+        }
+        if (r.qid == r.tid) continue;                              // slr2:102
+        if ((int64_t)r.nmatch < (int64_t)len_over) continue;       // slr2:105
+        if (is_internal(r, min_o)) continue;                       // slr2:116-131
+        done = true;                                               // slr2:133-136 first surviving row of the pair
+        keep[i] = 1;
+        uint32_t sum = 0;                                          // slr2:156-161 digit before every 'X'
+        const uint32_t *o = ops + r.cig_off;
+        for (uint32_t k = 0; k < r.cig_n; ++k)
+            if ((o[k] & 15u) == OP_X) sum += (o[k] >> 4) % 10u;
+        xdig[i] = sum;
+    }
+}
+
+std::vector<uint64_t> make_windows(const std::vector<uint64_t> &chunk_row_start, std::vector<uint32_t> &len) {
+    std::vector<uint64_t> start;
+    for (size_t c = 0; c + 1 < chunk_row_start.size(); ++c)
+        for (uint64_t p = chunk_row_start[c]; p < chunk_row_start[c + 1]; p += WINDOW) {
+            start.push_back(p);
+            len.push_back((uint32_t)std::min<uint64_t>(WINDOW, chunk_row_start[c + 1] - p));
+        }
+    return start;
+}
+
+}  // namespace
+
+void window_filter_device(const PafRec *d_recs, size_t n, const std::vector<uint64_t> &chunk_row_start, int variant,
+                          int min_len, double min_iden, int min_o, uint8_t *d_keep) {
+    if (!n) return;
+    std::vector<uint32_t> wlen;
+    std::vector<uint64_t> wstart = make_windows(chunk_row_start, wlen);
+    DBuf<uint64_t> d_ws;
+    DBuf<uint32_t> d_wl;
+    d_ws.upload(wstart);
+    d_wl.upload(wlen);
+    if (variant == 4)
+        hipLaunchKernelGGL(window_filter_kernel<4>, dim3((unsigned)wstart.size()), dim3(WG), 0, stream(), d_recs, d_ws.p,
+                           d_wl.p, min_len, min_iden, min_o, d_keep);
+    else if (variant == 3)
+        hipLaunchKernelGGL(window_filter_kernel<3>, dim3((unsigned)wstart.size()), dim3(WG), 0, stream(), d_recs, d_ws.p,
+                           d_wl.p, min_len, min_iden, min_o, d_keep);
+    else
+        fail(HLMI_EINVAL, "window filter variant must be 3 or 4");
+    HIP_CHECK(hipGetLastError());
+    sync();
+}
+
+void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
+                         const std::vector<uint64_t> &chunk_row_start, const FilterCfg &cfg, FilterOut &out) {
+    out = FilterOut();
+    if (!n) return;
+    const uint32_t n_chunks = (uint32_t)(chunk_row_start.size() - 1);
+    const int lm = cfg.long_mode ? 1 : 0;
+
+    // ---- a4 ------------------------------------------------------------------------------
+    DBuf<uint8_t> keep1(n);
+    window_filter_device(d_recs, n, chunk_row_start, 4, cfg.v4_min_len, cfg.v4_min_iden, cfg.v4_min_o, keep1.p);
+    DBuf<uint32_t> rows(n);
+    const size_t m = select_flagged_indices(keep1.p, rows.p, n);
+    out.n_after_v4 = m;
+    if (!m) return;
+
+    // ---- group by (chunk, unordered pair) ------------------------------------------------------
+    DBuf<uint32_t> rchunk(m);
+    DBuf<uint64_t> rkey(m);
+    hipLaunchKernelGGL(pair_keys_kernel, grid1(m), dim3(WG), 0, stream(), d_recs, rows.p, m, rchunk.p, rkey.p);
+    SortedCK g;
+    sort_chunk_key(rchunk.p, rkey.p, m, n_chunks, g);
+    DBuf<uint32_t> grows(m);
+    hipLaunchKernelGGL(gather_u32_kernel, grid1(m), dim3(WG), 0, stream(), rows.p, g.perm.p, grows.p, m);
+    DBuf<uint8_t> head(m);
+    hipLaunchKernelGGL(head_flags_kernel, grid1(m), dim3(WG), 0, stream(), g.chunk.p, g.key.p, head.p, m);
+    DBuf<uint32_t> pseg_start(m);
+    const size_t n_pseg = select_flagged_indices(head.p, pseg_start.p, m);
+    out.n_pairs = n_pseg;
+    DBuf<uint32_t> pseg_chunk(n_pseg);
+    DBuf<uint64_t> pseg_key(n_pseg);
+    hipLaunchKernelGGL(gather_u32_kernel, grid1(n_pseg), dim3(WG), 0, stream(), g.chunk.p, pseg_start.p, pseg_chunk.p, n_pseg);
+    hipLaunchKernelGGL(gather_u64_kernel, grid1(n_pseg), dim3(WG), 0, stream(), g.key.p, pseg_start.p, pseg_key.p, n_pseg);
+    DBuf<uint8_t> sel(m);
+    hipLaunchKernelGGL(pair_order_select_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, grows.p, pseg_start.p,
+                       n_pseg, m, lm, sel.p);
+
+    // ---- a5: events + intervals -------------------------------------------------------------------
+    DBuf<uint32_t> n_ev(m), n_iv(m), ev_off(m), iv_off(m);
+    hipLaunchKernelGGL(snp_count_kernel, grid1(m), dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm, n_ev.p,
+                       n_iv.p);
+    exclusive_scan_u32(n_ev.p, ev_off.p, m);
+    exclusive_scan_u32(n_iv.p, iv_off.p, m);
+    const size_t E = (size_t)download_one(ev_off.p + (m - 1)) + download_one(n_ev.p + (m - 1));
+    const size_t I = (size_t)download_one(iv_off.p + (m - 1)) + download_one(n_iv.p + (m - 1));
+    out.n_events = E;
+    DBuf<uint32_t> pair_mut(n_pseg);
+    pair_mut.zero();
+    if (E) {
+        DBuf<uint32_t> ev_chunk(E), ev_partner(E), iv_chunk(I ? I : 1);
+        DBuf<uint64_t> ev_key(E), iv_skey(I ? I : 1), iv_ekey(I ? I : 1);
+        hipLaunchKernelGGL(snp_fill_kernel, grid1(m), dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm,
+                           ev_off.p, iv_off.p, ev_chunk.p, ev_key.p, ev_partner.p, iv_chunk.p, iv_skey.p, iv_ekey.p);
+        SortedCK sev, sis, sie;
+        sort_chunk_key(ev_chunk.p, ev_key.p, E, n_chunks, sev);
+        sort_chunk_key(iv_chunk.p, iv_skey.p, I, n_chunks, sis);
+        sort_chunk_key(iv_chunk.p, iv_ekey.p, I, n_chunks, sie);
+        DBuf<uint8_t> khead(E);
+        hipLaunchKernelGGL(head_flags_kernel, grid1(E), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p, khead.p, E);
+        DBuf<uint32_t> kseg_start(E);
+        const size_t n_kseg = select_flagged_indices(khead.p, kseg_start.p, E);
+        // ---- a6 ---------------------------------------------------------------------------------
+        hipLaunchKernelGGL(snp_support_kernel, grid1(n_kseg), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p,
+                           ev_partner.p, sev.perm.p, kseg_start.p, n_kseg, E, sis.chunk.p, sis.key.p, sie.chunk.p,
+                           sie.key.p, I, pseg_chunk.p, pseg_key.p, n_pseg, cfg.mc, pair_mut.p);
+        HIP_CHECK(hipGetLastError());
+        sync();
+    }
+
+    // ---- a7 ---------------------------------------------------------------------------------------
+    DBuf<uint8_t> keep2(m);
+    DBuf<uint32_t> xdig(m);
+    xdig.zero();
+    hipLaunchKernelGGL(pass2_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, d_ops, grows.p, pseg_start.p, n_pseg,
+                       m, pair_mut.p, lm, cfg.len_over, cfg.thre, cfg.min_o, keep2.p, xdig.p);
+    HIP_CHECK(hipGetLastError());
+    DBuf<uint32_t> kidx(m);
+    const size_t nk = select_flagged_indices(keep2.p, kidx.p, m);
+    if (!nk) return;
+    DBuf<uint32_t> krows(nk), kx(nk);
+    hipLaunchKernelGGL(gather_u32_kernel, grid1(nk), dim3(WG), 0, stream(), grows.p, kidx.p, krows.p, nk);
+    hipLaunchKernelGGL(gather_u32_kernel, grid1(nk), dim3(WG), 0, stream(), xdig.p, kidx.p, kx.p, nk);
+    std::vector<uint32_t> hrows = krows.download(nk), hx = kx.download(nk);
+    // reference write order: per chunk, the slr2:57 order.  Only kept rows are ordered on the host.
+    std::vector<PafRec> hrecs(nk);
+    {
+        DBuf<PafRec> tmp(nk);   // gather the kept records (64 B each) for the ordering keys
+        hipLaunchKernelGGL(gather_rec_kernel, grid1(nk), dim3(WG), 0, stream(), d_recs, krows.p, tmp.p, nk);
+        hrecs = tmp.download(nk);
+    }
+    std::vector<uint32_t> ord(nk);
+    for (size_t i = 0; i < nk; ++i) ord[i] = (uint32_t)i;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+        const PafRec &x = hrecs[a], &y = hrecs[b];
+        if (x.chunk != y.chunk) return x.chunk < y.chunk;
+        if (x.tlen != y.tlen) return x.tlen < y.tlen;
+        if (x.ts != y.ts) return x.ts < y.ts;
+        if (x.te != y.te) return x.te < y.te;
+        return x.tie < y.tie;
+    });
+    out.rows.resize(nk);
+    out.x_digit_sum.resize(nk);
+    for (size_t i = 0; i < nk; ++i) {
+        out.rows[i] = hrows[ord[i]];
+        out.x_digit_sum[i] = hx[ord[i]];
+    }
+}
+
+}  // namespace hlmi

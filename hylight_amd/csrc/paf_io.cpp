@@ -1,0 +1,279 @@
+// paf_io.cpp - host text I/O (see paf_io.h).  Nothing here is on the timed device path; it is
+// the text boundary the reference pipes between its processes.
+#include "paf_io.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdlib>
+#include <numeric>
+
+namespace hlmi {
+
+uint32_t NameDict::put(std::string_view s) {
+    auto it = index.find(std::string(s));
+    if (it != index.end()) return it->second;
+    uint32_t id = (uint32_t)names.size();
+    names.emplace_back(s);
+    index.emplace(names.back(), id);
+    return id;
+}
+
+std::string read_file(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) fail(HLMI_EIO, "cannot open %s: %s", path, strerror(errno));
+    std::string s;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    return s;
+}
+
+void write_lines(const char *path, const std::vector<std::string> &lines) {
+    FILE *f = fopen(path, "wb");
+    if (!f) fail(HLMI_EIO, "cannot write %s: %s", path, strerror(errno));
+    for (auto &l : lines) {
+        fwrite(l.data(), 1, l.size(), f);
+        fputc('\n', f);
+    }
+    if (fclose(f) != 0) fail(HLMI_EIO, "write error on %s", path);
+}
+
+static bool parse_u32(std::string_view s, uint32_t &v) {
+    if (s.empty() || s.size() > 10) return false;
+    uint64_t x = 0;
+    for (char c : s) {
+        if (c < '0' || c > '9') return false;
+        x = x * 10 + (uint64_t)(c - '0');
+    }
+    if (x > 0xffffffffull) return false;
+    v = (uint32_t)x;
+    return true;
+}
+
+void read_paf(const char *path, PafText &out, bool need_tie_rank) {
+    out.data = read_file(path);
+    const std::string &d = out.data;
+    size_t pos = 0, N = d.size();
+    while (pos < N) {
+        size_t e = d.find('\n', pos);
+        if (e == std::string::npos) e = N;
+        out.line_off.push_back(pos);
+        out.line_len.push_back((uint32_t)(e - pos));
+        pos = e + 1;
+    }
+    size_t n = out.line_off.size();
+    out.recs.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        std::string_view L = out.line(i);
+        PafRec r{};
+        // split into fields
+        size_t fs[12];
+        size_t nf = 0, p = 0, last_start = 0;
+        while (true) {
+            if (nf < 12) fs[nf] = p;
+            last_start = p;
+            ++nf;
+            size_t t = L.find('\t', p);
+            if (t == std::string_view::npos) break;
+            p = t + 1;
+        }
+        if (nf < 11) fail(HLMI_EINVAL, "%s:%zu: PAF row has %zu columns (< 11)", path, i + 1, nf);
+        auto field = [&](int k) {
+            size_t b = fs[k];
+            size_t e2 = (k + 1 < (int)nf && k + 1 < 12) ? fs[k + 1] - 1 : L.find('\t', b);
+            if (e2 == std::string_view::npos) e2 = L.size();
+            return L.substr(b, e2 - b);
+        };
+        uint32_t *dst[] = {&r.qlen, &r.qs, &r.qe, nullptr, nullptr, &r.tlen, &r.ts, &r.te, &r.nmatch, &r.blen};
+        for (int k = 1; k <= 10; ++k) {
+            if (!dst[k - 1]) continue;
+            if (!parse_u32(field(k), *dst[k - 1]))
+                fail(HLMI_EINVAL, "%s:%zu: column %d is not an unsigned integer", path, i + 1, k + 1);
+        }
+        r.qid = out.dict.put(field(0));
+        r.tid = out.dict.put(field(5));
+        std::string_view strand = field(4);
+        r.flags = (strand == "+") ? 0u : PF_REV;   // the reference tests `qori == '-'` / `flag == "+"`
+        if (strand != "+" && strand != "-") fail(HLMI_EINVAL, "%s:%zu: strand must be + or -", path, i + 1);
+        // last field: CIGAR (filter_overlap_slr2.py:312 reads len_sp[-1])
+        std::string_view lf = L.substr(last_start);
+        r.cig_off = out.ops.size();
+        if (lf == "*") {
+            r.flags |= PF_STAR;
+        } else if (lf.size() > 5 && lf.substr(0, 5) == "cg:Z:") {
+            uint64_t num = 0;
+            bool have = false;
+            for (size_t q = 5; q < lf.size(); ++q) {
+                char c = lf[q];
+                if (c >= '0' && c <= '9') {
+                    num = num * 10 + (uint64_t)(c - '0');
+                    have = true;
+                    if (num >= (1ull << 28)) fail(HLMI_EINVAL, "%s:%zu: CIGAR op too long", path, i + 1);
+                } else {
+                    if (!have) fail(HLMI_EINVAL, "%s:%zu: malformed cg:Z: field", path, i + 1);
+                    uint32_t code = c == '=' ? OP_EQ : c == 'X' ? OP_X : c == 'I' ? OP_I : c == 'D' ? OP_D : OP_OTHER;
+                    out.ops.push_back((uint32_t)num << 4 | code);
+                    num = 0;
+                    have = false;
+                }
+            }
+        }
+        r.cig_n = (uint32_t)(out.ops.size() - r.cig_off);
+        r.chunk = 0;
+        r.tie = (uint32_t)i;
+        out.recs[i] = r;
+    }
+    if (need_tie_rank && n) {
+        std::vector<uint32_t> idx(n);
+        std::iota(idx.begin(), idx.end(), 0u);
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return out.line(a) < out.line(b); });
+        for (size_t k = 0; k < n; ++k) out.recs[idx[k]].tie = (uint32_t)k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// FASTA / FASTQ
+// ------------------------------------------------------------------------------------------
+void read_seqs(const char *path, SeqSet &out) {
+    std::string d = read_file(path);
+    size_t N = d.size(), pos = 0;
+    uint32_t line_no = 0;
+    out.off.push_back(0);
+    auto next_line = [&](std::string_view &L) -> bool {
+        if (pos >= N) return false;
+        size_t e = d.find('\n', pos);
+        if (e == std::string::npos) e = N;
+        size_t end = e;
+        if (end > pos && d[end - 1] == '\r') --end;
+        L = std::string_view(d).substr(pos, end - pos);
+        pos = e + 1;
+        ++line_no;
+        return true;
+    };
+    out.n_lines = (uint64_t)std::count(d.begin(), d.end(), '\n');
+    std::string_view L;
+    bool have = next_line(L);
+    while (have) {
+        if (L.empty() || (L[0] != '>' && L[0] != '@')) {  // kseq skips to the next header
+            have = next_line(L);
+            continue;
+        }
+        bool fq = L[0] == '@';
+        size_t ws = L.find_first_of(" \t", 1);
+        out.names.emplace_back(L.substr(1, (ws == std::string_view::npos ? L.size() : ws) - 1));
+        out.first_line.push_back(line_no - 1);
+        size_t start = out.bases.size();
+        have = next_line(L);
+        while (have && !(L.size() && (L[0] == '>' || L[0] == '@' || L[0] == '+'))) {
+            out.bases.append(L);
+            have = next_line(L);
+        }
+        size_t slen = out.bases.size() - start;
+        if (fq && have && L.size() && L[0] == '+') {
+            size_t q = 0;
+            have = next_line(L);
+            while (have && q < slen) {
+                q += L.size();
+                have = next_line(L);
+            }
+        }
+        out.off.push_back(out.bases.size());
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// final rows
+// ------------------------------------------------------------------------------------------
+bool format_scored_row(const PafRec &r, const std::string &qname, const std::string &tname,
+                       uint32_t x_digit_sum, double iden, std::string &out) {
+    // filter_overlap_slr2.py:113,138-146 - plain IEEE doubles in the reference's evaluation order
+    double mc = (double)r.nmatch, ln = (double)r.blen;
+    double mlen = (double)((uint64_t)r.qlen + r.tlen) / 2.0;
+    double t1 = mc / mlen, t2 = mc / ln;
+    double a = 0.4 * t1, b = 0.6 * t2;
+    double score = a + b;
+    double mis = (double)x_digit_sum / mc;
+    double score2 = 1.0 - mis;
+    char s1[64], s2[64], s3[64];
+    snprintf(s1, sizeof s1, "%.4f", score);
+    snprintf(s2, sizeof s2, "%.4f", score2);
+    snprintf(s3, sizeof s3, "%.4f", t2);
+    if (strtod(s2, nullptr) < iden) return false;
+    char buf[256];
+    int m = snprintf(buf, sizeof buf, "\t%u\t%u\t%u\t%c\t", r.qlen, r.qs, r.qe, (r.flags & PF_REV) ? '-' : '+');
+    out.assign(qname);
+    out.append(buf, m);
+    out.append(tname);
+    m = snprintf(buf, sizeof buf, "\t%u\t%u\t%u\t%u\t%u\t%s\t%s\t%s\t", r.tlen, r.ts, r.te, r.nmatch, r.blen, s1, s2, s3);
+    out.append(buf, m);
+    return true;
+}
+
+namespace {
+// exact view of the number GNU `sort -n` reads at p: sign, integer digits, fraction digits
+struct NumKey {
+    bool neg;
+    std::string_view ip, fp;
+};
+NumKey gnu_num(std::string_view s) {
+    size_t p = 0;
+    while (p < s.size() && (s[p] == ' ' || s[p] == '\t')) ++p;
+    NumKey k{false, {}, {}};
+    if (p < s.size() && s[p] == '-') { k.neg = true; ++p; }
+    size_t b = p;
+    while (p < s.size() && s[p] >= '0' && s[p] <= '9') ++p;
+    k.ip = s.substr(b, p - b);
+    while (!k.ip.empty() && k.ip[0] == '0') k.ip.remove_prefix(1);
+    if (p < s.size() && s[p] == '.') {
+        ++p;
+        b = p;
+        while (p < s.size() && s[p] >= '0' && s[p] <= '9') ++p;
+        k.fp = s.substr(b, p - b);
+        while (!k.fp.empty() && k.fp.back() == '0') k.fp.remove_suffix(1);
+    }
+    if (k.ip.empty() && k.fp.empty()) k.neg = false;  // -0 == 0
+    return k;
+}
+int cmp_mag(const NumKey &a, const NumKey &b) {
+    if (a.ip.size() != b.ip.size()) return a.ip.size() < b.ip.size() ? -1 : 1;
+    int c = a.ip.compare(b.ip);
+    if (c) return c < 0 ? -1 : 1;
+    c = a.fp.compare(b.fp);   // digit strings without trailing zeros: lexicographic == numeric
+    return c < 0 ? -1 : c > 0 ? 1 : 0;
+}
+int gnu_numcmp(std::string_view a, std::string_view b) {
+    NumKey x = gnu_num(a), y = gnu_num(b);
+    if (x.neg != y.neg) return x.neg ? -1 : 1;
+    int c = cmp_mag(x, y);
+    return x.neg ? -c : c;
+}
+std::string_view field_tail(std::string_view L, int k) {
+    size_t p = 0;
+    for (int i = 1; i < k; ++i) {
+        size_t t = L.find('\t', p);
+        if (t == std::string_view::npos) return {};
+        p = t + 1;
+    }
+    return L.substr(p);
+}
+}  // namespace
+
+void sort_scored_lines(std::vector<std::string> &lines) {
+    size_t n = lines.size();
+    std::vector<uint32_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::vector<std::string_view> key(n);
+    for (size_t i = 0; i < n; ++i) key[i] = field_tail(lines[i], 12);
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        int c = gnu_numcmp(key[a], key[b]);
+        if (c) return c > 0;               // -r: descending
+        return lines[a] > lines[b];        // last resort, reversed as well
+    });
+    std::vector<std::string> out;
+    out.reserve(n);
+    for (uint32_t i : idx) out.push_back(std::move(lines[i]));
+    lines.swap(out);
+}
+
+}  // namespace hlmi

@@ -1,0 +1,57 @@
+// runtime.cpp - process-level state: device selection, the compute stream, last error, stats.
+#include <mutex>
+
+#include "common.h"
+
+namespace hlmi {
+
+namespace {
+thread_local std::string g_last_error;
+hipStream_t g_stream = nullptr;
+bool g_ready = false;
+int g_threads = 8;
+std::map<std::string, double> g_stats;
+std::mutex g_mu;
+}  // namespace
+
+void set_last_error(const std::string &m) { g_last_error = m; }
+const std::string &last_error() { return g_last_error; }
+
+int host_threads() { return g_threads; }
+
+void init_device(int device, int threads) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        fail(HLMI_ENODEV, "no HIP device available (%s); libhylight_mi has no CPU fallback",
+             e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device >= n) fail(HLMI_EINVAL, "device %d out of range (have %d)", device, n);
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    if (!g_stream) HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (threads > 0) g_threads = threads;
+    g_ready = true;
+}
+
+void shutdown_device() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_stream) {
+        (void)hipStreamSynchronize(g_stream);
+        (void)hipStreamDestroy(g_stream);
+    }
+    g_stream = nullptr;
+    g_ready = false;
+}
+
+void require_device() {
+    if (!g_ready) init_device(-1, 0);
+}
+
+hipStream_t stream() { return g_stream; }
+
+void stat_reset() { g_stats.clear(); }
+void stat_set(const std::string &k, double v) { g_stats[k] = v; }
+void stat_add(const std::string &k, double v) { g_stats[k] += v; }
+std::map<std::string, double> &stats() { return g_stats; }
+
+}  // namespace hlmi

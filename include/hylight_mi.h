@@ -1,0 +1,129 @@
+/* hylight_mi.h - C ABI of libhylight_mi.so: the MI355X-native overlap -> filter -> graph hot path
+ * of HyLight.
+ *
+ * The reference (kangxiongbin/HyLight @ 2024_10_08) has no FFI: the path sits behind process
+ * boundaries.  Each entry point below replaces one of those
+ * boundaries and cites it; `INTEGRATION.md` shows the ctypes stub a maintainer would add on the
+ * reference side.  Conventions:
+ *   - plain C types only; strings are caller-owned NUL-terminated paths; outputs are files,
+ *     so no memory ownership crosses the boundary (device pointers, where they appear, are
+ *     caller-owned HIP allocations passed as void*);
+ *   - every call returns 0 on success or a negative HLMI_E* code; the message is available
+ *     from hlmi_last_error() (thread-local);
+ *   - calls need a HIP device: the library has NO CPU fallback and fails with HLMI_ENODEV
+ *     when none is usable.
+ */
+#ifndef HYLIGHT_MI_H
+#define HYLIGHT_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HLMI_OK        0
+#define HLMI_EINVAL   -1   /* bad argument / malformed input file */
+#define HLMI_EIO      -2   /* cannot open / read / write a file */
+#define HLMI_ENODEV   -3   /* no usable HIP device (there is no CPU fallback) */
+#define HLMI_EHIP     -4   /* a HIP runtime call or kernel failed */
+#define HLMI_ENOMEM   -5
+#define HLMI_ESTATE   -6   /* call sequence error (e.g. job step called out of order) */
+
+/* ---- library state -------------------------------------------------------------------- */
+/* Select the HIP device used by this process (one process per GPU).  device < 0 keeps the
+ * current device.  host_threads bounds host-side helper threads (text formatting, sorting). */
+int         hlmi_init(int device, int host_threads);
+void        hlmi_shutdown(void);
+const char *hlmi_last_error(void);
+const char *hlmi_version(void);
+
+/* ---- B1: whole stage = utils.split_reads2 (script/utils.py:41-71) ----------------------- */
+/* reads_fa = query reads (`-r`), ref_fa = targets that get --nsplit-chunked (`-c`); writes the
+ * merged, score-sorted 14-column PAF (trailing TAB before newline, filter_overlap_slr2.py:151)
+ * to out_paf.  `threads` is accepted for signature parity (the reference uses it for xargs -P
+ * and minimap2 -t; here the GPU does the work).  rank/world shard the target chunks
+ * (chunk i -> rank i % world); with world > 1 each rank writes `out_paf` for its own chunks and
+ * hlmi_merge_scored_paf() combines them. */
+int hlmi_split_reads2(const char *reads_fa, const char *ref_fa, int nsplit, const char *out_dir,
+                      const char *out_paf, int threads, int len_over, int mc, double iden,
+                      int long_mode);
+int hlmi_split_reads2_shard(const char *reads_fa, const char *ref_fa, int nsplit, const char *out_dir,
+                            const char *out_paf, int threads, int len_over, int mc, double iden,
+                            int long_mode, int rank, int world);
+/* merge of per-rank outputs = the final `sort -k12 -nr` of utils.py:69 */
+int hlmi_merge_scored_paf(const char *const *in_pafs, int n_in, const char *out_paf);
+
+/* ---- B2: one chunk of filter_overlap_slr2.main after the overlapper (slr2:57-152) ------- */
+/* paf_in: overlapper output (PAF with cg:Z: as LAST field, slr2:312).  Runs the v4 window
+ * filter (-len 30 -oh 3, slr2:51), the intermediate order (slr2:57), the SNP pile-up
+ * (slr2:229-367), mutation_re (slr2:370-405) and pass 2 (slr2:77-152) on the GPU and writes
+ * <chunk>_tmp_overlap4.paf-format rows (unsorted, in pass-2 order) to out_paf. */
+int hlmi_filter_chunk(const char *paf_in, const char *out_overlap4_paf, int len_over, int mc,
+                      double iden, double thre /*0.0025*/, int min_o /*4*/, int long_mode);
+
+/* ---- a4 / a17: filter_trans_ovlp_inline_v4.py:31-85 and _v3.py:39-102 ------------------- */
+/* variant 4: rows are copied through unchanged; variant 3: sfo != 0 writes SFO rows, else
+ * "q t score" rows.  min_iden < 0 selects the script default (0.6 for v4, 0.8 for v3). */
+int hlmi_paf_window_filter(int variant, int min_len, double min_iden, int min_o, int sfo,
+                           const char *in_paf, const char *out_path);
+
+/* ---- a3: the overlapper (replaces the external minimap2 call, slr2:51 / slr2:55) -------- */
+typedef struct {
+    int k;                 /* 19 (long, -Hk19) */
+    int w;                 /* 5  (ava-pb)      */
+    int hpc;               /* 1  (-H)          */
+    int min_chain_score;   /* 100   (-m100)    */
+    int max_gap;           /* 10000 (-g10000)  */
+    int bandwidth;         /* chaining band, 2000 */
+    int min_cnt;           /* 3 minimizers per chain (-n default) */
+    int min_mid_occ;       /* 10 */
+    double mid_occ_frac;   /* 2e-4 */
+    int match, mismatch, gap_open, gap_ext, ambi;   /* 2 4 4 2 1 */
+} hlmi_ava_opts;
+void hlmi_ava_opts_long(hlmi_ava_opts *o);   /* the constants of slr2:51 */
+/* target_fa = one chunk, query_fa = all reads; writes minimap2-style PAF rows (12 columns +
+ * NM, tp, cg:Z: tags, cg last) in query-file order. */
+int hlmi_ava(const char *target_fa, const char *query_fa, const hlmi_ava_opts *opts,
+             const char *out_paf);
+
+/* ---- B3: miniasm (tools/miniasm/main.c:32-211) with the flags HyLight passes ------------- */
+/* HyLight.py:137,140,171:  miniasm -d <bub_dist> -n <n_rounds_arg> -e <max_ext> -c <min_dp>
+ * -f <reads_fa> <paf> > <out_gfa>.  reads_fa may be NULL (S lines then carry '*').
+ * outfmt: "ug" (GFA, default when NULL), "sg", "paf", "bed" (main.c:146-150). */
+int hlmi_miniasm(const char *paf, const char *reads_fa, int bub_dist, int n_rounds_arg,
+                 int max_ext, int min_dp, const char *outfmt, const char *out_path);
+
+/* ---- a18: sfo2overlaps.py (--num_pairs 0 branch, HyLight.py:315-318) --------------------- */
+int hlmi_sfo2overlaps(const char *in_sfo, const char *out_savage, int num_singles, int num_pairs);
+
+/* ---- staged multi-GPU job: sketch shard -> (RCCL all-gather by the caller) -> run -------- */
+/* One process per GPU.  Every rank opens the same files, sketches its slice of the query
+ * reads into a caller-owned device buffer (16 B per minimizer: two uint64), the caller
+ * all-gathers the buffers over RCCL (torch.distributed), hands the gathered sketch back and
+ * runs its share of the target chunks. */
+typedef struct hlmi_job hlmi_job;
+hlmi_job *hlmi_job_open(const char *reads_fa, const char *ref_fa, int nsplit, int long_mode);
+void      hlmi_job_close(hlmi_job *j);
+int64_t   hlmi_job_num_queries(const hlmi_job *j);
+int64_t   hlmi_job_num_chunks(const hlmi_job *j);
+/* upper bound of minimizers for query reads [lo,hi): capacity needed by hlmi_job_sketch */
+int64_t   hlmi_job_sketch_bound(const hlmi_job *j, int64_t lo, int64_t hi);
+/* sketch query reads [lo,hi) on the GPU into dev_mz (capacity cap entries of 16 B), sorted by
+ * (read, position); per-read counts go to dev_counts[hi-lo] (uint32).  *n_out = entries. */
+int       hlmi_job_sketch(hlmi_job *j, int64_t lo, int64_t hi, void *dev_mz, int64_t cap,
+                          void *dev_counts, int64_t *n_out);
+/* install the complete query sketch (all reads, read-major): dev_mz[n] + dev_counts[nq] */
+int       hlmi_job_set_query_sketch(hlmi_job *j, const void *dev_mz, int64_t n, const void *dev_counts);
+/* overlap + filter the chunks {c : c % world == rank}; writes the rank's score-sorted PAF */
+int       hlmi_job_run(hlmi_job *j, int rank, int world, int len_over, int mc, double iden,
+                       const char *out_paf);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------- */
+/* Counters of the last stage run in this process: name -> value, written as JSON to buf. */
+int hlmi_last_stats_json(char *buf, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYLIGHT_MI_H */
