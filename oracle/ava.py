@@ -1,0 +1,64 @@
+"""ORACLE loader (test infrastructure): ctypes access to oracle/liboracle_ava.so, the CPU
+restatement of the overlapper spec (oracle/ava_oracle.c).  Never imported by hylight_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle_ava.so")
+
+
+class Opts(C.Structure):
+    _fields_ = [("k", C.c_int), ("w", C.c_int), ("hpc", C.c_int), ("min_chain_score", C.c_int),
+                ("max_gap", C.c_int), ("bandwidth", C.c_int), ("min_cnt", C.c_int),
+                ("min_mid_occ", C.c_int), ("mid_occ_frac", C.c_double),
+                ("match", C.c_int), ("mismatch", C.c_int), ("gap_open", C.c_int), ("gap_ext", C.c_int),
+                ("ambi", C.c_int)]
+
+
+def opts_long():
+    """The constants of script/filter_overlap_slr2.py:51 (ava-pb -Hk19 -m100 -g10000)."""
+    return Opts(19, 5, 1, 100, 10000, 2000, 3, 10, 2e-4, 2, 4, 4, 2, 1)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "ava_oracle.c")
+        if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
+        l = C.CDLL(_LIB)
+        l.oracle_hash64.restype = C.c_uint64
+        l.oracle_hash64.argtypes = [C.c_uint64, C.c_uint64]
+        l.oracle_sketch.restype = C.c_int64
+        l.oracle_sketch.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        l.oracle_ava.restype = C.c_int
+        l.oracle_ava.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Opts), C.c_char_p]
+        _lib = l
+    return _lib
+
+
+def hash64(key, mask):
+    return lib().oracle_hash64(key, mask)
+
+
+def sketch(seq: bytes, rid=0, k=19, w=5, hpc=1):
+    """(n,2) uint64 array of minimizers (x = hash<<8|span, y = rid<<32|pos<<1|strand)."""
+    cap = max(len(seq), 1)
+    out = np.zeros((cap, 2), dtype=np.uint64)
+    n = lib().oracle_sketch(seq, len(seq), rid, k, w, hpc, out.ctypes.data, cap)
+    return out[:n].copy()
+
+
+def ava(target_fa, query_fa, out_paf, opts=None):
+    o = opts or opts_long()
+    rc = lib().oracle_ava(os.fspath(target_fa).encode(), os.fspath(query_fa).encode(), C.byref(o),
+                          os.fspath(out_paf).encode())
+    if rc != 0:
+        raise RuntimeError(f"oracle_ava failed: {rc}")
+    return out_paf

@@ -1,0 +1,608 @@
+/* ORACLE (test infrastructure, NOT product code): sequential CPU restatement of the overlapper
+ * specification (DESIGN.md "Overlapper spec").
+ *
+ * PARITY UNPINNED against minimap2: the reference calls an external, un-vendored, un-pinned
+ * `minimap2` (lh3/minimap2; bioconda "latest", 2.28 series at the reference date) at
+ * script/filter_overlap_slr2.py:51 with `-x ava-pb -Hk19 -m100 -g10000 --max-chain-skip 25 -c
+ * --eqx`; no source, binary or golden PAF exists under /root/reference.  This file restates the
+ * PUBLISHED algorithm (Li 2016 Alg. 1-2, Li 2018 section 2.1) with the integer / fixed-window
+ * choices listed in DESIGN.md, and is the bit-exact oracle for the HIP kernels - not for
+ * minimap2.  Known answers pinned in tests/test_oracle_ava.py: the invertible hash, HPC edge
+ * cases, simulator truth (pair, strand, coordinates).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#include <ctype.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    int k, w, hpc, min_chain_score, max_gap, bandwidth, min_cnt, min_mid_occ;
+    double mid_occ_frac;
+    int match, mismatch, gap_open, gap_ext, ambi;
+} ava_opts_t;   /* same layout as hlmi_ava_opts (include/hylight_mi.h) */
+
+/* ---- fixed constants of the spec -------------------------------------------- */
+#define CHAIN_PRED   64      /* predecessors examined per anchor                            */
+#define BLOCK_MIN    64      /* min distance between alignment fixed points                 */
+#define BLOCK_MAX    256     /* max rows / cols of one alignment block                      */
+#define BAND_W       64      /* diagonals per block                                         */
+#define BAND_PAD     12      /* padding around [min(0,delta), max(0,delta)]                 */
+#define EXT_MAX      256     /* max rows of an end extension                                */
+#define MIN_DP_SCORE 80      /* alignment pieces below this DP score are dropped            */
+#define MAX_MID_OCC  1000000
+#define NEG_INF      (-(1 << 29))
+
+/* ---- sequences ---------------------------------------------------------------------------- */
+typedef struct {
+    int n;
+    char **name;
+    uint8_t **code;   /* 0..3 ACGT, 4 other */
+    int *len;
+    int *rank;        /* strcmp rank of the name among all names of both sets */
+} seqset_t;
+
+static int nt4(int c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return 4;
+    }
+}
+
+static void seqset_free(seqset_t *s) {
+    for (int i = 0; i < s->n; ++i) { free(s->name[i]); free(s->code[i]); }
+    free(s->name); free(s->code); free(s->len); free(s->rank);
+}
+
+/* FASTA/FASTQ, multi-line tolerant; name = header up to first blank */
+static int seqset_read(const char *path, seqset_t *s) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *d = (char *)malloc(sz + 1);
+    if (fread(d, 1, sz, f) != (size_t)sz) { fclose(f); free(d); return -1; }
+    d[sz] = 0;
+    fclose(f);
+    memset(s, 0, sizeof *s);
+    int cap = 0;
+    long p = 0;
+    while (p < sz) {
+        long e = p;
+        while (e < sz && d[e] != '\n') ++e;
+        if (d[p] == '>' || d[p] == '@') {
+            int fq = d[p] == '@';
+            if (s->n == cap) {
+                cap = cap ? cap * 2 : 1024;
+                s->name = (char **)realloc(s->name, cap * sizeof(char *));
+                s->code = (uint8_t **)realloc(s->code, cap * sizeof(uint8_t *));
+                s->len = (int *)realloc(s->len, cap * sizeof(int));
+            }
+            long q = p + 1;
+            while (q < e && !isspace((unsigned char)d[q])) ++q;
+            s->name[s->n] = strndup(d + p + 1, q - p - 1);
+            /* sequence lines */
+            long b = e + 1, tot = 0, capb = 0;
+            uint8_t *buf = 0;
+            while (b < sz && d[b] != '>' && d[b] != '@' && d[b] != '+') {
+                long e2 = b;
+                while (e2 < sz && d[e2] != '\n') ++e2;
+                long l = e2 - b;
+                if (l && d[e2 - 1] == '\r') --l;
+                if (tot + l > capb) { capb = (tot + l) * 2 + 16; buf = (uint8_t *)realloc(buf, capb); }
+                for (long i = 0; i < l; ++i) buf[tot + i] = (uint8_t)nt4(d[b + i]);
+                tot += l;
+                b = e2 + 1;
+            }
+            if (fq && b < sz && d[b] == '+') {
+                while (b < sz && d[b] != '\n') ++b;
+                ++b;
+                long ql = 0;
+                while (b < sz && ql < tot) {
+                    long e2 = b;
+                    while (e2 < sz && d[e2] != '\n') ++e2;
+                    ql += e2 - b;
+                    b = e2 + 1;
+                }
+            }
+            s->code[s->n] = buf ? buf : (uint8_t *)malloc(1);
+            s->len[s->n] = (int)tot;
+            ++s->n;
+            p = b;
+        } else p = e + 1;
+    }
+    free(d);
+    return 0;
+}
+
+/* ---- S1: sketch ----------------------------------------------------------------------------- */
+/* Thomas Wang's invertible integer hash as minimap2 uses it (Li 2016, section 2.2) */
+uint64_t oracle_hash64(uint64_t key, uint64_t mask) {
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+typedef struct { uint64_t x, y; } mz_t;   /* x = hash<<8 | span ; y = rid<<32 | pos<<1 | strand */
+
+/* Minimizers of one read, position order.  Returns the count (<= cap written). */
+int64_t oracle_sketch_codes(const uint8_t *c, int len, uint32_t rid, int k, int w, int hpc, mz_t *out, int64_t cap) {
+    if (len <= 0) return 0;
+    const uint64_t mask = (1ULL << 2 * k) - 1, shift = 2 * (k - 1);
+    uint64_t *sx = (uint64_t *)malloc((size_t)len * 8);    /* slot key (x) or UINT64_MAX */
+    uint32_t *sp = (uint32_t *)malloc((size_t)len * 4);    /* slot position<<1 | strand  */
+    int32_t *sl = (int32_t *)malloc((size_t)len * 4);      /* symbols since the last ambiguous base */
+    int *runq = (int *)calloc(k, sizeof(int));
+    int ns = 0, l = 0, qn = 0, qh = 0, span = 0;
+    uint64_t fwd = 0, rev = 0;
+    for (int i = 0; i < len; ++i) {
+        int b = c[i];
+        uint64_t x = UINT64_MAX;
+        uint32_t pz = 0;
+        if (b < 4) {
+            int run = 1;
+            if (hpc) {
+                while (i + run < len && c[i + run] == b) ++run;
+                i += run - 1;
+            }
+            if (hpc) {
+                if (qn == k) { span -= runq[qh]; runq[qh] = run; qh = (qh + 1) % k; }
+                else { runq[(qh + qn) % k] = run; ++qn; }
+                span += run;
+            } else span = l + 1 < k ? l + 1 : k;
+            fwd = (fwd << 2 | (uint64_t)b) & mask;
+            rev = (rev >> 2) | (3ULL ^ (uint64_t)b) << shift;
+            ++l;
+            if (l >= k && span < 256 && fwd != rev) {
+                int z = fwd < rev ? 0 : 1;
+                x = oracle_hash64(z ? rev : fwd, mask) << 8 | (uint64_t)span;
+                pz = (uint32_t)i << 1 | (uint32_t)z;
+            }
+        } else {
+            l = 0; qn = 0; qh = 0; span = 0;
+        }
+        sx[ns] = x; sp[ns] = pz; sl[ns] = l; ++ns;
+    }
+    int64_t n = 0;
+    for (int j = 0; j < ns; ++j) {
+        if (sx[j] == UINT64_MAX) continue;
+        int sel = 0;
+        for (int s = j; s < j + w && s < ns && !sel; ++s) {      /* windows [s-w+1, s] containing j */
+            if (sl[s] < w + k - 1 || s - w + 1 < 0) continue;      /* window not eligible */
+            uint64_t mn = UINT64_MAX;
+            for (int t = s - w + 1; t <= s; ++t) if (sx[t] < mn) mn = sx[t];
+            if (mn == sx[j]) sel = 1;
+        }
+        if (sel) {
+            if (n < cap) { out[n].x = sx[j]; out[n].y = (uint64_t)rid << 32 | sp[j]; }
+            ++n;
+        }
+    }
+    free(sx); free(sp); free(sl); free(runq);
+    return n;
+}
+
+int64_t oracle_sketch(const char *seq, int len, uint32_t rid, int k, int w, int hpc, uint64_t *out_xy, int64_t cap) {
+    uint8_t *c = (uint8_t *)malloc(len > 0 ? len : 1);
+    for (int i = 0; i < len; ++i) c[i] = (uint8_t)nt4(seq[i]);
+    int64_t n = oracle_sketch_codes(c, len, rid, k, w, hpc, (mz_t *)out_xy, cap);
+    free(c);
+    return n;
+}
+
+/* ---- S2: index of the target chunk ---------------------------------------------------------- */
+typedef struct { uint64_t key; uint64_t y; } ient_t;   /* key = hash (x>>8) */
+
+static int cmp_ient(const void *a, const void *b) {
+    const ient_t *x = (const ient_t *)a, *y = (const ient_t *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->y < y->y ? -1 : x->y > y->y ? 1 : 0;
+}
+static int cmp_u32(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+typedef struct {
+    ient_t *e;
+    int64_t n;
+    int mid_occ;
+} index_t;
+
+static void index_build(const seqset_t *T, const ava_opts_t *o, index_t *ix) {
+    int64_t cap = 0;
+    for (int i = 0; i < T->n; ++i) cap += T->len[i];
+    mz_t *tmp = (mz_t *)malloc((size_t)(cap + 1) * sizeof(mz_t));
+    ix->e = (ient_t *)malloc((size_t)(cap + 1) * sizeof(ient_t));
+    ix->n = 0;
+    for (int i = 0; i < T->n; ++i) {
+        int64_t m = oracle_sketch_codes(T->code[i], T->len[i], (uint32_t)i, o->k, o->w, o->hpc, tmp, cap);
+        for (int64_t j = 0; j < m; ++j) { ix->e[ix->n].key = tmp[j].x >> 8; ix->e[ix->n].y = tmp[j].y; ++ix->n; }
+    }
+    free(tmp);
+    qsort(ix->e, ix->n, sizeof(ient_t), cmp_ient);
+    /* occurrence threshold: count at the (1-f) quantile of distinct minimizers, +1, clamped */
+    uint32_t *cnt = (uint32_t *)malloc((size_t)(ix->n + 1) * 4);
+    int64_t nd = 0;
+    for (int64_t i = 0; i < ix->n;) {
+        int64_t j = i;
+        while (j < ix->n && ix->e[j].key == ix->e[i].key) ++j;
+        cnt[nd++] = (uint32_t)(j - i);
+        i = j;
+    }
+    ix->mid_occ = o->min_mid_occ;
+    if (nd) {
+        qsort(cnt, nd, 4, cmp_u32);
+        int64_t q = (int64_t)(uint32_t)((1.0 - o->mid_occ_frac) * (double)nd);
+        if (q >= nd) q = nd - 1;
+        int t = (int)cnt[q] + 1;
+        if (t > ix->mid_occ) ix->mid_occ = t;
+        if (ix->mid_occ > MAX_MID_OCC) ix->mid_occ = MAX_MID_OCC;
+    }
+    free(cnt);
+}
+
+static int64_t index_find(const index_t *ix, uint64_t key, int64_t *cnt) {
+    int64_t lo = 0, hi = ix->n;
+    while (lo < hi) { int64_t m = (lo + hi) >> 1; if (ix->e[m].key < key) lo = m + 1; else hi = m; }
+    int64_t j = lo;
+    while (j < ix->n && ix->e[j].key == key) ++j;
+    *cnt = j - lo;
+    return lo;
+}
+
+/* ---- S3: anchors ------------------------------------------------------------------------------ */
+typedef struct { uint32_t t, strand, tpos, qpos, qspan, gen; } anchor_t;   /* gen = generation order */
+
+static int cmp_anchor(const void *a, const void *b) {
+    const anchor_t *x = (const anchor_t *)a, *y = (const anchor_t *)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    if (x->strand != y->strand) return x->strand < y->strand ? -1 : 1;
+    if (x->tpos != y->tpos) return x->tpos < y->tpos ? -1 : 1;
+    if (x->gen != y->gen) return x->gen < y->gen ? -1 : 1;   /* stable: (query minimizer, occurrence) order */
+    return 0;
+}
+
+static int ilog2_32(uint32_t v) { int r = 0; while (v >>= 1) ++r; return r; }
+
+/* ---- S5: alignment ---------------------------------------------------------------------------- */
+typedef struct { uint32_t *op; int n, m; } cigar_t;   /* op = len<<4 | code ; '='7 'X'8 'I'1 'D'2 */
+static void cig_push(cigar_t *c, int code, int len) {
+    if (len <= 0) return;
+    if (c->n && (int)(c->op[c->n - 1] & 15) == code) { c->op[c->n - 1] += (uint32_t)len << 4; return; }
+    if (c->n == c->m) { c->m = c->m ? c->m * 2 : 64; c->op = (uint32_t *)realloc(c->op, c->m * 4); }
+    c->op[c->n++] = (uint32_t)len << 4 | (uint32_t)code;
+}
+
+static inline int sub_score(const ava_opts_t *o, int a, int b) {
+    if (a > 3 || b > 3) return -o->ambi;
+    return a == b ? o->match : -o->mismatch;
+}
+
+/* Banded affine DP over rows i=0..m (query), diagonals d=j-i in [dlo, dlo+BAND_W).
+ * q[i], t[j] are accessed through stride (+1 forward, -1 for left extensions).
+ * mode 0: global, must end at (m,n); returns score, ops appended in forward order.
+ * mode 1: extension, best cell (max H; ties: smaller i+j, then smaller i); *bi,*bj returned.
+ * Cells: H = max(M, E, F) with priority M, E, F on ties; E (gap in query, consumes target, 'D'),
+ * F (gap in target, consumes query, 'I'); open preferred over extend on ties. */
+static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, const uint8_t *t, int tstride, int n,
+                   int dlo, int mode, int *bi, int *bj, uint32_t *rev_ops, int *n_rev) {
+    const int W = BAND_W, go = o->gap_open, ge = o->gap_ext;
+    int rows = m + 1;
+    uint8_t *tb = (uint8_t *)malloc((size_t)rows * W);
+    int32_t *H = (int32_t *)malloc((size_t)rows * W * 4), *E = (int32_t *)malloc((size_t)rows * W * 4),
+            *F = (int32_t *)malloc((size_t)rows * W * 4);
+    int best = NEG_INF, best_i = 0, best_j = 0;
+    for (int i = 0; i <= m; ++i)
+        for (int dd = 0; dd < W; ++dd) {
+            int j = i + dlo + dd, idx = i * W + dd;
+            int h = NEG_INF, e = NEG_INF, f = NEG_INF;
+            uint8_t b = 0;
+            if (j >= 0 && j <= n) {
+                if (i == 0 && j == 0) h = 0;
+                else {
+                    int mm = NEG_INF;
+                    if (i > 0 && j > 0) {   /* diagonal: same dd in row i-1 */
+                        int hp = H[(i - 1) * W + dd];
+                        if (hp > NEG_INF) mm = hp + sub_score(o, q[(i - 1) * qstride], t[(j - 1) * tstride]);
+                    }
+                    if (j > 0 && dd > 0) {  /* horizontal: (i, j-1) = dd-1 same row */
+                        int hl = H[idx - 1], el = E[idx - 1];
+                        int open = hl > NEG_INF ? hl - go - ge : NEG_INF, ext = el > NEG_INF ? el - ge : NEG_INF;
+                        if (open >= ext) { e = open; } else { e = ext; b |= 4; }
+                    }
+                    if (i > 0 && dd + 1 < W) {  /* vertical: (i-1, j) = dd+1 in row i-1 */
+                        int hu = H[(i - 1) * W + dd + 1], fu = F[(i - 1) * W + dd + 1];
+                        int open = hu > NEG_INF ? hu - go - ge : NEG_INF, ext = fu > NEG_INF ? fu - ge : NEG_INF;
+                        if (open >= ext) { f = open; } else { f = ext; b |= 8; }
+                    }
+                    if (mm >= e && mm >= f) { h = mm; b |= 0; }
+                    else if (e >= f) { h = e; b |= 1; }
+                    else { h = f; b |= 2; }
+                    if (h < NEG_INF) h = NEG_INF;
+                }
+                if (mode == 1 && h > NEG_INF) {
+                    if (h > best || (h == best && (i + j < best_i + best_j || (i + j == best_i + best_j && i < best_i)))) {
+                        best = h; best_i = i; best_j = j;
+                    }
+                }
+            }
+            H[idx] = h; E[idx] = e; F[idx] = f; tb[idx] = b;
+        }
+    int ei, ej, score;
+    if (mode == 0) { ei = m; ej = n; score = H[m * W + (n - m - dlo)]; }
+    else { ei = best_i; ej = best_j; score = best; }
+    /* traceback */
+    int i = ei, j = ej, state = 0, nr = 0;
+    while (i > 0 || j > 0) {
+        int idx = i * W + (j - i - dlo);
+        uint8_t b = tb[idx];
+        if (state == 0) {
+            int src = b & 3;
+            if (src == 0) {
+                int eq = q[(i - 1) * qstride] == t[(j - 1) * tstride];
+                rev_ops[nr++] = eq ? 7 : 8;
+                --i; --j;
+            } else state = src;   /* 1: E, 2: F */
+        } else if (state == 1) {
+            rev_ops[nr++] = 2;   /* D */
+            if (!(b & 4)) state = 0;
+            --j;
+        } else {
+            rev_ops[nr++] = 1;   /* I */
+            if (!(b & 8)) state = 0;
+            --i;
+        }
+    }
+    *n_rev = nr;
+    if (bi) *bi = ei;
+    if (bj) *bj = ej;
+    free(tb); free(H); free(E); free(F);
+    return score;
+}
+
+typedef struct {
+    int qs, qe, ts, te;   /* aligned-orientation query coords, target coords */
+    int score;
+    cigar_t cg;
+} piece_t;
+
+/* global block between fixed points (q0,t0) -> (q1,t1); returns 0 if it violates the block limits */
+static int block_ok(int q0, int t0, int q1, int t1) {
+    int m = q1 - q0, n = t1 - t0, delta = n - m;
+    if (m < 0 || n < 0 || m > BLOCK_MAX || n > BLOCK_MAX) return 0;
+    if ((delta < 0 ? -delta : delta) + 2 * BAND_PAD + 1 > BAND_W) return 0;
+    return 1;
+}
+
+static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, int q0, int t0, int q1, int t1,
+                        piece_t *p, uint32_t *scratch) {
+    int m = q1 - q0, n = t1 - t0, delta = n - m, nr;
+    int dlo = (delta < 0 ? delta : 0) - BAND_PAD;
+    p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, 0, 0, 0, scratch, &nr);
+    for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
+}
+
+/* one chain (anchors ascending) -> alignment pieces -> PAF rows */
+static void emit_piece(FILE *out, const seqset_t *Q, int qi, const seqset_t *T, int ti, int strand, piece_t *p) {
+    if (p->cg.n && p->score >= MIN_DP_SCORE) {
+        long nm = 0, bl = 0;
+        for (int x = 0; x < p->cg.n; ++x) {
+            long l = p->cg.op[x] >> 4;
+            bl += l;
+            if ((p->cg.op[x] & 15) == 7) nm += l;
+        }
+        int ql = Q->len[qi];
+        int qs = strand ? ql - p->qe : p->qs, qe = strand ? ql - p->qs : p->qe;
+        fprintf(out, "%s\t%d\t%d\t%d\t%c\t%s\t%d\t%d\t%d\t%ld\t%ld\t0\tNM:i:%ld\ttp:A:S\tcg:Z:", Q->name[qi], ql, qs, qe,
+                strand ? '-' : '+', T->name[ti], T->len[ti], p->ts, p->te, nm, bl, bl - nm);
+        for (int x = 0; x < p->cg.n; ++x) {
+            static const char opc[16] = {'?', 'I', 'D', '?', '?', '?', '?', '=', 'X', '?', '?', '?', '?', '?', '?', '?'};
+            fprintf(out, "%u%c", p->cg.op[x] >> 4, opc[p->cg.op[x] & 15]);
+        }
+        fputc('\n', out);
+    }
+    p->cg.n = 0;
+    p->score = 0;
+}
+
+static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, piece_t *p, uint32_t *scratch) {
+    int m = p->qs < EXT_MAX ? p->qs : EXT_MAX, n = p->ts < EXT_MAX + BAND_W ? p->ts : EXT_MAX + BAND_W, bi, bj, nr;
+    if (m <= 0 || n <= 0) return;
+    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(BAND_W / 2 - 1), 1, &bi, &bj, scratch, &nr);
+    if (sc <= 0 || nr == 0) return;
+    /* rev_ops run from the far end towards the fixed point on reversed sequences = forward order */
+    cigar_t pre = {0, 0, 0};
+    for (int x = 0; x < nr; ++x) cig_push(&pre, (int)scratch[x], 1);
+    for (int x = 0; x < p->cg.n; ++x) cig_push(&pre, (int)(p->cg.op[x] & 15), (int)(p->cg.op[x] >> 4));
+    free(p->cg.op);
+    p->cg = pre;
+    p->qs -= bi; p->ts -= bj; p->score += sc;
+}
+
+static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const uint8_t *t, int tl, piece_t *p,
+                         uint32_t *scratch) {
+    int m = ql - p->qe < EXT_MAX ? ql - p->qe : EXT_MAX;
+    int n = tl - p->te < EXT_MAX + BAND_W ? tl - p->te : EXT_MAX + BAND_W, bi, bj, nr;
+    if (m <= 0 || n <= 0) return;
+    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(BAND_W / 2 - 1), 1, &bi, &bj, scratch, &nr);
+    if (sc <= 0 || nr == 0) return;
+    for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
+    p->qe += bi; p->te += bj; p->score += sc;
+}
+
+static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa /* aligned orientation */,
+                        const seqset_t *T, int ti, int strand, const anchor_t *a, const int *chain, int m) {
+    const uint8_t *t = T->code[ti];
+    int ql = Q->len[qi], tl = T->len[ti];
+    uint32_t *scratch = (uint32_t *)malloc((size_t)(2 * (EXT_MAX + BLOCK_MAX) + 2 * BAND_W + 8) * 4);
+    piece_t p;
+    memset(&p, 0, sizeof p);
+    int open = 0, cq = 0, ct = 0;   /* current fixed point */
+    for (int x = 0; x < m; ++x) {
+        const anchor_t *an = &a[chain[x]];
+        int qe = (int)an->qpos + 1, te = (int)an->tpos + 1;
+        if (!open) {    /* start a piece at the start of this anchor */
+            int sp = (int)an->qspan;
+            int q0 = qe - sp, t0 = te - sp;
+            if (q0 < 0 || t0 < 0) { int sh = q0 < t0 ? -q0 : -t0; q0 += sh; t0 += sh; }
+            if (q0 < 0) q0 = 0;
+            if (t0 < 0) t0 = 0;
+            if (!block_ok(q0, t0, qe, te)) continue;
+            p.qs = q0; p.ts = t0; p.score = 0; p.cg.n = 0;
+            align_block(o, qa, t, q0, t0, qe, te, &p, scratch);
+            cq = qe; ct = te; open = 1;
+            continue;
+        }
+        if (!((qe - cq >= BLOCK_MIN && te - ct >= BLOCK_MIN) || x == m - 1)) continue;
+        if (qe <= cq || te <= ct) continue;
+        if (block_ok(cq, ct, qe, te)) {
+            align_block(o, qa, t, cq, ct, qe, te, &p, scratch);
+            cq = qe; ct = te;
+        } else {        /* split: close the piece here, reopen at this anchor */
+            p.qe = cq; p.te = ct;
+            extend_left(o, qa, t, &p, scratch);
+            extend_right(o, qa, ql, t, tl, &p, scratch);
+            emit_piece(out, Q, qi, T, ti, strand, &p);
+            open = 0;
+            --x;        /* revisit this anchor as the start of a new piece */
+        }
+    }
+    if (open) {
+        p.qe = cq; p.te = ct;
+        extend_left(o, qa, t, &p, scratch);
+        extend_right(o, qa, ql, t, tl, &p, scratch);
+        emit_piece(out, Q, qi, T, ti, strand, &p);
+    }
+    free(p.cg.op);
+    free(scratch);
+}
+
+/* ---- S4: chaining of one (target, strand) group ------------------------------------------------ */
+/* DP: Li 2018 eq. (1)-(2) over the previous CHAIN_PRED anchors, integer gap cost
+ *     gamma(dd) = dd*k/100 + (floor(log2 dd) >> 1).
+ * Chain extraction (parallel-friendly restatement of "best-scoring chains first"): the parent links
+ * p[] form a forest; every anchor hands its trunk to its best child (larger f, then smaller index);
+ * a chain starts at every anchor that is not its parent's best child, follows best-child links and
+ * is cut at its highest-scoring anchor (first one on ties).  score = f[peak] - f[parent of start]. */
+static void chain_group(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa, const seqset_t *T,
+                        const anchor_t *a, int n) {
+    int32_t *f = (int32_t *)malloc(n * 4), *p = (int32_t *)malloc(n * 4), *bc = (int32_t *)malloc(n * 4);
+    for (int i = 0; i < n; ++i) {
+        int32_t best = (int32_t)a[i].qspan, bp = -1;
+        for (int j = i - 1; j >= 0 && j >= i - CHAIN_PRED; --j) {
+            int32_t dr = (int32_t)a[i].tpos - (int32_t)a[j].tpos, dq = (int32_t)a[i].qpos - (int32_t)a[j].qpos;
+            if (dr > o->max_gap) break;
+            if (dq <= 0 || dq > o->max_gap || dr == 0) continue;
+            int32_t dd = dr > dq ? dr - dq : dq - dr;
+            if (dd > o->bandwidth) continue;
+            int32_t dg = dr < dq ? dr : dq;
+            int32_t sc = dg < (int32_t)a[i].qspan ? dg : (int32_t)a[i].qspan;
+            int32_t pen = dd ? (dd * o->k) / 100 + (ilog2_32((uint32_t)dd) >> 1) : 0;
+            int32_t cand = f[j] + sc - pen;
+            if (cand > best) { best = cand; bp = j; }
+        }
+        f[i] = best; p[i] = bp;
+    }
+    for (int i = 0; i < n; ++i) bc[i] = -1;
+    for (int i = 0; i < n; ++i)            /* ascending i: a later child wins only with a strictly larger f */
+        if (p[i] >= 0 && (bc[p[i]] < 0 || f[i] > f[bc[p[i]]])) bc[p[i]] = i;
+    int *path = (int *)malloc(n * sizeof(int));
+    for (int s = 0; s < n; ++s) {
+        if (p[s] >= 0 && bc[p[s]] == s) continue;      /* continues its parent's chain */
+        int m = 0, best_len = 1, cur = s;
+        int32_t best_f = f[s];
+        path[m++] = s;
+        while (bc[cur] >= 0) {
+            cur = bc[cur];
+            path[m++] = cur;
+            if (f[cur] > best_f) { best_f = f[cur]; best_len = m; }
+        }
+        int32_t sc = best_f - (p[s] >= 0 ? f[p[s]] : 0);
+        if (sc < o->min_chain_score || best_len < o->min_cnt) continue;
+        align_chain(out, o, Q, qi, qa, T, (int)a[0].t, (int)a[0].strand, a, path, best_len);
+    }
+    free(f); free(p); free(bc); free(path);
+}
+
+/* ---- driver: one target chunk vs all queries ---------------------------------------------------- */
+static int cmp_str(const void *a, const void *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
+
+static void assign_ranks(seqset_t *T, seqset_t *Q) {
+    int n = T->n + Q->n;
+    char **all = (char **)malloc((size_t)(n ? n : 1) * sizeof(char *));
+    for (int i = 0; i < T->n; ++i) all[i] = T->name[i];
+    for (int i = 0; i < Q->n; ++i) all[T->n + i] = Q->name[i];
+    qsort(all, n, sizeof(char *), cmp_str);
+    T->rank = (int *)malloc((size_t)(T->n ? T->n : 1) * sizeof(int));
+    Q->rank = (int *)malloc((size_t)(Q->n ? Q->n : 1) * sizeof(int));
+    for (int s = 0; s < 2; ++s) {
+        seqset_t *S = s ? Q : T;
+        for (int i = 0; i < S->n; ++i) {   /* rank = index of the first equal name */
+            int lo = 0, hi = n;
+            while (lo < hi) { int m = (lo + hi) >> 1; if (strcmp(all[m], S->name[i]) < 0) lo = m + 1; else hi = m; }
+            S->rank[i] = lo;
+        }
+    }
+    free(all);
+}
+
+int oracle_ava(const char *target_fa, const char *query_fa, const ava_opts_t *o, const char *out_paf) {
+    seqset_t Ts, Qs, *T = &Ts, *Q = &Qs;
+    if (seqset_read(target_fa, T) != 0) return -2;
+    if (seqset_read(query_fa, Q) != 0) { seqset_free(T); return -2; }
+    if (!(o->k & 1) || o->k > 28 || o->w < 1 || o->w > 64) { seqset_free(T); seqset_free(Q); return -1; }
+    assign_ranks(T, Q);
+    FILE *out = fopen(out_paf, "w");
+    if (!out) { seqset_free(T); seqset_free(Q); return -2; }
+    index_t ix;
+    index_build(T, o, &ix);
+    int64_t qcap = 0;
+    for (int i = 0; i < Q->n; ++i) if (Q->len[i] > qcap) qcap = Q->len[i];
+    mz_t *qm = (mz_t *)malloc((size_t)(qcap + 1) * sizeof(mz_t));
+    uint8_t *qrc = (uint8_t *)malloc((size_t)qcap + 1);
+    anchor_t *an = 0;
+    int64_t an_cap = 0;
+    for (int qi = 0; qi < Q->n; ++qi) {
+        int ql = Q->len[qi];
+        int64_t nm = oracle_sketch_codes(Q->code[qi], ql, (uint32_t)qi, o->k, o->w, o->hpc, qm, qcap);
+        int64_t na = 0;
+        for (int64_t x = 0; x < nm; ++x) {
+            int64_t cnt, s = index_find(&ix, qm[x].x >> 8, &cnt);
+            if (cnt == 0 || cnt > ix.mid_occ) continue;
+            uint32_t qspan = (uint32_t)(qm[x].x & 0xff), qpos = (uint32_t)qm[x].y >> 1, qz = (uint32_t)qm[x].y & 1;
+            for (int64_t e = s; e < s + cnt; ++e) {
+                uint32_t t = (uint32_t)(ix.e[e].y >> 32), tpos = (uint32_t)ix.e[e].y >> 1, tz = (uint32_t)ix.e[e].y & 1;
+                if (Q->rank[qi] >= T->rank[t]) continue;   /* pair once: strcmp(q,t) < 0 only; self skipped */
+                if (na == an_cap) { an_cap = an_cap ? an_cap * 2 : 4096; an = (anchor_t *)realloc(an, an_cap * sizeof(anchor_t)); }
+                anchor_t *a = &an[na++];
+                a->t = t; a->strand = qz ^ tz; a->tpos = tpos; a->qspan = qspan; a->gen = (uint32_t)(na - 1);
+                a->qpos = a->strand ? (uint32_t)(ql - (int)(qpos + 1 - qspan) - 1) : qpos;
+            }
+        }
+        if (!na) continue;
+        qsort(an, na, sizeof(anchor_t), cmp_anchor);
+        for (int i = 0; i < ql; ++i) { uint8_t c = Q->code[qi][ql - 1 - i]; qrc[i] = c < 4 ? 3 - c : 4; }
+        for (int64_t b = 0; b < na;) {
+            int64_t e = b;
+            while (e < na && an[e].t == an[b].t && an[e].strand == an[b].strand) ++e;
+            chain_group(out, o, Q, qi, an[b].strand ? qrc : Q->code[qi], T, an + b, (int)(e - b));
+            b = e;
+        }
+    }
+    free(an); free(qm); free(qrc); free(ix.e);
+    fclose(out);
+    seqset_free(T); seqset_free(Q);
+    return 0;
+}
