@@ -1,9 +1,82 @@
-// ava.h - the overlapper: sketch -> index -> seed -> chain -> align -> PAF.
+// ava.h - the overlapper: sketch -> index -> seed -> chain -> align -> PAF rows.
+// Specification: DESIGN.md "Overlapper spec" (restated sequentially in oracle/ava_oracle.c, which the
+// kernels must match bit for bit).  Replaces the external minimap2 call of
+// script/filter_overlap_slr2.py:51.
 #pragma once
+#include <vector>
+
 #include "common.h"
+#include "paf_io.h"
 
 namespace hlmi {
+
+// ---- spec constants (same values as oracle/ava_oracle.c) -------------------------------------
+constexpr int CHAIN_PRED = 64;
+constexpr int BLOCK_MIN = 64;
+constexpr int BLOCK_MAX = 256;
+constexpr int BAND_W = 64;
+constexpr int BAND_PAD = 12;
+constexpr int EXT_MAX = 256;
+constexpr int MIN_DP_SCORE = 80;
+constexpr int MAX_MID_OCC = 1000000;
+constexpr int NEG_INF = -(1 << 29);
+
 hlmi_ava_opts ava_opts_long();
+
+struct Mz {                 // one minimizer, 16 B (the unit all-gathered between GPUs)
+    uint64_t x;             // hash << 8 | span
+    uint64_t y;             // read << 32 | pos << 1 | strand
+};
+
+struct DevReads {           // a read set resident in HBM: 1 B/base codes (0..3 ACGT, 4 other)
+    size_t n = 0;
+    uint64_t total = 0;
+    DBuf<uint8_t> codes;
+    DBuf<uint64_t> off;     // n+1 base offsets
+    std::vector<uint64_t> h_off;
+};
+// reads [lo,hi) of s, in order
+void upload_reads(const SeqSet &s, size_t lo, size_t hi, DevReads &out);
+void upload_reads(const SeqSet &s, const std::vector<uint32_t> &ids, DevReads &out);
+
+struct DevSketch {
+    size_t n = 0;
+    DBuf<Mz> mz;            // read-major, position order; y carries rid = rid_base + local index
+    DBuf<uint32_t> counts;  // per read
+};
+void sketch_device(const DevReads &r, int k, int w, int hpc, uint32_t rid_base, DevSketch &out);
+// same, into caller-owned buffers (multi-GPU staging); returns the number of minimizers
+int64_t sketch_device_into(const DevReads &r, int k, int w, int hpc, uint32_t rid_base, Mz *d_out, int64_t cap,
+                           uint32_t *d_counts);
+
+struct AvaInput {
+    const DevReads *T = nullptr;           // targets of this run (local ids 0..nT), grouped by chunk
+    const DevReads *Q = nullptr;           // all queries
+    const uint32_t *d_rank_t = nullptr;    // strcmp rank of each target / query name (equal names, equal rank)
+    const uint32_t *d_rank_q = nullptr;
+    const uint32_t *d_chunk_of_t = nullptr;  // chunk slot (0..n_chunks) of each local target
+    uint32_t n_chunks = 1;
+    const Mz *d_qmz = nullptr;             // complete query sketch
+    std::vector<uint64_t> qmz_off;         // host: nQ+1 offsets into d_qmz
+};
+
+struct AvaRows {            // overlapper output in stream order (chunk, query, target, strand, chain, piece)
+    size_t n_rows = 0, n_ops = 0;
+    DBuf<PafRec> recs;
+    DBuf<uint32_t> ops;
+    std::vector<uint64_t> chunk_row_start;   // n_chunks+1
+};
+void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out);
+
 // one target file vs one query file, PAF text out (the minimap2 call of filter_overlap_slr2.py:51)
 void ava_files(const char *target_fa, const char *query_fa, const hlmi_ava_opts &o, const char *out_paf);
+
+// strcmp ranks of the names of two sets over their union
+void name_ranks(const std::vector<std::string> &a, const std::vector<std::string> &b, std::vector<uint32_t> &ra,
+                std::vector<uint32_t> &rb, std::vector<std::string> &name_of_rank);
+
+// PAF text of one overlapper row (12 columns + NM, tp, cg)
+void format_ava_row(const PafRec &r, const uint32_t *ops, const std::string &qname, const std::string &tname,
+                    std::string &out);
+
 }  // namespace hlmi

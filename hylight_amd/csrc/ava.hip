@@ -1,0 +1,210 @@
+// ava.hip - overlapper orchestration: index once, then query batches of seed -> sort -> chain ->
+// align, rows gathered in HBM and put into stream order (chunk, query, target, strand, chain, piece).
+#include "ava.h"
+
+#include <algorithm>
+#include <numeric>
+
+#include "ava_internal.h"
+#include "dev_prims.h"
+
+namespace hlmi {
+
+namespace {
+constexpr int WG = 256;
+inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
+constexpr size_t ANCHOR_BATCH = 48u << 20;   // anchors per query batch (16 B each, x2 for the sort)
+constexpr size_t QUERY_BATCH = 2048;
+
+__global__ void lens_kernel(const uint64_t *off, size_t n, uint32_t *len) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) len[i] = (uint32_t)(off[i + 1] - off[i]);
+}
+__global__ void iota_kernel(uint32_t *a, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+__global__ void gather_u64_kernel(const uint64_t *src, const uint32_t *idx, uint64_t *dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void gather_rows_kernel(const PafRec *src, const uint32_t *idx, PafRec *dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PafRec r = src[idx[i]];
+    r.tie = (uint32_t)i;    // stream position: last-resort order of rows the overlapper itself emitted
+    dst[i] = r;
+}
+__global__ void shift_cigar_kernel(PafRec *recs, size_t n, uint64_t base) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) recs[i].cig_off += base;
+}
+}  // namespace
+
+hlmi_ava_opts ava_opts_long() {
+    // script/filter_overlap_slr2.py:51: -x ava-pb -Hk19 -m100 -g10000 (+ ava-pb: w=5; defaults -n3, A2 B4 O4 E2)
+    hlmi_ava_opts o{};
+    o.k = 19; o.w = 5; o.hpc = 1;
+    o.min_chain_score = 100; o.max_gap = 10000; o.bandwidth = 2000; o.min_cnt = 3;
+    o.min_mid_occ = 10; o.mid_occ_frac = 2e-4;
+    o.match = 2; o.mismatch = 4; o.gap_open = 4; o.gap_ext = 2; o.ambi = 1;
+    return o;
+}
+
+void name_ranks(const std::vector<std::string> &a, const std::vector<std::string> &b, std::vector<uint32_t> &ra,
+                std::vector<uint32_t> &rb, std::vector<std::string> &name_of_rank) {
+    std::vector<const std::string *> all;
+    all.reserve(a.size() + b.size());
+    for (auto &s : a) all.push_back(&s);
+    for (auto &s : b) all.push_back(&s);
+    std::sort(all.begin(), all.end(), [](const std::string *x, const std::string *y) { return *x < *y; });
+    name_of_rank.assign(all.size(), std::string());
+    auto rank_of = [&](const std::string &s) {
+        size_t lo = 0, hi = all.size();
+        while (lo < hi) {
+            size_t m = (lo + hi) >> 1;
+            if (*all[m] < s) lo = m + 1; else hi = m;
+        }
+        return (uint32_t)lo;
+    };
+    ra.resize(a.size());
+    rb.resize(b.size());
+    for (size_t i = 0; i < a.size(); ++i) { ra[i] = rank_of(a[i]); name_of_rank[ra[i]] = a[i]; }
+    for (size_t i = 0; i < b.size(); ++i) { rb[i] = rank_of(b[i]); name_of_rank[rb[i]] = b[i]; }
+}
+
+void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
+    out = AvaRows();
+    out.chunk_row_start.assign(in.n_chunks + 1, 0);
+    const size_t nQ = in.Q->n, nT = in.T->n;
+    if (!nQ || !nT) return;
+    DBuf<uint32_t> qlen(nQ), tlen(nT);
+    hipLaunchKernelGGL(lens_kernel, grid1(nQ), dim3(WG), 0, stream(), in.Q->off.p, nQ, qlen.p);
+    hipLaunchKernelGGL(lens_kernel, grid1(nT), dim3(WG), 0, stream(), in.T->off.p, nT, tlen.p);
+
+    // ---- S1 (targets) + S2 ---------------------------------------------------------------------------
+    DevSketch tsk;
+    sketch_device(*in.T, o.k, o.w, o.hpc, 0, tsk);
+    DevIndex ix;
+    build_index(tsk, in.d_chunk_of_t, in.n_chunks, o, ix);
+    tsk.mz.release();
+    stat_add("index_entries", (double)ix.n);
+
+    // ---- query batches ----------------------------------------------------------------------------------
+    std::vector<AlignOut> parts;
+    SeedStats st;
+    size_t q = 0;
+    while (q < nQ) {
+        size_t hi = std::min(nQ, q + QUERY_BATCH);
+        std::vector<uint64_t> per_q = count_anchors_per_query(in, ix, q, hi);
+        uint64_t acc = 0;
+        size_t take = 0;
+        while (take < per_q.size() && (take == 0 || acc + per_q[take] <= ANCHOR_BATCH)) acc += per_q[take++];
+        hi = q + take;
+        ChainOut ch;
+        seed_and_chain(in, ix, o, qlen.p, tlen.p, q, hi, ch, st);
+        stat_add("pieces", (double)ch.n_pieces);
+        if (ch.n_pieces) {
+            AlignOut ao;
+            align_pieces(in, o, qlen.p, tlen.p, ch, ao);
+            if (ao.n_rows) parts.push_back(std::move(ao));
+        }
+        q = hi;
+    }
+    stat_add("anchors", (double)st.anchors);
+    stat_add("chain_groups", (double)st.groups);
+
+    // ---- concatenate + stream order ---------------------------------------------------------------------
+    size_t R = 0, E = 0;
+    for (auto &p : parts) { R += p.n_rows; E += p.n_ops; }
+    stat_add("ava_rows", (double)R);
+    stat_add("cigar_ops", (double)E);
+    if (!R) return;
+    DBuf<PafRec> recs(R);
+    DBuf<uint64_t> hi64(R), lo64(R);
+    out.ops.alloc(E ? E : 1);
+    size_t r0 = 0, e0 = 0;
+    for (auto &p : parts) {
+        HIP_CHECK(hipMemcpyAsync(recs.p + r0, p.recs.p, p.n_rows * sizeof(PafRec), hipMemcpyDeviceToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(hi64.p + r0, p.ord_hi.p, p.n_rows * 8, hipMemcpyDeviceToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(lo64.p + r0, p.ord_lo.p, p.n_rows * 8, hipMemcpyDeviceToDevice, stream()));
+        if (p.n_ops) HIP_CHECK(hipMemcpyAsync(out.ops.p + e0, p.ops.p, p.n_ops * 4, hipMemcpyDeviceToDevice, stream()));
+        if (e0) hipLaunchKernelGGL(shift_cigar_kernel, grid1(p.n_rows), dim3(WG), 0, stream(), recs.p + r0, p.n_rows, (uint64_t)e0);
+        r0 += p.n_rows;
+        e0 += p.n_ops;
+    }
+    sync();
+    parts.clear();
+    DBuf<uint32_t> perm(R);
+    hipLaunchKernelGGL(iota_kernel, grid1(R), dim3(WG), 0, stream(), perm.p, R);
+    sort_pairs_u64_u32(lo64.p, perm.p, R);
+    DBuf<uint64_t> hi_g(R);
+    hipLaunchKernelGGL(gather_u64_kernel, grid1(R), dim3(WG), 0, stream(), hi64.p, perm.p, hi_g.p, R);
+    sort_pairs_u64_u32(hi_g.p, perm.p, R);
+    out.recs.alloc(R);
+    hipLaunchKernelGGL(gather_rows_kernel, grid1(R), dim3(WG), 0, stream(), recs.p, perm.p, out.recs.p, R);
+    HIP_CHECK(hipGetLastError());
+    std::vector<uint64_t> h_hi = hi_g.download(R);
+    out.n_rows = R;
+    out.n_ops = E;
+    size_t i = 0;
+    for (uint32_t c = 0; c < in.n_chunks; ++c) {
+        out.chunk_row_start[c] = i;
+        while (i < R && (uint32_t)(h_hi[i] >> 32) == c) ++i;
+    }
+    out.chunk_row_start[in.n_chunks] = R;
+}
+
+void format_ava_row(const PafRec &r, const uint32_t *ops, const std::string &qname, const std::string &tname,
+                    std::string &out) {
+    char buf[256];
+    out.assign(qname);
+    int m = snprintf(buf, sizeof buf, "\t%u\t%u\t%u\t%c\t", r.qlen, r.qs, r.qe, (r.flags & PF_REV) ? '-' : '+');
+    out.append(buf, m);
+    out.append(tname);
+    m = snprintf(buf, sizeof buf, "\t%u\t%u\t%u\t%u\t%u\t0\tNM:i:%u\ttp:A:S\tcg:Z:", r.tlen, r.ts, r.te, r.nmatch, r.blen,
+                 r.blen - r.nmatch);
+    out.append(buf, m);
+    static const char opc[16] = {'?', 'I', 'D', '?', '?', '?', '?', '=', 'X', '?', '?', '?', '?', '?', '?', '?'};
+    for (uint32_t i = 0; i < r.cig_n; ++i) {
+        m = snprintf(buf, sizeof buf, "%u%c", ops[i] >> 4, opc[ops[i] & 15]);
+        out.append(buf, m);
+    }
+}
+
+void ava_files(const char *target_fa, const char *query_fa, const hlmi_ava_opts &o, const char *out_paf) {
+    stat_reset();
+    SeqSet T, Q;
+    read_seqs(target_fa, T);
+    read_seqs(query_fa, Q);
+    std::vector<uint32_t> rt, rq;
+    std::vector<std::string> name_of_rank;
+    name_ranks(T.names, Q.names, rt, rq, name_of_rank);
+    DevReads dT, dQ;
+    upload_reads(T, 0, T.size(), dT);
+    upload_reads(Q, 0, Q.size(), dQ);
+    DBuf<uint32_t> d_rt, d_rq, d_chunk(T.size() ? T.size() : 1);
+    d_rt.upload(rt);
+    d_rq.upload(rq);
+    if (rt.empty()) d_rt.alloc(1);
+    if (rq.empty()) d_rq.alloc(1);
+    d_chunk.zero();
+    DevSketch qsk;
+    sketch_device(dQ, o.k, o.w, o.hpc, 0, qsk);
+    std::vector<uint32_t> qc = qsk.counts.download(Q.size());
+    AvaInput in;
+    in.T = &dT; in.Q = &dQ; in.d_rank_t = d_rt.p; in.d_rank_q = d_rq.p; in.d_chunk_of_t = d_chunk.p; in.n_chunks = 1;
+    in.d_qmz = qsk.mz.p;
+    in.qmz_off.assign(Q.size() + 1, 0);
+    for (size_t i = 0; i < Q.size(); ++i) in.qmz_off[i + 1] = in.qmz_off[i] + qc[i];
+    AvaRows rows;
+    ava_device(in, o, rows);
+    std::vector<PafRec> hr = rows.recs.download(rows.n_rows);
+    std::vector<uint32_t> hops = rows.ops.download(rows.n_ops);
+    std::vector<std::string> lines(rows.n_rows);
+    for (size_t i = 0; i < rows.n_rows; ++i)
+        format_ava_row(hr[i], hops.data() + hr[i].cig_off, name_of_rank[hr[i].qid], name_of_rank[hr[i].tid], lines[i]);
+    write_lines(out_paf, lines);
+}
+
+}  // namespace hlmi

@@ -1,0 +1,397 @@
+// ava_align.hip - S5 of the overlapper spec: base-level alignment of the chain pieces.
+//
+// Every piece is a list of fixed points; consecutive fixed points bound an independent global
+// alignment block (<= 256 x 256, |diagonal shift| <= 39) and the two piece ends get a local
+// extension (<= 256 rows).  One wavefront per task:
+//   * the 64 lanes are the 64 diagonals of the band, rows are processed one by one;
+//   * affine gaps (Gotoh): the vertical gap F comes from lane d+1 of the previous row, the
+//     horizontal gap E from a max-plus prefix scan across the lanes of the current row
+//     (E(d) = max_{d'<d} Ht(d') - open - ext*(d-d'));
+//   * the 4 traceback bits per cell are written as 4 wave ballots (32 B per row) into LDS;
+//   * lane 0 walks the traceback and run-length encodes the =/X/I/D ops.
+// The recurrences, tie rules and the best-cell rule of the extensions are those of
+// oracle/ava_oracle.c:band_dp.  LDS/VALU bound by nature: reads ~1 B per
+// DP row per sequence from HBM.
+#include <algorithm>
+
+#include "ava_internal.h"
+#include "dev_prims.h"
+
+namespace hlmi {
+
+namespace {
+constexpr int WG = 256;
+constexpr int WAVES = WG / 64;
+constexpr int TB_ROWS = 257;
+constexpr int SEQ_T_MAX = EXT_MAX + BAND_W;     // 320
+constexpr int UNIT_MAX = EXT_MAX + SEQ_T_MAX + 16;
+inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
+
+struct Task {               // 32 B
+    uint32_t piece;
+    uint32_t kind;          // 0 block, 1 left extension, 2 right extension
+    int32_t q0, t0;         // block: start fixed point; extensions: the fixed point extended from
+    int32_t m, n;           // rows (query), cols (target)
+    int32_t dlo;            // first diagonal of the band
+    uint32_t pad;
+};
+struct TaskOut {            // 24 B
+    int32_t score;
+    int32_t bi, bj;         // extension: rows / cols consumed
+    uint32_t runs_off, n_runs;
+    uint32_t pad;
+};
+
+__global__ void piece_task_count_kernel(const Piece *pieces, size_t n, uint32_t *cnt) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = pieces[i].n_fp + 1;      // (n_fp - 1) blocks + 2 extensions
+}
+
+__global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const uint32_t *task_off, size_t n,
+                                  const uint32_t *qlen, const uint32_t *tlen, Task *tasks) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Piece p = pieces[i];
+    Task *out = tasks + task_off[i];
+    const FixPt *fp = fps + p.fp_off;
+    const int ql = (int)qlen[p.q], tl = (int)tlen[p.t];
+    {   // left extension
+        const int qs = (int)fp[0].q, ts = (int)fp[0].t;
+        Task t{(uint32_t)i, 1u, qs, ts, qs < EXT_MAX ? qs : EXT_MAX, ts < SEQ_T_MAX ? ts : SEQ_T_MAX, -(BAND_W / 2 - 1), 0};
+        out[0] = t;
+    }
+    for (uint32_t b = 0; b + 1 < p.n_fp; ++b) {
+        const int q0 = (int)fp[b].q, t0 = (int)fp[b].t, m = (int)fp[b + 1].q - q0, n2 = (int)fp[b + 1].t - t0;
+        const int delta = n2 - m;
+        Task t{(uint32_t)i, 0u, q0, t0, m, n2, (delta < 0 ? delta : 0) - BAND_PAD, 0};
+        out[1 + b] = t;
+    }
+    {   // right extension
+        const int qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
+        const int m = ql - qe < EXT_MAX ? ql - qe : EXT_MAX, n2 = tl - te < SEQ_T_MAX ? tl - te : SEQ_T_MAX;
+        Task t{(uint32_t)i, 2u, qe, te, m, n2, -(BAND_W / 2 - 1), 0};
+        out[p.n_fp] = t;
+    }
+}
+
+struct AlignArgs {
+    const Task *tasks;
+    size_t n_tasks;
+    const Piece *pieces;
+    const uint8_t *qcodes, *tcodes;
+    const uint64_t *qoff, *toff;
+    const uint32_t *qlen;
+    int match, mismatch, go, ge, ambi;
+    TaskOut *out;
+    uint32_t *runs;
+    uint32_t cap_runs;
+    uint32_t *counters;     // [0] runs cursor, [1] overflow
+};
+
+__device__ __forceinline__ int wave_prefix_max_excl(int v, int lane) {
+    // inclusive scan with max, then shift by one lane
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(v, o, 64);
+        if (lane >= o) v = u > v ? u : v;
+    }
+    int r = __shfl_up(v, 1, 64);
+    return lane == 0 ? NEG_INF * 2 : r;
+}
+
+__global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
+    __shared__ unsigned long long s_tb[WAVES][TB_ROWS][4];
+    __shared__ uint8_t s_q[WAVES][EXT_MAX];
+    __shared__ uint8_t s_t[WAVES][SEQ_T_MAX];
+    __shared__ uint8_t s_u[WAVES][UNIT_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long(*tb)[4] = s_tb[wv];
+    uint8_t *sq = s_q[wv], *st = s_t[wv], *su = s_u[wv];
+    for (size_t ti = wave; ti < a.n_tasks; ti += n_waves) {
+        const Task tk = a.tasks[ti];
+        TaskOut res{0, 0, 0, 0, 0, 0};
+        const int m = tk.m, n = tk.n;
+        if (m <= 0 || n <= 0) {
+            if (lane == 0) a.out[ti] = res;
+            continue;
+        }
+        const Piece pc = a.pieces[tk.piece];
+        const uint8_t *qb = a.qcodes + a.qoff[pc.q];
+        const uint8_t *tbs = a.tcodes + a.toff[pc.t];
+        const int ql = (int)a.qlen[pc.q];
+        // ---- stage the two windows in LDS (aligned orientation, DP order) ---------------------------------
+        for (int x = lane; x < m; x += 64) {
+            const int pos = tk.kind == 1 ? tk.q0 - 1 - x : tk.q0 + x;       // aligned-orientation index
+            uint8_t c;
+            if (pc.strand) { c = qb[ql - 1 - pos]; c = c < 4 ? 3 - c : 4; } else c = qb[pos];
+            sq[x] = c;
+        }
+        for (int x = lane; x < n; x += 64) st[x] = tbs[tk.kind == 1 ? tk.t0 - 1 - x : tk.t0 + x];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ---- DP ------------------------------------------------------------------------------------------------
+        const int dlo = tk.dlo, go = a.go, ge = a.ge;
+        int Hp = NEG_INF, Fp = NEG_INF;
+        unsigned long long best = 0;
+        for (int i = 0; i <= m; ++i) {
+            const int j = i + dlo + lane;
+            const bool valid = j >= 0 && j <= n;
+            int Hup = __shfl_down(Hp, 1, 64), Fup = __shfl_down(Fp, 1, 64);
+            if (lane == 63) { Hup = NEG_INF; Fup = NEG_INF; }
+            int mm = NEG_INF, f = NEG_INF;
+            bool flagF = false;
+            if (valid && i > 0) {
+                if (j > 0) {
+                    const int qa = sq[i - 1], tb2 = st[j - 1];
+                    const int s = (qa > 3 || tb2 > 3) ? -a.ambi : (qa == tb2 ? a.match : -a.mismatch);
+                    mm = Hp + s;
+                }
+                if (lane < 63) {
+                    const int fo = Hup - go - ge, fe = Fup - ge;
+                    if (fo >= fe) f = fo; else { f = fe; flagF = true; }
+                }
+            }
+            int ht = mm > f ? mm : f;
+            if (i == 0 && j == 0) ht = 0;
+            if (!valid) ht = NEG_INF;
+            const int pm = wave_prefix_max_excl(ht + ge * lane, lane);
+            int e = NEG_INF;
+            if (valid && j > 0 && lane > 0) e = pm - go - ge * lane;
+            int h, src;
+            if (i == 0 && j == 0) { h = 0; src = 0; }
+            else if (mm >= e && mm >= f) { h = mm; src = 0; }
+            else if (e >= f) { h = e; src = 1; }
+            else { h = f; src = 2; }
+            if (!valid) { h = NEG_INF; f = NEG_INF; e = NEG_INF; }
+            const int Hl = __shfl_up(h, 1, 64), El = __shfl_up(e, 1, 64);
+            const bool flagE = lane > 0 && !(Hl - go - ge >= El - ge);
+            const unsigned long long b0 = __ballot(src & 1), b1 = __ballot(src & 2), b2 = __ballot(flagE), b3 = __ballot(flagF);
+            if (lane == 0) { tb[i][0] = b0; tb[i][1] = b1; tb[i][2] = b2; tb[i][3] = b3; }
+            if (tk.kind != 0 && valid && h > NEG_INF / 2) {
+                const unsigned long long key = (unsigned long long)(uint32_t)(h + (1 << 20)) << 32 |
+                                               (unsigned long long)(0xffffu - (uint32_t)(i + j)) << 16 |
+                                               (unsigned long long)(0xffffu - (uint32_t)i);
+                best = key > best ? key : best;
+            }
+            Hp = h;
+            Fp = f;
+        }
+        int ei, ej, score;
+        if (tk.kind == 0) {
+            ei = m; ej = n;
+            score = __shfl(Hp, n - m - dlo, 64);
+        } else {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned long long u = __shfl_xor(best, o, 64);
+                best = u > best ? u : best;
+            }
+            score = (int)(uint32_t)(best >> 32) - (1 << 20);
+            ei = (int)(0xffffu - (uint32_t)(best & 0xffff));
+            ej = (int)(0xffffu - (uint32_t)((best >> 16) & 0xffff)) - ei;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ---- traceback + run-length encoding by lane 0 --------------------------------------------------------
+        if (lane == 0) {
+            int i = ei, j = ej, state = 0, nr = 0;
+            while (i > 0 || j > 0) {
+                const int d = j - i - dlo;
+                const unsigned long long bit = 1ull << d;
+                if (state == 0) {
+                    const int src = ((tb[i][0] & bit) ? 1 : 0) | ((tb[i][1] & bit) ? 2 : 0);
+                    if (src == 0) {
+                        su[nr++] = sq[i - 1] == st[j - 1] ? (uint8_t)OP_EQ : (uint8_t)OP_X;
+                        --i; --j;
+                    } else state = src;
+                } else if (state == 1) {
+                    su[nr++] = (uint8_t)OP_D;
+                    if (!(tb[i][2] & bit)) state = 0;
+                    --j;
+                } else {
+                    su[nr++] = (uint8_t)OP_I;
+                    if (!(tb[i][3] & bit)) state = 0;
+                    --i;
+                }
+            }
+            // forward order: blocks and right extensions reverse the emission order, left extensions keep it
+            const bool fwd = tk.kind == 1;
+            uint32_t n_runs = 0;
+            for (int x = 0; x < nr; ++x) {
+                const int y = fwd ? x : nr - 1 - x, yp = fwd ? x - 1 : nr - x;
+                if (x == 0 || su[y] != su[yp]) ++n_runs;
+            }
+            uint32_t off = 0;
+            bool ok = true;
+            if (n_runs) {
+                off = atomicAdd(&a.counters[0], n_runs);
+                if (off + n_runs > a.cap_runs) { a.counters[1] = 1; ok = false; }
+            }
+            if (ok && n_runs) {
+                uint32_t w = off, len = 0;
+                uint8_t code = 0;
+                for (int x = 0; x < nr; ++x) {
+                    const uint8_t c = su[fwd ? x : nr - 1 - x];
+                    if (x && c != code) { a.runs[w++] = len << 4 | code; len = 0; }
+                    code = c;
+                    ++len;
+                }
+                a.runs[w++] = len << 4 | code;
+            }
+            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0;
+            a.out[ti] = res;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- assembly of the task results into PAF rows ----------------------------------------------------------
+struct AsmArgs {
+    const Piece *pieces;
+    const FixPt *fps;
+    const uint32_t *task_off;
+    const TaskOut *tout;
+    const uint32_t *runs;
+    size_t n_pieces;
+    const uint32_t *qlen, *tlen, *rank_q, *rank_t, *chunk_of_t;
+};
+
+template <bool WRITE>
+__global__ void assemble_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, const uint64_t *ops_off, uint32_t *ops,
+                                PafRec *recs, uint64_t *ord_hi, uint64_t *ord_lo) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= a.n_pieces) return;
+    if (WRITE && !valid[i]) return;
+    const Piece p = a.pieces[i];
+    const FixPt *fp = a.fps + p.fp_off;
+    const TaskOut *to = a.tout + a.task_off[i];
+    const uint32_t n_tasks = p.n_fp + 1;
+    int qs = (int)fp[0].q, ts = (int)fp[0].t, qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
+    long long score = 0;
+    uint32_t cnt = 0, last_code = 99;
+    uint64_t nmatch = 0, blen = 0;
+    uint32_t *w = WRITE ? ops + ops_off[i] : nullptr;
+    for (uint32_t t = 0; t < n_tasks; ++t) {
+        const TaskOut r = to[t];
+        const bool is_ext = t == 0 || t == n_tasks - 1;
+        if (is_ext) {
+            if (r.score <= 0 || r.n_runs == 0) continue;
+            if (t == 0) { qs -= r.bi; ts -= r.bj; } else { qe += r.bi; te += r.bj; }
+        }
+        score += r.score;
+        for (uint32_t x = 0; x < r.n_runs; ++x) {
+            const uint32_t run = a.runs[r.runs_off + x], code = run & 15u, len = run >> 4;
+            if (code == last_code) {
+                if (WRITE) w[cnt - 1] += len << 4;
+            } else {
+                if (WRITE) w[cnt] = run;
+                ++cnt;
+                last_code = code;
+            }
+            blen += len;
+            if (code == OP_EQ) nmatch += len;
+        }
+    }
+    if (!WRITE) {
+        const bool ok = cnt > 0 && score >= MIN_DP_SCORE;
+        valid[i] = ok ? 1 : 0;
+        n_ops[i] = ok ? cnt : 0;
+        return;
+    }
+    const uint32_t ql = a.qlen[p.q];
+    PafRec r{};
+    r.qid = a.rank_q[p.q]; r.tid = a.rank_t[p.t];
+    r.qlen = ql; r.tlen = a.tlen[p.t];
+    r.qs = p.strand ? ql - (uint32_t)qe : (uint32_t)qs;
+    r.qe = p.strand ? ql - (uint32_t)qs : (uint32_t)qe;
+    r.ts = (uint32_t)ts; r.te = (uint32_t)te;
+    r.nmatch = (uint32_t)nmatch; r.blen = (uint32_t)blen;
+    r.flags = p.strand ? PF_REV : 0;
+    r.chunk = a.chunk_of_t[p.t];
+    r.cig_off = ops_off[i]; r.cig_n = cnt; r.tie = 0;
+    recs[i] = r;
+    ord_hi[i] = (uint64_t)r.chunk << 32 | p.q;
+    ord_lo[i] = (uint64_t)p.t << 43 | (uint64_t)p.strand << 42 | (uint64_t)(p.chain & 0x3fffffu) << 20 | (p.piece & 0xfffffu);
+}
+
+__global__ void compact_rows_kernel(const uint32_t *idx, size_t n, const PafRec *recs, const uint64_t *hi,
+                                    const uint64_t *lo, PafRec *orecs, uint64_t *ohi, uint64_t *olo) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    orecs[i] = recs[idx[i]];
+    ohi[i] = hi[idx[i]];
+    olo[i] = lo[idx[i]];
+}
+}  // namespace
+
+void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
+                  const ChainOut &ch, AlignOut &out) {
+    out = AlignOut();
+    const size_t P = ch.n_pieces;
+    if (!P) return;
+    DBuf<uint32_t> tcnt(P), toff(P);
+    hipLaunchKernelGGL(piece_task_count_kernel, grid1(P), dim3(WG), 0, stream(), ch.pieces.p, P, tcnt.p);
+    exclusive_scan_u32(tcnt.p, toff.p, P);
+    const size_t NT = (size_t)download_one(toff.p + (P - 1)) + download_one(tcnt.p + (P - 1));
+    DBuf<Task> tasks(NT);
+    hipLaunchKernelGGL(make_tasks_kernel, grid1(P), dim3(WG), 0, stream(), ch.pieces.p, ch.fps.p, toff.p, P, d_qlen, d_tlen,
+                       tasks.p);
+    HIP_CHECK(hipGetLastError());
+    DBuf<TaskOut> tout(NT);
+    DBuf<uint32_t> counters(2);
+    size_t cap_runs = std::max<size_t>(NT * 24, 1 << 16);
+    DBuf<uint32_t> runs;
+    for (int attempt = 0;; ++attempt) {
+        if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
+        runs.alloc(cap_runs);
+        counters.zero();
+        AlignArgs aa{};
+        aa.tasks = tasks.p; aa.n_tasks = NT; aa.pieces = ch.pieces.p;
+        aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p; aa.qoff = in.Q->off.p; aa.toff = in.T->off.p;
+        aa.qlen = d_qlen;
+        aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
+        aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
+        const unsigned nb = (unsigned)std::min<size_t>((NT + WAVES - 1) / WAVES, 256 * 16);
+        hipLaunchKernelGGL(align_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+        HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> hc = counters.download(2);
+        if (!hc[1]) break;
+        if (attempt >= 3) fail(HLMI_ENOMEM, "CIGAR run pool overflow");
+        cap_runs *= 4;
+    }
+    stat_add("align_tasks", (double)NT);
+    // assemble
+    AsmArgs as{};
+    as.pieces = ch.pieces.p; as.fps = ch.fps.p; as.task_off = toff.p; as.tout = tout.p; as.runs = runs.p; as.n_pieces = P;
+    as.qlen = d_qlen; as.tlen = d_tlen; as.rank_q = in.d_rank_q; as.rank_t = in.d_rank_t; as.chunk_of_t = in.d_chunk_of_t;
+    DBuf<uint32_t> nops(P);
+    DBuf<uint8_t> valid(P);
+    hipLaunchKernelGGL(assemble_kernel<false>, grid1(P), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
+                       nullptr, nullptr, nullptr);
+    HIP_CHECK(hipGetLastError());
+    DBuf<uint64_t> ooff(P);
+    exclusive_scan_u32_to_u64(nops.p, ooff.p, P);
+    const size_t n_ops = (size_t)(download_one(ooff.p + (P - 1)) + download_one(nops.p + (P - 1)));
+    DBuf<uint32_t> vidx(P);
+    const size_t R = select_flagged_indices(valid.p, vidx.p, P);
+    if (!R) return;
+    out.ops.alloc(n_ops ? n_ops : 1);
+    DBuf<PafRec> recs(P);
+    DBuf<uint64_t> hi(P), lo(P);
+    hipLaunchKernelGGL(assemble_kernel<true>, grid1(P), dim3(WG), 0, stream(), as, nullptr, valid.p, ooff.p, out.ops.p,
+                       recs.p, hi.p, lo.p);
+    HIP_CHECK(hipGetLastError());
+    out.recs.alloc(R);
+    out.ord_hi.alloc(R);
+    out.ord_lo.alloc(R);
+    hipLaunchKernelGGL(compact_rows_kernel, grid1(R), dim3(WG), 0, stream(), vidx.p, R, recs.p, hi.p, lo.p, out.recs.p,
+                       out.ord_hi.p, out.ord_lo.p);
+    HIP_CHECK(hipGetLastError());
+    sync();
+    out.n_rows = R;
+    out.n_ops = n_ops;
+}
+
+}  // namespace hlmi

@@ -1,0 +1,441 @@
+// ava_chain.hip - S2 index, S3 seeding, S4 chaining of the overlapper spec.
+//
+//   index   : target minimizers radix-sorted by hash; per (hash, chunk) occurrence counts; per-chunk
+//             occurrence cut-off from the count histogram (Li 2016 section 2.3: drop the top fraction)
+//   seeds   : one thread per query minimizer: binary search of the hash, walk of its occurrence run,
+//             pair-once rule strcmp(qname,tname) < 0 (ava "no dual / no diagonal"), anchors packed as
+//             key = qlocal:11 | target:21 | strand:1 | tpos:31 ,  val = qpos:32 | qspan:8
+//   order   : one stable 64-bit radix sort per query batch (generation order breaks ties)
+//   chains  : one wavefront per (query,target,strand) group.  The DP keeps the previous 64 anchors in
+//             a register ring (lane l = predecessor i-1-l), every lane scores one predecessor and a
+//             wave max-reduction picks the best (Li 2018 eq. 1-2, integer gap cost); chain extraction
+//             hands each anchor's trunk to its best child (64-bit atomicMax) and lets every lane walk
+//             one chain: cut at the peak, split into alignment pieces of fixed points.
+// Integer / index work throughout: HBM- and latency-bound, no MFMA.
+#include <algorithm>
+
+#include "ava_internal.h"
+#include "dev_prims.h"
+
+namespace hlmi {
+
+namespace {
+constexpr int WG = 256;
+constexpr int HB = 1024;             // occurrence histogram bins per chunk
+constexpr int QL_BITS = 11, T_BITS = 21, TPOS_BITS = 31;
+inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
+
+__device__ __forceinline__ size_t lower_bound_u64(const uint64_t *a, size_t n, uint64_t v) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t m = (lo + hi) >> 1;
+        if (a[m] < v) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+__device__ __forceinline__ size_t upper_bound_u32(const uint32_t *a, size_t n, uint32_t v) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t m = (lo + hi) >> 1;
+        if (a[m] <= v) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------------------------
+__global__ void split_mz_kernel(const Mz *mz, size_t n, uint64_t *key, uint64_t *y) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = mz[i].x >> 8;
+    y[i] = mz[i].y;
+}
+__global__ void index_head_kernel(const uint64_t *key, const uint64_t *y, const uint32_t *chunk_of_t, size_t n,
+                                  uint8_t *head) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || key[i] != key[i - 1] || chunk_of_t[y[i] >> 32] != chunk_of_t[y[i - 1] >> 32]) ? 1 : 0;
+}
+__global__ void index_occ_kernel(const uint32_t *run_start, size_t n_runs, size_t n, uint32_t *occ) {
+    size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    size_t r = upper_bound_u32(run_start, n_runs, (uint32_t)e) - 1;
+    size_t end = r + 1 < n_runs ? run_start[r + 1] : n;
+    occ[e] = (uint32_t)(end - run_start[r]);
+}
+__global__ void index_hist_kernel(const uint32_t *run_start, size_t n_runs, size_t n, const uint64_t *y,
+                                  const uint32_t *chunk_of_t, uint32_t *hist) {
+    size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    size_t end = r + 1 < n_runs ? run_start[r + 1] : n;
+    uint32_t len = (uint32_t)(end - run_start[r]);
+    uint32_t c = chunk_of_t[y[run_start[r]] >> 32];
+    atomicAdd(&hist[(size_t)c * HB + (len < (uint32_t)HB - 1 ? len : (uint32_t)HB - 1)], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// seeds
+// ---------------------------------------------------------------------------------------------
+struct SeedArgs {
+    const Mz *qmz;              // first minimizer of the batch
+    size_t n_mz;
+    const uint64_t *ikey, *iy;
+    const uint32_t *iocc, *mid_occ, *chunk_of_t, *rank_q, *rank_t, *qlen;
+    size_t n_idx;
+    uint32_t q_lo;
+};
+
+template <bool FILL>
+__global__ void seed_kernel(SeedArgs a, uint32_t *cnt, const uint64_t *aoff, uint64_t *okey, uint64_t *oval) {
+    size_t m = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (m >= a.n_mz) return;
+    const Mz z = a.qmz[m];
+    const uint64_t key = z.x >> 8;
+    const uint32_t q = (uint32_t)(z.y >> 32);
+    const uint32_t qspan = (uint32_t)(z.x & 0xff), qpos = (uint32_t)z.y >> 1, qz = (uint32_t)z.y & 1;
+    const uint32_t rq = a.rank_q[q];
+    uint32_t c = 0;
+    uint64_t w = FILL ? aoff[m] : 0;
+    for (size_t e = lower_bound_u64(a.ikey, a.n_idx, key); e < a.n_idx && a.ikey[e] == key; ++e) {
+        const uint64_t y = a.iy[e];
+        const uint32_t t = (uint32_t)(y >> 32);
+        if (a.iocc[e] > a.mid_occ[a.chunk_of_t[t]]) continue;    // too frequent inside that chunk
+        if (rq >= a.rank_t[t]) continue;                          // pair once (and never self)
+        if (FILL) {
+            const uint32_t tpos = (uint32_t)y >> 1, strand = qz ^ ((uint32_t)y & 1);
+            const uint32_t qp = strand ? a.qlen[q] - (qpos + 1 - qspan) - 1 : qpos;
+            okey[w] = (uint64_t)(q - a.q_lo) << (T_BITS + 1 + TPOS_BITS) | (uint64_t)t << (1 + TPOS_BITS) |
+                      (uint64_t)strand << TPOS_BITS | tpos;
+            oval[w] = (uint64_t)qp << 32 | (uint64_t)qspan << 24;
+            ++w;
+        }
+        ++c;
+    }
+    if (!FILL) cnt[m] = c;
+}
+
+__global__ void gather_u64_at_kernel(const uint64_t *src, const uint64_t *idx, uint64_t *dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void group_head_kernel(const uint64_t *key, size_t n, uint8_t *head) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || (key[i] >> TPOS_BITS) != (key[i - 1] >> TPOS_BITS)) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// chains
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
+
+__device__ __forceinline__ bool block_ok(int q0, int t0, int q1, int t1) {
+    int m = q1 - q0, n = t1 - t0, d = n - m;
+    if (m < 0 || n < 0 || m > BLOCK_MAX || n > BLOCK_MAX) return false;
+    return (d < 0 ? -d : d) + 2 * BAND_PAD + 1 <= BAND_W;
+}
+
+struct ChainArgs {
+    const uint64_t *key, *val;
+    const uint32_t *gstart;
+    size_t n_groups, n_anchors;
+    int32_t *f, *p;
+    unsigned long long *bck;          // best child: f << 32 | ~index
+    int k, max_gap, bw, min_score, min_cnt;
+    uint32_t q_lo;
+    Piece *pieces;
+    FixPt *fps;
+    uint32_t cap_pieces, cap_fps;
+    uint32_t *counters;               // [0] pieces, [1] fixed points, [2] overflow flag
+};
+
+// walks one chain (start s, first `len` anchors along best-child links) and either counts or writes
+// its alignment pieces; mirrors oracle/ava_oracle.c:align_chain's fixed-point selection
+template <bool WRITE>
+__device__ void emit_chain(const ChainArgs &a, size_t b, int s, int len, uint32_t q, uint32_t t, uint32_t strand,
+                           uint32_t &n_pieces, uint32_t &n_fps, uint32_t piece_base, uint32_t fp_base) {
+    int cur = s, prev = -1;
+    bool open = false;
+    int cq = 0, ct = 0;
+    uint32_t np = 0, nf = 0, piece_fp0 = 0;
+    for (int x = 0; x < len;) {
+        const uint64_t key = a.key[b + cur], val = a.val[b + cur];
+        const int te = (int)(key & 0x7fffffffu) + 1, qe = (int)(val >> 32) + 1, sp = (int)((val >> 24) & 0xff);
+        bool advance = true;
+        if (!open) {
+            int q0 = qe - sp, t0 = te - sp;
+            if (q0 < 0 || t0 < 0) { int sh = q0 < t0 ? -q0 : -t0; q0 += sh; t0 += sh; }
+            if (q0 < 0) q0 = 0;
+            if (t0 < 0) t0 = 0;
+            if (block_ok(q0, t0, qe, te)) {
+                piece_fp0 = nf;
+                if (WRITE) { a.fps[fp_base + nf] = FixPt{(uint32_t)q0, (uint32_t)t0}; a.fps[fp_base + nf + 1] = FixPt{(uint32_t)qe, (uint32_t)te}; }
+                nf += 2;
+                cq = qe; ct = te; open = true;
+            }
+        } else if (((qe - cq >= BLOCK_MIN && te - ct >= BLOCK_MIN) || x == len - 1) && qe > cq && te > ct) {
+            if (block_ok(cq, ct, qe, te)) {
+                if (WRITE) a.fps[fp_base + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
+                ++nf;
+                cq = qe; ct = te;
+            } else {                                   // split: close here, reopen at this anchor
+                if (WRITE) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
+                ++np;
+                open = false;
+                advance = false;
+            }
+        }
+        if (advance) {
+            ++x;
+            prev = cur;
+            if (x < len) cur = (int)(0xffffffffu - (uint32_t)(a.bck[b + cur] & 0xffffffffull));
+        }
+    }
+    (void)prev;
+    if (open) {
+        if (WRITE) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
+        ++np;
+    }
+    n_pieces = np;
+    n_fps = nf;
+}
+
+__global__ __launch_bounds__(WG) void chain_kernel(ChainArgs a) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t g = wave; g < a.n_groups; g += n_waves) {
+        const size_t b = a.gstart[g];
+        const size_t e = g + 1 < a.n_groups ? a.gstart[g + 1] : a.n_anchors;
+        const int n = (int)(e - b);
+        if (n < a.min_cnt) continue;
+        // ---- phase A: DP -------------------------------------------------------------------------------
+        int r_t = 0, r_q = 0, r_f = 0;                   // ring: lane l holds predecessor i-1-l
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            int my_t = 0, my_q = 0, my_s = 0;
+            if (i0 + lane < n) {
+                const uint64_t key = a.key[b + i0 + lane], val = a.val[b + i0 + lane];
+                my_t = (int)(key & 0x7fffffffu);
+                my_q = (int)(val >> 32);
+                my_s = (int)((val >> 24) & 0xff);
+            }
+            const int nb = n - i0 < 64 ? n - i0 : 64;
+            for (int bb = 0; bb < nb; ++bb) {
+                const int i = i0 + bb;
+                const int ti = __shfl(my_t, bb, 64), qi = __shfl(my_q, bb, 64), si = __shfl(my_s, bb, 64);
+                const int dr = ti - r_t, dq = qi - r_q;
+                uint32_t k32 = 0;
+                if (lane < i && dr <= a.max_gap && dq > 0 && dq <= a.max_gap && dr != 0) {
+                    const int dd = dr > dq ? dr - dq : dq - dr;
+                    if (dd <= a.bw) {
+                        const int dg = dr < dq ? dr : dq;
+                        const int sc = dg < si ? dg : si;
+                        const int pen = dd ? (dd * a.k) / 100 + (ilog2_u32((uint32_t)dd) >> 1) : 0;
+                        const int cand = r_f + sc - pen;
+                        k32 = (uint32_t)(cand + 1024) << 6 | (uint32_t)(63 - lane);
+                    }
+                }
+                const uint32_t best = wave_max_u32(k32);
+                int bf = si, bp = -1;
+                if (best) {
+                    const int c = (int)(best >> 6) - 1024;
+                    if (c > si) { bf = c; bp = i - 1 - (63 - (int)(best & 63)); }
+                }
+                if (lane == 0) { a.f[b + i] = bf; a.p[b + i] = bp; }
+                r_t = __shfl_up(r_t, 1, 64);
+                r_q = __shfl_up(r_q, 1, 64);
+                r_f = __shfl_up(r_f, 1, 64);
+                if (lane == 0) { r_t = ti; r_q = qi; r_f = bf; }
+            }
+        }
+        __threadfence_block();
+        // ---- phase B: best child of every anchor -------------------------------------------------------------
+        for (int i = lane; i < n; i += 64) {
+            const int pi = a.p[b + i];
+            if (pi >= 0)
+                atomicMax(&a.bck[b + pi], (unsigned long long)(uint32_t)a.f[b + i] << 32 | (0xffffffffu - (uint32_t)i));
+        }
+        __threadfence_block();
+        // ---- phase C: every lane walks the chains that start at its anchors ------------------------------------
+        const uint64_t key0 = a.key[b];
+        const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (T_BITS + 1 + TPOS_BITS));
+        const uint32_t tg = (uint32_t)(key0 >> (1 + TPOS_BITS)) & ((1u << T_BITS) - 1);
+        const uint32_t strand = (uint32_t)(key0 >> TPOS_BITS) & 1u;
+        for (int s = lane; s < n; s += 64) {
+            const int ps = a.p[b + s];
+            if (ps >= 0 && (0xffffffffu - (uint32_t)(a.bck[b + ps] & 0xffffffffull)) == (uint32_t)s) continue;
+            int len = 1, best_len = 1, cur = s;
+            int best_f = a.f[b + s];
+            while (true) {
+                const unsigned long long bc = a.bck[b + cur];
+                if (!bc) break;
+                cur = (int)(0xffffffffu - (uint32_t)(bc & 0xffffffffull));
+                ++len;
+                const int fc = (int)(bc >> 32);            // = f[cur]
+                if (fc > best_f) { best_f = fc; best_len = len; }
+            }
+            const int sc = best_f - (ps >= 0 ? a.f[b + ps] : 0);
+            if (sc < a.min_score || best_len < a.min_cnt) continue;
+            uint32_t np = 0, nf = 0;
+            emit_chain<false>(a, b, s, best_len, qg, tg, strand, np, nf, 0, 0);
+            if (!np) continue;
+            const uint32_t pb = atomicAdd(&a.counters[0], np), fb = atomicAdd(&a.counters[1], nf);
+            if (pb + np > a.cap_pieces || fb + nf > a.cap_fps) { a.counters[2] = 1; continue; }
+            emit_chain<true>(a, b, s, best_len, qg, tg, strand, np, nf, pb, fb);
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_chunks, const hlmi_ava_opts &o,
+                 DevIndex &ix) {
+    const size_t n = tsk.n;
+    ix.n = n;
+    ix.key.alloc(n ? n : 1);
+    ix.y.alloc(n ? n : 1);
+    ix.occ.alloc(n ? n : 1);
+    std::vector<uint32_t> mid(n_chunks, (uint32_t)o.min_mid_occ);
+    if (n) {
+        hipLaunchKernelGGL(split_mz_kernel, grid1(n), dim3(WG), 0, stream(), tsk.mz.p, n, ix.key.p, ix.y.p);
+        sort_pairs_u64_u64(ix.key.p, ix.y.p, n, 0, 2 * o.k);
+        DBuf<uint8_t> head(n);
+        hipLaunchKernelGGL(index_head_kernel, grid1(n), dim3(WG), 0, stream(), ix.key.p, ix.y.p, d_chunk_of_t, n, head.p);
+        DBuf<uint32_t> run_start(n);
+        const size_t n_runs = select_flagged_indices(head.p, run_start.p, n);
+        hipLaunchKernelGGL(index_occ_kernel, grid1(n), dim3(WG), 0, stream(), run_start.p, n_runs, n, ix.occ.p);
+        DBuf<uint32_t> hist((size_t)n_chunks * HB);
+        hist.zero();
+        hipLaunchKernelGGL(index_hist_kernel, grid1(n_runs), dim3(WG), 0, stream(), run_start.p, n_runs, n, ix.y.p,
+                           d_chunk_of_t, hist.p);
+        HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> h = hist.download();
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            uint64_t nd = 0;
+            for (int v = 0; v < HB; ++v) nd += h[(size_t)c * HB + v];
+            if (!nd) continue;
+            uint64_t q = (uint64_t)(uint32_t)((1.0 - o.mid_occ_frac) * (double)nd);
+            if (q >= nd) q = nd - 1;
+            uint64_t cum = 0;
+            int v = 0;
+            for (; v < HB; ++v) { cum += h[(size_t)c * HB + v]; if (cum > q) break; }
+            if (v >= HB - 1)
+                fail(HLMI_EINVAL, "chunk %u: minimizer occurrence quantile beyond %d (extremely repetitive input)", c, HB - 2);
+            int t = v + 1;
+            if (t > (int)mid[c]) mid[c] = (uint32_t)t;
+            if (mid[c] > (uint32_t)MAX_MID_OCC) mid[c] = MAX_MID_OCC;
+        }
+    }
+    ix.mid_occ.upload(mid);
+    sync();
+}
+
+static SeedArgs make_seed_args(const AvaInput &in, const DevIndex &ix, const uint32_t *d_qlen, size_t q_lo, size_t q_hi) {
+    SeedArgs sa{};
+    sa.qmz = in.d_qmz + in.qmz_off[q_lo];
+    sa.n_mz = in.qmz_off[q_hi] - in.qmz_off[q_lo];
+    sa.ikey = ix.key.p; sa.iy = ix.y.p; sa.iocc = ix.occ.p; sa.mid_occ = ix.mid_occ.p;
+    sa.chunk_of_t = in.d_chunk_of_t; sa.rank_q = in.d_rank_q; sa.rank_t = in.d_rank_t; sa.qlen = d_qlen;
+    sa.n_idx = ix.n;
+    sa.q_lo = (uint32_t)q_lo;
+    return sa;
+}
+
+std::vector<uint64_t> count_anchors_per_query(const AvaInput &in, const DevIndex &ix, size_t q_lo, size_t q_hi) {
+    std::vector<uint64_t> per_q(q_hi - q_lo, 0);
+    SeedArgs sa = make_seed_args(in, ix, nullptr, q_lo, q_hi);
+    if (!sa.n_mz || !ix.n) return per_q;
+    DBuf<uint32_t> cnt(sa.n_mz);
+    DBuf<uint64_t> aoff(sa.n_mz + 1);
+    hipLaunchKernelGGL(seed_kernel<false>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, cnt.p, nullptr, nullptr, nullptr);
+    HIP_CHECK(hipGetLastError());
+    exclusive_scan_u32_to_u64(cnt.p, aoff.p, sa.n_mz);
+    // cumulative anchors at the query boundaries
+    std::vector<uint64_t> bidx(q_hi - q_lo);
+    for (size_t q = q_lo; q < q_hi; ++q) bidx[q - q_lo] = in.qmz_off[q] - in.qmz_off[q_lo];
+    // the boundary of the last query needs the total
+    const uint64_t total = (uint64_t)download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt.p + (sa.n_mz - 1));
+    DBuf<uint64_t> d_bidx, d_b(q_hi - q_lo);
+    d_bidx.upload(bidx);
+    // boundaries equal to n_mz (queries without minimizers at the end) read the total instead
+    std::vector<uint64_t> cum(q_hi - q_lo + 1, total);
+    {
+        std::vector<uint64_t> safe = bidx;
+        for (auto &v : safe) if (v >= sa.n_mz) v = sa.n_mz - 1;
+        d_bidx.upload(safe);
+        hipLaunchKernelGGL(gather_u64_at_kernel, grid1(safe.size()), dim3(WG), 0, stream(), aoff.p, d_bidx.p, d_b.p, safe.size());
+        std::vector<uint64_t> hb = d_b.download(safe.size());
+        for (size_t i = 0; i < hb.size(); ++i) cum[i] = bidx[i] >= sa.n_mz ? total : hb[i];
+    }
+    for (size_t i = 0; i + 1 < cum.size(); ++i) per_q[i] = cum[i + 1] - cum[i];
+    return per_q;
+}
+
+void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const uint32_t *d_qlen,
+                    const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out, SeedStats &st) {
+    (void)d_tlen;
+    out = ChainOut();
+    if (q_hi - q_lo > (1u << QL_BITS)) fail(HLMI_EINVAL, "query batch larger than %d", 1 << QL_BITS);
+    if (in.T->n > (1u << T_BITS)) fail(HLMI_EINVAL, "more than %d targets in one run", 1 << T_BITS);
+    SeedArgs sa = make_seed_args(in, ix, d_qlen, q_lo, q_hi);
+    if (!sa.n_mz || !ix.n) return;
+    DBuf<uint32_t> cnt(sa.n_mz);
+    DBuf<uint64_t> aoff(sa.n_mz);
+    hipLaunchKernelGGL(seed_kernel<false>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, cnt.p, nullptr, nullptr, nullptr);
+    HIP_CHECK(hipGetLastError());
+    exclusive_scan_u32_to_u64(cnt.p, aoff.p, sa.n_mz);
+    const size_t A = (size_t)(download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt.p + (sa.n_mz - 1)));
+    st.anchors += A;
+    if (!A) return;
+    if (A >= (1ull << 32)) fail(HLMI_EINVAL, "anchor batch too large");
+    DBuf<uint64_t> akey(A), aval(A);
+    hipLaunchKernelGGL(seed_kernel<true>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, nullptr, aoff.p, akey.p, aval.p);
+    HIP_CHECK(hipGetLastError());
+    cnt.release();
+    aoff.release();
+    const int qbits = bits_for((uint64_t)(q_hi - q_lo - 1 ? q_hi - q_lo - 1 : 1));
+    sort_pairs_u64_u64(akey.p, aval.p, A, 0, T_BITS + 1 + TPOS_BITS + qbits);
+    DBuf<uint8_t> head(A);
+    hipLaunchKernelGGL(group_head_kernel, grid1(A), dim3(WG), 0, stream(), akey.p, A, head.p);
+    DBuf<uint32_t> gstart(A);
+    const size_t G = select_flagged_indices(head.p, gstart.p, A);
+    head.release();
+    st.groups += G;
+
+    DBuf<int32_t> f(A), p(A);
+    DBuf<unsigned long long> bck(A);
+    bck.zero();
+    DBuf<uint32_t> counters(4);
+    counters.zero();
+    ChainArgs ca{};
+    ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.n_groups = G; ca.n_anchors = A;
+    ca.f = f.p; ca.p = p.p; ca.bck = bck.p;
+    ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
+    ca.q_lo = (uint32_t)q_lo;
+    ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);
+    ca.cap_fps = (uint32_t)std::min<size_t>(2 * A + 1024, 0xfffffff0u);
+    out.pieces.alloc(ca.cap_pieces);
+    out.fps.alloc(ca.cap_fps);
+    ca.pieces = out.pieces.p; ca.fps = out.fps.p; ca.counters = counters.p;
+    const unsigned n_blocks = (unsigned)std::min<size_t>((G + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(chain_kernel, dim3(n_blocks ? n_blocks : 1), dim3(WG), 0, stream(), ca);
+    HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> hc = counters.download(4);
+    if (hc[2]) fail(HLMI_ENOMEM, "chain output buffers overflowed (pieces %u/%u, fixed points %u/%u)", hc[0],
+                    ca.cap_pieces, hc[1], ca.cap_fps);
+    out.n_pieces = hc[0];
+    out.n_fp = hc[1];
+}
+
+}  // namespace hlmi

@@ -1,0 +1,51 @@
+// ava_internal.h - structures shared by the overlapper's translation units.
+#pragma once
+#include "ava.h"
+
+namespace hlmi {
+
+// ---- S2: index over the targets of this run (all chunks together, per-chunk semantics kept) ----
+struct DevIndex {
+    size_t n = 0;
+    DBuf<uint64_t> key;      // minimizer hash (x >> 8), ascending; equal keys ordered by (target, pos)
+    DBuf<uint64_t> y;        // target << 32 | pos << 1 | strand
+    DBuf<uint32_t> occ;      // occurrences of this key inside the entry's chunk
+    DBuf<uint32_t> mid_occ;  // per chunk: occurrence cut-off
+};
+void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_chunks, const hlmi_ava_opts &o,
+                 DevIndex &ix);
+
+// ---- S3/S4 output: alignment pieces = lists of fixed points -----------------------------------
+struct Piece {               // 32 B
+    uint32_t q, t;           // global query index, local target index
+    uint32_t strand;
+    uint32_t chain;          // start anchor of the chain inside its (q,t,strand) group
+    uint32_t piece;          // index of the piece inside the chain
+    uint32_t fp_off, n_fp;   // fixed points: (q,t) exclusive-end coordinates, n_fp >= 2
+    uint32_t pad;
+};
+struct FixPt { uint32_t q, t; };
+
+struct ChainOut {
+    size_t n_pieces = 0, n_fp = 0;
+    DBuf<Piece> pieces;
+    DBuf<FixPt> fps;
+};
+struct SeedStats { uint64_t anchors = 0, groups = 0; };
+// seeds + chains queries [q_lo,q_hi)
+void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const uint32_t *d_qlen,
+                    const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out, SeedStats &st);
+// number of anchors each query of [q_lo, q_hi) generates (host vector), for batching
+std::vector<uint64_t> count_anchors_per_query(const AvaInput &in, const DevIndex &ix, size_t q_lo, size_t q_hi);
+
+// ---- S5: alignment of the pieces -> PAF rows -------------------------------------------------------
+struct AlignOut {
+    size_t n_rows = 0, n_ops = 0;
+    DBuf<PafRec> recs;       // qid/tid = name ranks; chunk = chunk slot; tie unset
+    DBuf<uint32_t> ops;
+    DBuf<uint64_t> ord_hi, ord_lo;   // stream-order keys of each row
+};
+void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
+                  const ChainOut &ch, AlignOut &out);
+
+}  // namespace hlmi

@@ -36,4 +36,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
 void window_filter_device(const PafRec *d_recs, size_t n, const std::vector<uint64_t> &chunk_row_start,
                           int variant, int min_len, double min_iden, int min_o, uint8_t *d_keep);
 
+// host copies of the rows recs[idx[i]]
+std::vector<PafRec> download_rows(const PafRec *d_recs, const std::vector<uint32_t> &idx);
+
 }  // namespace hlmi

@@ -348,6 +348,17 @@ std::vector<uint64_t> make_windows(const std::vector<uint64_t> &chunk_row_start,
 
 }  // namespace
 
+std::vector<PafRec> download_rows(const PafRec *d_recs, const std::vector<uint32_t> &idx) {
+    std::vector<PafRec> out;
+    if (idx.empty()) return out;
+    DBuf<uint32_t> d_idx;
+    d_idx.upload(idx);
+    DBuf<PafRec> tmp(idx.size());
+    hipLaunchKernelGGL(gather_rec_kernel, grid1(idx.size()), dim3(WG), 0, stream(), d_recs, d_idx.p, tmp.p, idx.size());
+    HIP_CHECK(hipGetLastError());
+    return tmp.download(idx.size());
+}
+
 void window_filter_device(const PafRec *d_recs, size_t n, const std::vector<uint64_t> &chunk_row_start, int variant,
                           int min_len, double min_iden, int min_o, uint8_t *d_keep) {
     if (!n) return;

@@ -1,0 +1,155 @@
+// stage.cpp - one split_reads2 stage (script/utils.py:41-71) on the GPU: --nsplit chunking of the
+// target file, overlapper, filter chain, score-sorted 14-column PAF.  Also the staged entry
+// points used by the multi-GPU driver (sketch shard / install gathered sketch / run chunk share).
+#include "stage.h"
+
+#include <algorithm>
+#include <chrono>
+
+#include "ava.h"
+#include "filter_stage.h"
+#include "paf_io.h"
+
+namespace hlmi {
+
+struct Job::Impl {
+    SeqSet Q, T;
+    bool long_mode = true;
+    hlmi_ava_opts opts{};
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;   // target read ranges [lo,hi) per chunk
+    std::vector<uint32_t> rank_q, rank_t;
+    std::vector<std::string> name_of_rank;
+    DevReads dQ;
+    DBuf<uint32_t> d_rank_q;
+    DevSketch own;                    // sketch owned by the job (single-GPU path)
+    const Mz *d_qmz = nullptr;        // installed query sketch (own.mz or caller memory)
+    std::vector<uint64_t> qmz_off;
+};
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode) : impl_(new Impl) {
+    Impl &m = *impl_;
+    if (!long_mode)
+        fail(HLMI_ESTATE, "short-read mode (minimap2 --sr, filter_overlap_slr2.py:55) is not built yet: long_mode=0 "
+                          "is SURVEY.md section 8f rank 1");
+    m.long_mode = long_mode;
+    m.opts = ava_opts_long();
+    read_seqs(reads_fa, m.Q);
+    if (std::string(reads_fa) == ref_fa) m.T = m.Q; else read_seqs(ref_fa, m.T);
+    name_ranks(m.T.names, m.Q.names, m.rank_t, m.rank_q, m.name_of_rank);
+    // --nsplit chunking by LINES (utils.py:44-47): nu = `wc -l`, per = int(nu/(8*nsplit)+1)*8
+    const uint64_t nu = m.T.n_lines;
+    const uint64_t per = (nu / (8ull * (uint64_t)nsplit) + 1) * 8;
+    for (size_t r = 0; r < m.T.size();) {
+        const uint64_t c = m.T.first_line[r] / per;
+        size_t e = r;
+        while (e < m.T.size() && m.T.first_line[e] / per == c) ++e;
+        // a record must not straddle a chunk boundary (`split -l` would cut it and the reference would
+        // silently work on the truncated pieces)
+        const uint64_t end_line = e < m.T.size() ? m.T.first_line[e] : std::max<uint64_t>(nu, m.T.first_line[e - 1] + 1);
+        if ((end_line - 1) / per != c)
+            fail(HLMI_EINVAL, "record %s straddles an --nsplit chunk boundary", m.T.names[e - 1].c_str());
+        m.chunks.emplace_back((uint32_t)r, (uint32_t)e);
+        r = e;
+    }
+    upload_reads(m.Q, 0, m.Q.size(), m.dQ);
+    m.d_rank_q.upload(m.rank_q);
+    if (m.rank_q.empty()) m.d_rank_q.alloc(1);
+}
+
+Job::~Job() = default;
+size_t Job::num_queries() const { return impl_->Q.size(); }
+size_t Job::num_chunks() const { return impl_->chunks.size(); }
+
+int64_t Job::sketch_bound(int64_t lo, int64_t hi) const {
+    const Impl &m = *impl_;
+    if (lo < 0 || hi < lo || (size_t)hi > m.Q.size()) fail(HLMI_EINVAL, "sketch range out of bounds");
+    return (int64_t)(m.Q.off[hi] - m.Q.off[lo]);
+}
+
+int64_t Job::sketch_range(int64_t lo, int64_t hi, void *dev_mz, int64_t cap, void *dev_counts) {
+    Impl &m = *impl_;
+    if (lo < 0 || hi < lo || (size_t)hi > m.Q.size()) fail(HLMI_EINVAL, "sketch range out of bounds");
+    if (lo == hi) return 0;
+    DevReads part;
+    upload_reads(m.Q, (size_t)lo, (size_t)hi, part);
+    return sketch_device_into(part, m.opts.k, m.opts.w, m.opts.hpc, (uint32_t)lo, (Mz *)dev_mz, cap, (uint32_t *)dev_counts);
+}
+
+void Job::set_query_sketch(const void *dev_mz, int64_t n, const void *dev_counts) {
+    Impl &m = *impl_;
+    std::vector<uint32_t> cnt(m.Q.size());
+    if (!cnt.empty()) {
+        HIP_CHECK(hipMemcpyAsync(cnt.data(), dev_counts, cnt.size() * 4, hipMemcpyDeviceToHost, stream()));
+        sync();
+    }
+    m.qmz_off.assign(m.Q.size() + 1, 0);
+    for (size_t i = 0; i < cnt.size(); ++i) m.qmz_off[i + 1] = m.qmz_off[i] + cnt[i];
+    if ((int64_t)m.qmz_off.back() != n) fail(HLMI_EINVAL, "query sketch has %lld entries but counts sum to %llu", (long long)n,
+                                             (unsigned long long)m.qmz_off.back());
+    m.d_qmz = (const Mz *)dev_mz;
+}
+
+void Job::sketch_all_queries() {
+    Impl &m = *impl_;
+    sketch_device(m.dQ, m.opts.k, m.opts.w, m.opts.hpc, 0, m.own);
+    set_query_sketch(m.own.mz.p, (int64_t)m.own.n, m.own.counts.p);
+}
+
+void Job::run(int rank, int world, int len_over, int mc, double iden, const char *out_paf) {
+    Impl &m = *impl_;
+    if (!m.d_qmz && m.Q.size()) fail(HLMI_ESTATE, "hlmi_job_run before a query sketch was installed");
+    stat_reset();
+    const double t0 = now_s();
+    // ---- this rank's chunks and targets ---------------------------------------------------------------
+    std::vector<uint32_t> tids, chunk_of_t;
+    uint32_t n_my = 0;
+    for (size_t c = 0; c < m.chunks.size(); ++c) {
+        if ((int)(c % (size_t)world) != rank) continue;
+        for (uint32_t t = m.chunks[c].first; t < m.chunks[c].second; ++t) { tids.push_back(t); chunk_of_t.push_back(n_my); }
+        ++n_my;
+    }
+    std::vector<std::string> lines;
+    if (!tids.empty() && m.Q.size()) {
+        DevReads dT;
+        upload_reads(m.T, tids, dT);
+        std::vector<uint32_t> rt(tids.size());
+        for (size_t i = 0; i < tids.size(); ++i) rt[i] = m.rank_t[tids[i]];
+        DBuf<uint32_t> d_rt, d_ct;
+        d_rt.upload(rt);
+        d_ct.upload(chunk_of_t);
+        AvaInput in;
+        in.T = &dT; in.Q = &m.dQ; in.d_rank_t = d_rt.p; in.d_rank_q = m.d_rank_q.p; in.d_chunk_of_t = d_ct.p;
+        in.n_chunks = n_my; in.d_qmz = m.d_qmz; in.qmz_off = m.qmz_off;
+        AvaRows rows;
+        ava_device(in, m.opts, rows);
+        const double t1 = now_s();
+        FilterCfg cfg;
+        cfg.len_over = len_over; cfg.mc = mc; cfg.long_mode = m.long_mode;
+        FilterOut fo;
+        filter_stage_device(rows.recs.p, rows.n_rows, rows.ops.p, rows.chunk_row_start, cfg, fo);
+        const double t2 = now_s();
+        std::vector<PafRec> kept = download_rows(rows.recs.p, fo.rows);
+        std::string s;
+        for (size_t i = 0; i < kept.size(); ++i)
+            if (format_scored_row(kept[i], m.name_of_rank[kept[i].qid], m.name_of_rank[kept[i].tid], fo.x_digit_sum[i], iden, s))
+                lines.push_back(s);
+        stat_set("rows_after_v4", (double)fo.n_after_v4);
+        stat_set("snp_events", (double)fo.n_events);
+        stat_set("pairs", (double)fo.n_pairs);
+        stat_set("t_ava_s", t1 - t0);
+        stat_set("t_filter_s", t2 - t1);
+    }
+    const double t3 = now_s();
+    sort_scored_lines(lines);     // per-chunk sort + merged sort of utils.py:54,69 collapse into one total order
+    write_lines(out_paf, lines);
+    stat_set("rows_out", (double)lines.size());
+    stat_set("t_format_sort_write_s", now_s() - t3);
+    stat_set("t_total_s", now_s() - t0);
+    stat_set("bases_q", (double)m.Q.bases.size());
+}
+
+}  // namespace hlmi
