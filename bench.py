@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py - long-read all-vs-all overlaps/sec of the hot path on synthetic reads (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the split_reads2-equivalent stage (sketch -> index -> seed -> chain -> align ->
+v4 window filter -> SNP pile-up filter -> pass 2 -> score-sorted PAF on disk) over the workload, with
+the reads already resident in HBM when the timed region starts (hlmi_job_open uploads them).
+Workload at N=1 = BASELINE.json configs[1] (C2): 10 000 synthetic ONT reads, mean 8 kb, 5 strains of
+400 kb, --nsplit 100; the stage constants are those of the reference's main all-vs-all call
+(script/HyLight.py:130: len_over=6000, mc=2, iden=0.95).  With N>1 the --nsplit target chunks are
+sharded over the ranks (chunk i -> rank i % N), every rank sketches 1/N of the reads and the sketches
+are all-gathered over RCCL; the read set is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "C2": dict(seed=20241008, n_strains=5, genome_len=400_000, n_reads=10_000, mean_len=8_000, min_len=1_000,
+               max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001, nsplit=100),
+    # small variant for quick checks (not a bench line)
+    "C2mini": dict(seed=20241008, n_strains=5, genome_len=40_000, n_reads=1_000, mean_len=8_000, min_len=1_000,
+                   max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001, nsplit=100),
+}
+STAGE = dict(len_over=6000, mc=2, iden=0.95)     # script/HyLight.py:130
+HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def make_workload(name, path):
+    from hylight_amd import simulate as S
+    w = dict(WORKLOADS[name])
+    w.pop("nsplit")
+    reads, _ = S.simulate_reads(**w)
+    S.write_fasta(reads, path)
+    return sum(len(r.seq) for r in reads)
+
+
+def cpu_baseline(fa, nsplit, budget_s=25.0):
+    """Oracle (CPU port) timed on a bounded sample of the same workload: as many --nsplit target chunks
+    (each vs ALL query reads, exactly like one reference worker) as fit the budget, one process per
+    host core like the reference's `xargs -P`."""
+    import multiprocessing as mp
+    from oracle import filters as F
+    lines = open(fa).read().split("\n")[:-1]
+    ranges = F.chunk_ranges(len(lines), nsplit)
+    cores = min(len(os.sched_getaffinity(0)), 32, len(ranges))
+    tmp = tempfile.mkdtemp(prefix="hl_cpu_")
+    t0 = time.time()
+    done, rows = 0, 0
+    with mp.get_context("fork").Pool(cores) as pool:
+        nxt = 0
+        while nxt < len(ranges) and (done == 0 or (time.time() - t0) * (1 + cores / max(done, 1)) < budget_s):
+            batch = [(fa, lines, ranges[i], os.path.join(tmp, f"c{i}")) for i in range(nxt, min(nxt + cores, len(ranges)))]
+            rows += sum(pool.map(_cpu_chunk, batch))
+            done += len(batch)
+            nxt += len(batch)
+    dt = time.time() - t0
+    return dict(value=rows / dt, unit="overlaps/s", cores=cores, kind="port",
+                sample=f"{done} of {len(ranges)} --nsplit target chunks x all queries, oracle overlapper + oracle filters, "
+                       f"{dt:.1f} s wall")
+
+
+def _cpu_chunk(args):
+    fa, lines, (lo, hi), base = args
+    from oracle import ava as OA
+    from oracle import filters as F
+    with open(base + ".fa", "w") as f:
+        f.write("\n".join(lines[lo:hi]) + "\n")
+    OA.ava(base + ".fa", fa, base + ".paf")
+    raw = open(base + ".paf").read().split("\n")[:-1]
+    return len(F.worker(raw, True, STAGE["len_over"], STAGE["mc"], STAGE["iden"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hylight_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    api.init(local, 0)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    wl = WORKLOADS[args.workload]
+    work = os.environ.get("HL_BENCH_DIR") or tempfile.mkdtemp(prefix="hl_bench_")
+    fa = os.path.join(work, f"{args.workload}.fa")
+    if rank == 0 and not os.path.exists(fa):
+        make_workload(args.workload, fa + ".tmp")
+        os.replace(fa + ".tmp", fa)
+    if world > 1:
+        obj = [fa]
+        dist.broadcast_object_list(obj, src=0)
+        fa = obj[0]
+        dist.barrier()
+
+    from hylight_amd.stage import StageRunner
+    runner = StageRunner(fa, fa, wl["nsplit"], long_mode=True, rank=rank, world=world)
+    out_paf = os.path.join(work, f"out.rank{rank}.paf")
+
+    def step():
+        return runner.run(out_paf, **STAGE)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.time()
+    rows = 0
+    stats = None
+    for _ in range(args.steps):
+        rows = step()
+        stats = api.last_stats()
+    fence()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, rows = float(tmax[0]), int(t[1])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = dt / args.steps * 1e3
+    value = rows / (dt / args.steps)
+
+    # ---- roofline of the dominant kernel (HIP events on the library stream, last step) --------------
+    kms = {k.split(".", 1)[1]: v for k, v in stats.items() if k.startswith("kernel_ms.")}
+    kn = {k.split(".", 1)[1]: v for k, v in stats.items() if k.startswith("kernel_launches.")}
+    dom = max(kms, key=kms.get)
+    # algorithmic bytes per kernel for the whole step (DESIGN.md "Algorithmic bytes")
+    A, P = stats.get("anchors", 0.0), stats.get("pieces", 0.0)
+    algo = {
+        "chain": 16 * A + 8 * A,                       # read anchors (16 B) + write f,p (8 B)
+        "align": stats.get("align_dp_bases", 0.0) + 4 * stats.get("cigar_ops", 0.0) + 64 * stats.get("ava_rows", 0.0),
+        "anchor_sort": 32 * A,                         # one read + one write of 16 B per anchor
+        "seed_fill": 16 * stats.get("sketch_minimizers", 0.0) / 2 + 8 * A + 16 * A,
+        "seed_count": 16 * stats.get("sketch_minimizers", 0.0) / 2 + 8 * A,
+        "sketch_kmer_window": stats.get("sketch_bases", 0.0) * 1 + 16 * stats.get("sketch_minimizers", 0.0),
+    }
+    launches = max(kn.get(dom, 1.0), 1.0)
+    avg_ms = kms[dom] / launches
+    bytes_per_launch = algo.get(dom, 0.0) / launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                traffic=None, avg_launch_ms=avg_ms, launches_per_step=launches,
+                kernel_ms_per_step={k: round(v, 3) for k, v in sorted(kms.items(), key=lambda kv: -kv[1])})
+
+    line = dict(metric="long-read all-vs-all overlaps/sec", value=value, unit="overlaps/s", n_gpus=world,
+                steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
+                scaling="strong" if world > 1 else "weak", vs_baseline=None, dtype="u8/int32", data="synthetic",
+                config=dict(workload=f"{args.workload}: {wl['n_reads']} synthetic ONT reads, mean {wl['mean_len']} bp, "
+                                     f"{wl['n_strains']} strains x {wl['genome_len']} bp, ava, --nsplit {wl['nsplit']}",
+                            nsplit=wl["nsplit"], parallelism=f"chunks%{world}", **STAGE,
+                            overlaps_out=rows, candidate_rows=stats.get("ava_rows"), anchors=A),
+                roofline=roof,
+                stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(fa, wl["nsplit"])
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,8 @@ struct DevReads {           // a read set resident in HBM: 1 B/base codes (0..3 
 // reads [lo,hi) of s, in order
 void upload_reads(const SeqSet &s, size_t lo, size_t hi, DevReads &out);
 void upload_reads(const SeqSet &s, const std::vector<uint32_t> &ids, DevReads &out);
+// device-to-device subset (reads already resident in HBM)
+void subset_reads_device(const DevReads &all, const std::vector<uint32_t> &ids, DevReads &out);
 
 struct DevSketch {
     size_t n = 0;

@@ -199,6 +199,7 @@ void ava_files(const char *target_fa, const char *query_fa, const hlmi_ava_opts 
     for (size_t i = 0; i < Q.size(); ++i) in.qmz_off[i + 1] = in.qmz_off[i] + qc[i];
     AvaRows rows;
     ava_device(in, o, rows);
+    ktimer_flush();
     std::vector<PafRec> hr = rows.recs.download(rows.n_rows);
     std::vector<uint32_t> hops = rows.ops.download(rows.n_ops);
     std::vector<std::string> lines(rows.n_rows);

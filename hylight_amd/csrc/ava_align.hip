@@ -74,6 +74,15 @@ __global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const u
     }
 }
 
+__global__ void task_bases_kernel(const Task *tasks, size_t n, unsigned long long *sum) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < n && tasks[i].m > 0 && tasks[i].n > 0) v = (unsigned long long)(tasks[i].m + tasks[i].n);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
+}
+
 struct AlignArgs {
     const Task *tasks;
     size_t n_tasks;
@@ -354,7 +363,10 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         const unsigned nb = (unsigned)std::min<size_t>((NT + WAVES - 1) / WAVES, 256 * 16);
-        hipLaunchKernelGGL(align_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+        {
+            KTimer kt("align");
+            hipLaunchKernelGGL(align_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+        }
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> hc = counters.download(2);
         if (!hc[1]) break;
@@ -362,6 +374,12 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         cap_runs *= 4;
     }
     stat_add("align_tasks", (double)NT);
+    {
+        DBuf<unsigned long long> sum(1);
+        sum.zero();
+        hipLaunchKernelGGL(task_bases_kernel, grid1(NT), dim3(WG), 0, stream(), tasks.p, NT, sum.p);
+        stat_add("align_dp_bases", (double)download_one(sum.p));   // bases staged by the DP tasks (Lq + Lt)
+    }
     // assemble
     AsmArgs as{};
     as.pieces = ch.pieces.p; as.fps = ch.fps.p; as.task_off = toff.p; as.tout = tout.p; as.runs = runs.p; as.n_pieces = P;

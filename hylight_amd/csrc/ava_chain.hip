@@ -392,7 +392,10 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (!sa.n_mz || !ix.n) return;
     DBuf<uint32_t> cnt(sa.n_mz);
     DBuf<uint64_t> aoff(sa.n_mz);
-    hipLaunchKernelGGL(seed_kernel<false>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, cnt.p, nullptr, nullptr, nullptr);
+    {
+        KTimer kt("seed_count");
+        hipLaunchKernelGGL(seed_kernel<false>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, cnt.p, nullptr, nullptr, nullptr);
+    }
     HIP_CHECK(hipGetLastError());
     exclusive_scan_u32_to_u64(cnt.p, aoff.p, sa.n_mz);
     const size_t A = (size_t)(download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt.p + (sa.n_mz - 1)));
@@ -400,12 +403,18 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (!A) return;
     if (A >= (1ull << 32)) fail(HLMI_EINVAL, "anchor batch too large");
     DBuf<uint64_t> akey(A), aval(A);
-    hipLaunchKernelGGL(seed_kernel<true>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, nullptr, aoff.p, akey.p, aval.p);
+    {
+        KTimer kt("seed_fill");
+        hipLaunchKernelGGL(seed_kernel<true>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, nullptr, aoff.p, akey.p, aval.p);
+    }
     HIP_CHECK(hipGetLastError());
     cnt.release();
     aoff.release();
     const int qbits = bits_for((uint64_t)(q_hi - q_lo - 1 ? q_hi - q_lo - 1 : 1));
-    sort_pairs_u64_u64(akey.p, aval.p, A, 0, T_BITS + 1 + TPOS_BITS + qbits);
+    {
+        KTimer kt("anchor_sort");
+        sort_pairs_u64_u64(akey.p, aval.p, A, 0, T_BITS + 1 + TPOS_BITS + qbits);
+    }
     DBuf<uint8_t> head(A);
     hipLaunchKernelGGL(group_head_kernel, grid1(A), dim3(WG), 0, stream(), akey.p, A, head.p);
     DBuf<uint32_t> gstart(A);
@@ -429,7 +438,10 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     out.fps.alloc(ca.cap_fps);
     ca.pieces = out.pieces.p; ca.fps = out.fps.p; ca.counters = counters.p;
     const unsigned n_blocks = (unsigned)std::min<size_t>((G + 3) / 4, 256 * 8);
-    hipLaunchKernelGGL(chain_kernel, dim3(n_blocks ? n_blocks : 1), dim3(WG), 0, stream(), ca);
+    {
+        KTimer kt("chain");
+        hipLaunchKernelGGL(chain_kernel, dim3(n_blocks ? n_blocks : 1), dim3(WG), 0, stream(), ca);
+    }
     HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> hc = counters.download(4);
     if (hc[2]) fail(HLMI_ENOMEM, "chain output buffers overflowed (pieces %u/%u, fixed points %u/%u)", hc[0],

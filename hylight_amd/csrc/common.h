@@ -98,6 +98,16 @@ struct DBuf {
 
 inline void sync() { HIP_CHECK(hipStreamSynchronize(stream())); }
 
+// Scoped HIP-event timer on the library stream: per-kernel device time for bench.py's roofline line
+// (torch.cuda.Event would only see torch's stream).  Durations are summed per name by ktimer_flush()
+// into stats "kernel_ms.<name>" / "kernel_launches.<name>".
+struct KTimer {
+    explicit KTimer(const char *name);
+    ~KTimer();
+    size_t slot;
+};
+void ktimer_flush();
+
 template <typename T>
 T download_one(const T *dev) {
     T v;

@@ -49,6 +49,36 @@ void require_device() {
 
 hipStream_t stream() { return g_stream; }
 
+namespace {
+struct KRec { std::string name; hipEvent_t a, b; };
+std::vector<KRec> g_krecs;
+}  // namespace
+
+KTimer::KTimer(const char *name) {
+    KRec r;
+    r.name = name;
+    HIP_CHECK(hipEventCreate(&r.a));
+    HIP_CHECK(hipEventCreate(&r.b));
+    HIP_CHECK(hipEventRecord(r.a, g_stream));
+    slot = g_krecs.size();
+    g_krecs.push_back(r);
+}
+KTimer::~KTimer() { (void)hipEventRecord(g_krecs[slot].b, g_stream); }
+
+void ktimer_flush() {
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (auto &r : g_krecs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_stats["kernel_ms." + r.name] += ms;
+            g_stats["kernel_launches." + r.name] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_krecs.clear();
+}
+
 void stat_reset() { g_stats.clear(); }
 void stat_set(const std::string &k, double v) { g_stats[k] = v; }
 void stat_add(const std::string &k, double v) { g_stats[k] += v; }

@@ -194,6 +194,31 @@ void upload_reads(const SeqSet &s, const std::vector<uint32_t> &ids, DevReads &o
     finish_upload(bases, off, out);
 }
 
+__global__ void copy_reads_kernel(const uint8_t *src, const uint64_t *src_off, const uint32_t *ids, const uint64_t *dst_off,
+                                  uint8_t *dst) {
+    const uint32_t r = blockIdx.x;
+    const uint64_t s0 = src_off[ids[r]], d0 = dst_off[r], len = dst_off[r + 1] - d0;
+    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) dst[d0 + i] = src[s0 + i];
+}
+
+void subset_reads_device(const DevReads &all, const std::vector<uint32_t> &ids, DevReads &out) {
+    std::vector<uint64_t> off(ids.size() + 1, 0);
+    for (size_t i = 0; i < ids.size(); ++i) off[i + 1] = off[i] + (all.h_off[ids[i] + 1] - all.h_off[ids[i]]);
+    out.n = ids.size();
+    out.total = off.back();
+    out.h_off = off;
+    out.codes.alloc(out.total ? out.total : 1);
+    out.off.upload(off);
+    if (!ids.empty()) {
+        DBuf<uint32_t> d_ids;
+        d_ids.upload(ids);
+        hipLaunchKernelGGL(copy_reads_kernel, dim3((unsigned)ids.size()), dim3(WG), 0, stream(), all.codes.p, all.off.p,
+                           d_ids.p, out.off.p, out.codes.p);
+        HIP_CHECK(hipGetLastError());
+        sync();
+    }
+}
+
 // shared body: returns the compacted slot indices and fills per-read counts
 static int64_t sketch_core(const DevReads &r, int k, int w, int hpc, uint32_t rid_base, Mz *d_out, int64_t cap,
                            uint32_t *d_counts, DBuf<Mz> *own_out) {
@@ -211,6 +236,7 @@ static int64_t sketch_core(const DevReads &r, int k, int w, int hpc, uint32_t ri
     DBuf<uint32_t> slot_pos(n);
     const size_t ns = select_flagged_indices(flag.p, slot_pos.p, n);
     flag.release();
+    KTimer kt_all("sketch_kmer_window");
     DBuf<uint32_t> rslot0(r.n + 1), slot_rid(ns);
     hipLaunchKernelGGL(read_slot0_kernel, grid1(r.n + 1), dim3(WG), 0, stream(), slot_pos.p, ns, r.off.p, r.n, rslot0.p);
     hipLaunchKernelGGL(slot_read_kernel, grid1(ns), dim3(WG), 0, stream(), rslot0.p, r.n, ns, slot_rid.p);

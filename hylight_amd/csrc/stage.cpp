@@ -19,7 +19,8 @@ struct Job::Impl {
     std::vector<std::pair<uint32_t, uint32_t>> chunks;   // target read ranges [lo,hi) per chunk
     std::vector<uint32_t> rank_q, rank_t;
     std::vector<std::string> name_of_rank;
-    DevReads dQ;
+    DevReads dQ, dT_own;              // reads resident in HBM from job_open on
+    DevReads *dT = nullptr;           // all targets (aliases dQ when both paths name the same file)
     DBuf<uint32_t> d_rank_q;
     DevSketch own;                    // sketch owned by the job (single-GPU path)
     const Mz *d_qmz = nullptr;        // installed query sketch (own.mz or caller memory)
@@ -56,6 +57,8 @@ Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode) :
         r = e;
     }
     upload_reads(m.Q, 0, m.Q.size(), m.dQ);
+    if (std::string(reads_fa) == ref_fa) m.dT = &m.dQ;
+    else { upload_reads(m.T, 0, m.T.size(), m.dT_own); m.dT = &m.dT_own; }
     m.d_rank_q.upload(m.rank_q);
     if (m.rank_q.empty()) m.d_rank_q.alloc(1);
 }
@@ -74,8 +77,12 @@ int64_t Job::sketch_range(int64_t lo, int64_t hi, void *dev_mz, int64_t cap, voi
     Impl &m = *impl_;
     if (lo < 0 || hi < lo || (size_t)hi > m.Q.size()) fail(HLMI_EINVAL, "sketch range out of bounds");
     if (lo == hi) return 0;
+    if (lo == 0 && (size_t)hi == m.Q.size())     // the reads are already resident in HBM
+        return sketch_device_into(m.dQ, m.opts.k, m.opts.w, m.opts.hpc, 0, (Mz *)dev_mz, cap, (uint32_t *)dev_counts);
     DevReads part;
-    upload_reads(m.Q, (size_t)lo, (size_t)hi, part);
+    std::vector<uint32_t> ids((size_t)(hi - lo));
+    for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)(lo + (int64_t)i);
+    subset_reads_device(m.dQ, ids, part);
     return sketch_device_into(part, m.opts.k, m.opts.w, m.opts.hpc, (uint32_t)lo, (Mz *)dev_mz, cap, (uint32_t *)dev_counts);
 }
 
@@ -114,8 +121,10 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     }
     std::vector<std::string> lines;
     if (!tids.empty() && m.Q.size()) {
-        DevReads dT;
-        upload_reads(m.T, tids, dT);
+        DevReads dT_sub;
+        const bool all_in_order = tids.size() == m.T.size();   // world == 1: every chunk, file order
+        if (!all_in_order) subset_reads_device(*m.dT, tids, dT_sub);
+        DevReads &dT = all_in_order ? *m.dT : dT_sub;
         std::vector<uint32_t> rt(tids.size());
         for (size_t i = 0; i < tids.size(); ++i) rt[i] = m.rank_t[tids[i]];
         DBuf<uint32_t> d_rt, d_ct;
@@ -148,6 +157,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     write_lines(out_paf, lines);
     stat_set("rows_out", (double)lines.size());
     stat_set("t_format_sort_write_s", now_s() - t3);
+    ktimer_flush();
     stat_set("t_total_s", now_s() - t0);
     stat_set("bases_q", (double)m.Q.bases.size());
 }
