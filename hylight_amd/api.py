@@ -57,6 +57,20 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as
+    /opt/rocm's); if both get loaded, whichever initialises second finds no device.  Loading torch's
+    copy first makes the dynamic loader bind libhylight_mi.so's NEEDED libamdhip64.so.7 to it, so the
+    library, torch's allocator and RCCL share one runtime whatever the import order."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load the shared library (fails loudly when it has not been built)."""
     global _lib
@@ -64,6 +78,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -m hylight_amd.build` "
                               "(there is no CPU fallback)")
+        _preload_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
