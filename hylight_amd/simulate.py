@@ -223,3 +223,49 @@ def truth_paf(reads, min_cols=50, same_strain_only=False, pair_once=True, with_t
                 row += [f"NM:i:{nm}", "tp:A:S", f"cg:Z:{cigar}"]
             lines.append("\t".join(row))
     return lines
+
+
+def messy_graph_paf(seed, n_reads=260, genome=70_000, drop=0.12, trim=0.25, fake=25):
+    """Reads + a deliberately imperfect tag-less PAF (dropped rows, one-sided trimmed overlaps, false
+    suffix/prefix overlaps, shuffled order): exercises miniasm's tip / bubble / bi-loop / short-overlap
+    cleaning, which clean simulated overlaps never trigger."""
+    import random
+    rnd = random.Random(seed)
+    reads, _ = simulate_reads(seed=seed, n_strains=1, genome_len=genome, n_reads=n_reads, mean_len=5000,
+                              min_len=2500, max_len=11000, keep_gpos=True, name_prefix="m")
+    out = []
+    for l in truth_paf(reads, min_cols=500, with_tags=False):
+        if rnd.random() < drop:
+            continue
+        c = l.split("\t")
+        if rnd.random() < trim:
+            d = rnd.randint(50, 900)
+            qs, qe, ts, te = int(c[2]), int(c[3]), int(c[7]), int(c[8])
+            if qe - qs > d + 2100 and te - ts > d + 2100:
+                if rnd.random() < 0.5:
+                    if c[4] == "+":
+                        qs += d; ts += d
+                    else:
+                        qe -= d; ts += d
+                else:
+                    if c[4] == "+":
+                        qe -= d; te -= d
+                    else:
+                        qs += d; te -= d
+                c[2], c[3], c[7], c[8] = map(str, (qs, qe, ts, te))
+                c[9] = str(int(c[9]) - d)
+                c[10] = str(int(c[10]) - d)
+        out.append("\t".join(c))
+    names = [r.name for r in reads]
+    length = {r.name: len(r.seq) for r in reads}
+    for _ in range(fake):
+        a, b = rnd.sample(names, 2)
+        if not a < b:
+            a, b = b, a
+        ov = rnd.randint(2100, 3500)
+        if length[a] < ov + 10 or length[b] < ov + 10:
+            continue
+        out.append("\t".join([a, str(length[a]), str(length[a] - ov), str(length[a]), "+", b, str(length[b]), "0",
+                              str(ov), str(ov - 20), str(ov), "0"]))
+    rnd.shuffle(out)
+    return reads, out

@@ -172,10 +172,22 @@ def main():
     paf = f"{HERE}/fxA_stage_nsplit4.paf"
     fa = f"{HERE}/fxA_reads.fa"
     for tag, flags in (("n1c1", "-d 10000 -n 1 -e 1 -c 1"), ("n3c3", "-d 10000 -n 3 -e 1 -c 3")):
-        run(f"{mini} {flags} -f {fa} {paf} > {HERE}/fxA_miniasm_{tag}.gfa 2> {HERE}/fxA_miniasm_{tag}.log")
+        run(f"{mini} {flags} -f {fa} {paf} > {HERE}/fxA_miniasm_{tag}.gfa 2>/dev/null")
         for p in ("paf", "bed", "sg"):
             run(f"{mini} {flags} -p {p} {paf} > {HERE}/fxA_miniasm_{tag}.{p} 2>/dev/null")
-    # same-strain only graph: longer unitigs (exercises ug_gen / ug_seq)
+    # fixture D: imperfect overlaps -> tips, bubbles, bi-loops, internal cuts, short-overlap removal
+    for seed in (1, 2, 3):
+        readsD, pafD = S.messy_graph_paf(seed)
+        write_lines(f"{HERE}/fxD{seed}_messy.paf", pafD)
+        fa_d = f"{tmp}/fxD{seed}.fa"
+        S.write_fasta(readsD, fa_d)
+        if seed == 1:
+            shutil.copy(fa_d, f"{HERE}/fxD1_reads.fa")
+        for tag, flags in (("n1c1", "-d 10000 -n 1 -e 1 -c 1"), ("n3c3", "-d 10000 -n 3 -e 1 -c 3")):
+            f_opt = f"-f {fa_d}" if seed == 1 else ""
+            run(f"{mini} {flags} {f_opt} {HERE}/fxD{seed}_messy.paf > {HERE}/fxD{seed}_miniasm_{tag}.gfa "
+                f"2>/dev/null")
+            run(f"{mini} {flags} -p sg {HERE}/fxD{seed}_messy.paf > {HERE}/fxD{seed}_miniasm_{tag}.sg 2>/dev/null")
     shutil.rmtree(tmp)
     # compress the bulky text fixtures (tests read them through gzip)
     for fn in sorted(os.listdir(HERE)):
