@@ -1,0 +1,214 @@
+"""Counterpart of the reference driver for the long-read path.
+
+Keeps script/HyLight.py's CLI flags and defaults (HyLight.py:25-52), stage order and output tree
+(OUT/1.split_fastx/s1.fa, OUT/2.overlap/s1_s1.paf, OUT/tmp/contigs1.{gfa,fa}, OUT/tmp/ov_long_ref.paf,
+...), and calls libhylight_mi.so at the two boundaries the path owns: B1 = split_reads2 and
+B3 = miniasm.  External tools the reference shells out to (bfc, ropebwt2, fmlrc2, racon) are still
+external; unlike the reference (whose `execute()` swallows most failures) a missing or
+failing tool stops the run with a message.  The short-read branch (HyLight.py:198 onwards) needs the
+short-read overlapper mode, which is SURVEY.md §8f rank 1 and not built: the driver stops there.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+from . import api
+from .stage import StageRunner
+
+__version__ = "1.0.1-mi355x"
+
+
+def fq_or_fa(path):
+    """toolkits.fq_or_fa (script/toolkits.py:7-18): first character decides."""
+    with open(path) as f:
+        c = f.read(1)
+    if c == "@":
+        return "fastq"
+    if c == ">":
+        return "fasta"
+    raise SystemExit(f"{path}: neither FASTQ nor FASTA")
+
+
+def filter_non_atcg(fq, out_dir, model):
+    """utils.filter_non_atcg (script/utils.py:81-114): upper-case, [^ATGCN] -> N, header cut at the first
+    space; 4-line FASTQ / 2-line FASTA records."""
+    new_dir = os.path.join(out_dir, "1.split_fastx")
+    os.makedirs(new_dir, exist_ok=True)
+    out = os.path.join(new_dir, "s1.fa")
+    bad = re.compile(r"[^ATGCN\n]")
+    with open(out, "w") as o, open(fq) as f:
+        for num, line in enumerate(f):
+            if model == "fastq":
+                if num % 4 == 1:
+                    o.write(bad.sub("N", line.upper()))
+                elif num % 4 == 0 and line.startswith("@"):
+                    o.write(">" + line.strip().split(" ")[0][1:] + "\n")
+            else:
+                if num % 2 == 1:
+                    o.write(bad.sub("N", line.upper()))
+                else:
+                    o.write(line.strip().split(" ")[0] + "\n")
+    return out
+
+
+def gfa2fa(gfa, fa):
+    """HyLight.gfa2fa (script/HyLight.py:328-337): S lines only."""
+    with open(gfa) as g, open(fa, "w") as o:
+        for line in g:
+            f = line.split()
+            if f and f[0] == "S":
+                o.write(f">{f[1]}\n{f[2]}\n")
+
+
+def pick_up(ovlap, outdir, fq):
+    """HyLight.pick_up (script/HyLight.py:347-378): reads whose name (up to the first '/') appears in
+    neither column 1 nor column 6 of the PAF."""
+    seen = set()
+    with open(ovlap) as f:
+        for line in f:
+            k = line.split()
+            seen.add(k[0].split("/")[0])
+            seen.add(k[5].split("/")[0])
+    out = os.path.join(outdir, "sub" + str(time.time())[-3:] + "_remain.fq")
+    if os.path.exists(out):
+        os.remove(out)
+    nu = 4 if fq_or_fa(fq) == "fastq" else 2
+    keep = False
+    with open(fq) as f, open(out, "a") as o:
+        for num, line in enumerate(f):
+            if num % nu == 0:
+                keep = line.strip().split("/")[0][1:] not in seen
+            if keep:
+                o.write(line)
+    return out
+
+
+def _tool(name):
+    p = shutil.which(name)
+    if not p:
+        raise SystemExit(f"external tool `{name}` (README.md:14-19 of the reference) is not on PATH")
+    return p
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, shell=True, cwd=cwd, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        print(f"Error executing the command: {cmd}\n{r.stderr}", file=sys.stderr)
+        raise SystemExit(1)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="python -m hylight_amd.driver",
+                                description="Haplotype-aware de novo assembly of metagenome from hybrid sequencing data "
+                                            "(long reads, short reads) - MI355X long-read path",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("-s", "--short_reads", dest="short_reads", type=str, required=False)
+    p.add_argument("-l", "--long_reads", dest="long_reads", type=str, required=True)
+    p.add_argument("-o", "--outdir", dest="outdir", type=str, default="./")
+    p.add_argument("-t", "--threads", dest="threads", type=int, default=20)
+    p.add_argument("--corrected", dest="corrected", action="store_true")
+    p.add_argument("--low_q", dest="low_quality", action="store_true")
+    p.add_argument("--nsplit", dest="nsplit", type=int, default=60)
+    p.add_argument("--min_identity", dest="min_identity", type=float, default=0.95)
+    p.add_argument("--min_ovlp_len", dest="min_ovlp_len", type=int, default=3000)
+    p.add_argument("--size", dest="size", default=15000, type=int)
+    p.add_argument("--max_tip_len", dest="max_tip_len", type=int, default=10000)
+    p.add_argument("--insert_size", dest="insert_size", default=450, type=int)
+    p.add_argument("--average_read_len", dest="average_read_len", default=250, type=int)
+    p.add_argument("--version", "-v", action="version", version="%(prog)s version: " + __version__)
+    p.add_argument("--stop_after", choices=["overlap", "contigs1", "polish"], default=None,
+                   help="(extension) stop after the named long-read stage")
+    p.add_argument("--device", type=int, default=0, help="(extension) GPU index")
+    return p
+
+
+def stage(fa, ref, nsplit, out_file, len_over, mc, iden, long=True):
+    r = StageRunner(fa, ref, nsplit, long_mode=long)
+    try:
+        r.run(out_file, len_over, mc, iden)
+    finally:
+        r.close()
+    return out_file
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    api.init(args.device, args.threads)
+    outdir, nsplit, iden = args.outdir, args.nsplit, args.min_identity
+    len_over, max_tip = args.min_ovlp_len, args.max_tip_len
+    long_reads = os.path.abspath(args.long_reads)
+    os.makedirs(outdir, exist_ok=True)
+    tmp = os.path.join(outdir, "tmp") + "/"
+    os.makedirs(tmp, exist_ok=True)
+
+    if args.corrected:
+        infile = long_reads
+    else:                                                       # HyLight.py:85-112
+        if not args.short_reads:
+            raise SystemExit("read correction needs --short_reads (or pass --corrected)")
+        short_reads = os.path.abspath(args.short_reads)
+        bfc, rope, conv, fml = _tool("bfc"), _tool("ropebwt2"), _tool("fmlrc2-convert"), _tool("fmlrc2")
+        cor = os.path.join(tmp, "cor_short_reads.fq")
+        _run(f"{bfc} -s 3g -t{args.threads} {short_reads} 2>/dev/null | awk 'NR%4==1{{print $1; next}} {{print}}' > {cor}")
+        _run(f"cat {cor} | awk 'NR % 4 == 2' | sort | tr NT TN | {rope} -LR | tr NT TN | {conv} {tmp}/comp_msbwt.npy")
+        _run(f"{fml} -t 30 -m 2 comp_msbwt.npy {long_reads} fmlrc1.fasta && {fml} -t 30 -m 2 comp_msbwt.npy fmlrc1.fasta "
+             f"fmlrc2.fasta && {fml} -t 30 -m 2 comp_msbwt.npy fmlrc2.fasta fmlrc3.fasta && rm fmlrc1.fasta fmlrc2.fasta", cwd=tmp)
+        infile = os.path.join(tmp, "fmlrc3.fasta")
+
+    infile = filter_non_atcg(infile, outdir, fq_or_fa(infile))  # HyLight.py:116-118
+    ovl_dir = os.path.join(outdir, "2.overlap")
+    shutil.rmtree(ovl_dir, ignore_errors=True)
+    os.makedirs(ovl_dir)
+    # main all-vs-all: len_over is hard-coded to 6000 here in the reference (HyLight.py:130)
+    overlap = stage(infile, infile, nsplit, os.path.join(ovl_dir, "s1_s1.paf"), 6000, 2, iden)
+    if args.stop_after == "overlap":
+        return 0
+    gfa, long_con = tmp + "contigs1.gfa", tmp + "contigs1.fa"
+    n_arg, c_arg = (3, 3) if args.low_quality else (1, 1)       # HyLight.py:137,140
+    api.miniasm(overlap, infile, gfa, bub_dist=max_tip, n_rounds_arg=n_arg, max_ext=1, min_dp=c_arg)
+    gfa2fa(gfa, long_con)
+    if args.stop_after == "contigs1":
+        return 0
+
+    ov_long_ref = stage(infile, long_con, nsplit, tmp + "ov_long_ref.paf", len_over, 2, iden)   # HyLight.py:149
+    racon = _tool("racon")
+    p1, p2 = tmp + "polish1.fa", tmp + "polish2.fa"
+    _run(f"{racon} --no-trimming -u -t 30 {infile} {ov_long_ref} {long_con} > {p1}", cwd=tmp)
+    ti = 0
+    while ti < 2 and not args.low_quality:                      # HyLight.py:158-190
+        remain = pick_up(ov_long_ref, tmp, infile)
+        if os.path.getsize(remain) == 0:
+            break
+        ov_remain = stage(remain, remain, nsplit, tmp + "ov_long_remain.paf", len_over, 2, iden)
+        remain_gfa = tmp + "remain.gfa"
+        api.miniasm(ov_remain, infile, remain_gfa, bub_dist=max_tip, n_rounds_arg=1, max_ext=1, min_dp=1)
+        if os.path.getsize(remain_gfa) == 0:                    # HyLight.py:173
+            break
+        remain_con = tmp + "remain_con.fa"
+        gfa2fa(remain_gfa, remain_con)
+        ov2 = stage(infile, remain_con, nsplit, tmp + "ov_long_ref2.paf", len_over, 2, iden)
+        _run(f"{racon} --no-trimming -u -t 30 {infile} {ov2} {remain_con} >> {p2}; cat {ov2} >> {ov_long_ref}", cwd=tmp)
+        ti += 1
+    long_con2 = tmp + "long_con_polished.fa"
+    with open(long_con2, "w") as o:                             # HyLight.py:192-201
+        num = 0
+        for p in (p1, p2):
+            if not os.path.exists(p):
+                continue
+            for line in open(p):
+                o.write(line if num % 2 == 1 else f">longr_con_{num // 2}\n")
+                num += 1
+    if args.stop_after == "polish":
+        return 0
+    raise SystemExit("long-read path finished (tmp/long_con_polished.fa).  The short-read branch (HyLight.py:198-280) "
+                     "needs the --sr overlapper mode, which is not built yet (SURVEY.md section 8f rank 1).")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

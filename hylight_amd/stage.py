@@ -15,9 +15,12 @@ from . import api
 
 
 class StageRunner:
-    def __init__(self, reads_fa, ref_fa, nsplit, long_mode=True, rank=0, world=1, group=None):
-        self.rank, self.world, self.group = rank, world, group
-        self.job = api.Job(reads_fa, ref_fa, nsplit, long_mode)
+    def __init__(self, reads_fa, ref_fa, nsplit, long_mode=True, rank=0, world=1, group=None, job=None,
+                 device="cuda"):
+        """`job` / `device` exist for the CPU (gloo) tests of the exchange logic: the product always uses
+        api.Job on "cuda"."""
+        self.rank, self.world, self.group, self.device = rank, world, group, device
+        self.job = job if job is not None else api.Job(reads_fa, ref_fa, nsplit, long_mode)
         self._keep = None
 
     def close(self):
@@ -26,37 +29,39 @@ class StageRunner:
     # -- sketch exchange -------------------------------------------------------------------------
     def _install_sketch(self):
         import torch
-        job, world, rank = self.job, self.world, self.rank
+        job, world, rank, dev = self.job, self.world, self.rank, self.device
         nq = job.num_queries
         lo, hi = rank * nq // world, (rank + 1) * nq // world
         cap = max(job.sketch_bound(lo, hi), 1)
-        mz = torch.empty((cap, 2), dtype=torch.int64, device="cuda")
-        cnt = torch.zeros(max(hi - lo, 1), dtype=torch.int32, device="cuda")
+        mz = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+        cnt = torch.zeros(max(hi - lo, 1), dtype=torch.int32, device=dev)
         n = job.sketch(lo, hi, mz.data_ptr(), cap, cnt.data_ptr()) if hi > lo else 0
         if world == 1:
             all_mz, all_cnt, total = mz[:max(n, 1)], cnt, n
         else:
             import torch.distributed as dist
-            sizes = torch.tensor([n, hi - lo], dtype=torch.int64, device="cuda")
-            gathered = torch.empty((world, 2), dtype=torch.int64, device="cuda")
+            sizes = torch.tensor([n, hi - lo], dtype=torch.int64, device=dev)
+            gathered = torch.empty(world * 2, dtype=torch.int64, device=dev)      # flat: gloo and RCCL both take it
             dist.all_gather_into_tensor(gathered, sizes, group=self.group)
-            g = gathered.cpu().tolist()
+            g = gathered.view(world, 2).cpu().tolist()
             max_n, max_q = max(max(x[0] for x in g), 1), max(max(x[1] for x in g), 1)
             # RCCL all-gather of equally sized slabs (ring over xGMI: (N-1)/N of the sketch per link)
-            send = torch.zeros((max_n, 2), dtype=torch.int64, device="cuda")
+            send = torch.zeros((max_n, 2), dtype=torch.int64, device=dev)
             send[:n] = mz[:n]
-            recv = torch.empty((world * max_n, 2), dtype=torch.int64, device="cuda")
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-            csend = torch.zeros(max_q, dtype=torch.int32, device="cuda")
+            recv = torch.empty(world * max_n * 2, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)
+            recv = recv.view(world * max_n, 2)
+            csend = torch.zeros(max_q, dtype=torch.int32, device=dev)
             csend[:hi - lo] = cnt[:hi - lo]
-            crecv = torch.empty(world * max_q, dtype=torch.int32, device="cuda")
+            crecv = torch.empty(world * max_q, dtype=torch.int32, device=dev)
             dist.all_gather_into_tensor(crecv, csend, group=self.group)
             all_mz = torch.cat([recv[r * max_n:r * max_n + g[r][0]] for r in range(world)]).contiguous()
             all_cnt = torch.cat([crecv[r * max_q:r * max_q + g[r][1]] for r in range(world)]).contiguous()
             total = int(sum(x[0] for x in g))
             if all_mz.shape[0] == 0:
-                all_mz = torch.zeros((1, 2), dtype=torch.int64, device="cuda")
-        torch.cuda.synchronize()
+                all_mz = torch.zeros((1, 2), dtype=torch.int64, device=dev)
+        if dev == "cuda":
+            torch.cuda.synchronize()
         self._keep = (all_mz, all_cnt)          # the library reads these buffers during run()
         job.set_query_sketch(all_mz.data_ptr(), total, all_cnt.data_ptr())
 
@@ -66,7 +71,7 @@ class StageRunner:
         self._install_sketch()
         part = out_paf if self.world == 1 else f"{out_paf}.part{self.rank}"
         self.job.run(self.rank, self.world, len_over, mc, iden, part)
-        rows = int(api.last_stats().get("rows_out", 0))
+        rows = int(self.job.rows_out()) if hasattr(self.job, "rows_out") else int(api.last_stats().get("rows_out", 0))
         if self.world > 1 and merge:
             import torch.distributed as dist
             dist.barrier(group=self.group)
