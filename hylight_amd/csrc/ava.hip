@@ -84,28 +84,37 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
 
     // ---- S1 (targets) + S2 ---------------------------------------------------------------------------
     DevSketch tsk;
-    sketch_device(*in.T, o.k, o.w, o.hpc, 0, tsk);
     DevIndex ix;
-    build_index(tsk, in.d_chunk_of_t, in.n_chunks, o, ix);
-    tsk.mz.release();
+    {
+        HostTimer ht("index");
+        sketch_device(*in.T, o.k, o.w, o.hpc, 0, tsk);
+        build_index(tsk, in.d_chunk_of_t, in.n_chunks, o, ix);
+        tsk.mz.release();
+    }
     stat_add("index_entries", (double)ix.n);
 
     // ---- query batches ----------------------------------------------------------------------------------
     std::vector<AlignOut> parts;
     SeedStats st;
+    SeedPlan plan;
+    {
+        HostTimer ht("plan_seeds");
+        plan_seeds(in, ix, plan);
+    }
     size_t q = 0;
     while (q < nQ) {
-        size_t hi = std::min(nQ, q + QUERY_BATCH);
-        std::vector<uint64_t> per_q = count_anchors_per_query(in, ix, q, hi);
         uint64_t acc = 0;
-        size_t take = 0;
-        while (take < per_q.size() && (take == 0 || acc + per_q[take] <= ANCHOR_BATCH)) acc += per_q[take++];
-        hi = q + take;
+        size_t hi = q;
+        while (hi < nQ && hi - q < QUERY_BATCH && (hi == q || acc + plan.per_query[hi] <= ANCHOR_BATCH)) acc += plan.per_query[hi++];
         ChainOut ch;
-        seed_and_chain(in, ix, o, qlen.p, tlen.p, q, hi, ch, st);
+        {
+            HostTimer ht("seed_and_chain");
+            seed_and_chain(in, ix, o, plan, qlen.p, tlen.p, q, hi, ch, st);
+        }
         stat_add("pieces", (double)ch.n_pieces);
         if (ch.n_pieces) {
             AlignOut ao;
+            HostTimer ht("align_pieces");
             align_pieces(in, o, qlen.p, tlen.p, ch, ao);
             if (ao.n_rows) parts.push_back(std::move(ao));
         }
@@ -115,6 +124,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     stat_add("chain_groups", (double)st.groups);
 
     // ---- concatenate + stream order ---------------------------------------------------------------------
+    HostTimer ht_concat("concat_order");
     size_t R = 0, E = 0;
     for (auto &p : parts) { R += p.n_rows; E += p.n_ops; }
     stat_add("ava_rows", (double)R);

@@ -91,6 +91,7 @@ struct AlignArgs {
     const uint64_t *qoff, *toff;
     const uint32_t *qlen;
     int match, mismatch, go, ge, ambi;
+    int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     TaskOut *out;
     uint32_t *runs;
     uint32_t cap_runs;
@@ -121,7 +122,10 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     for (size_t ti = wave; ti < a.n_tasks; ti += n_waves) {
         const Task tk = a.tasks[ti];
         TaskOut res{0, 0, 0, 0, 0, 0};
-        const int m = tk.m, n = tk.n;
+        const int n = tk.n;
+        // rows i > n - dlo have no cell inside the band (j = i + dlo + lane > n): an extension whose query
+        // side is longer than the target side + half band never looks at them
+        const int m = tk.m < n - tk.dlo ? tk.m : n - tk.dlo;
         if (m <= 0 || n <= 0) {
             if (lane == 0) a.out[ti] = res;
             continue;
@@ -140,6 +144,53 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         for (int x = lane; x < n; x += 64) st[x] = tbs[tk.kind == 1 ? tk.t0 - 1 - x : tk.t0 + x];
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        // ---- fast path: square block, no ambiguous base, at most kmax substitutions ---------------------------
+        // With delta = 0 any gapped path has >= 1 insertion and >= 1 deletion and <= m-1 diagonal moves, i.e.
+        // scores <= match*(m-1) - 2*(open+ext); the all-diagonal path with k mismatches scores
+        // match*(m-k) - mismatch*k, which is strictly larger while k*(match+mismatch) < match + 2*(open+ext).
+        // It is then the unique optimum, so the DP + traceback would return exactly these runs.
+        if (tk.kind == 0 && m == n) {
+            unsigned long long mis[4] = {0, 0, 0, 0};
+            bool ambig = false;
+            int k = 0;
+            for (int c = 0; c * 64 < m; ++c) {
+                const int x = c * 64 + lane;
+                bool ne = false;
+                if (x < m) { const uint8_t qa = sq[x], tb2 = st[x]; ne = qa != tb2; ambig |= (qa > 3 || tb2 > 3); }
+                mis[c] = __ballot(ne);
+                k += __popcll(mis[c]);
+            }
+            if (!__any(ambig) && k <= a.kmax) {
+                if (lane == 0) {
+                    uint32_t runs[8];
+                    uint32_t nr = 0;
+                    int prev = 0;                         // start of the pending '=' run
+                    int xrun_start = -1, xrun_end = -1;   // pending X run [start, end)
+                    for (int c = 0; c * 64 < m; ++c) {
+                        unsigned long long bits = mis[c];
+                        while (bits) {
+                            const int x = c * 64 + __ffsll((long long)bits) - 1;
+                            bits &= bits - 1;
+                            if (x == xrun_end) { xrun_end = x + 1; continue; }      // adjacent mismatch extends the X run
+                            if (xrun_start >= 0) { runs[nr++] = (uint32_t)(xrun_end - xrun_start) << 4 | OP_X; prev = xrun_end; }
+                            if (x > prev) runs[nr++] = (uint32_t)(x - prev) << 4 | OP_EQ;
+                            xrun_start = x; xrun_end = x + 1;
+                        }
+                    }
+                    if (xrun_start >= 0) { runs[nr++] = (uint32_t)(xrun_end - xrun_start) << 4 | OP_X; prev = xrun_end; }
+                    if (m > prev) runs[nr++] = (uint32_t)(m - prev) << 4 | OP_EQ;
+                    uint32_t off = atomicAdd(&a.counters[0], nr);
+                    bool ok = off + nr <= a.cap_runs;
+                    if (!ok) a.counters[1] = 1;
+                    else for (uint32_t r = 0; r < nr; ++r) a.runs[off + r] = runs[r];
+                    res.score = a.match * (m - k) - a.mismatch * k;
+                    res.bi = m; res.bj = n; res.runs_off = off; res.n_runs = ok ? nr : 0;
+                    a.out[ti] = res;
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
         // ---- DP ------------------------------------------------------------------------------------------------
         const int dlo = tk.dlo, go = a.go, ge = a.ge;
         int Hp = NEG_INF, Fp = NEG_INF;
@@ -361,6 +412,11 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p; aa.qoff = in.Q->off.p; aa.toff = in.T->off.p;
         aa.qlen = d_qlen;
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
+        {   // largest k with k*(match+mismatch) < match + 2*(open+ext), capped at 3 (7 runs)
+            const int den = o.match + o.mismatch, num = o.match + 2 * (o.gap_open + o.gap_ext);
+            aa.kmax = den > 0 && num > 0 ? std::min(3, (num - 1) / den) : 0;
+            if (o.match <= 0 || o.gap_open < 0 || o.gap_ext <= 0) aa.kmax = -1;   // proof needs sane scores
+        }
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         const unsigned nb = (unsigned)std::min<size_t>((NT + WAVES - 1) / WAVES, 256 * 16);
         {

@@ -86,33 +86,67 @@ struct SeedArgs {
     uint32_t q_lo;
 };
 
+// Wave-cooperative: a wave owns 64 consecutive query minimizers.  Every lane binary-searches the
+// occurrence run of its own minimizer; the wave then serves the 64 runs one after the other with the
+// lanes striding the run, so index reads and anchor writes are coalesced and the anchors of one
+// minimizer keep ascending occurrence order (ballot + popcount ranks the survivors).
 template <bool FILL>
-__global__ void seed_kernel(SeedArgs a, uint32_t *cnt, const uint64_t *aoff, uint64_t *okey, uint64_t *oval) {
-    size_t m = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (m >= a.n_mz) return;
-    const Mz z = a.qmz[m];
-    const uint64_t key = z.x >> 8;
-    const uint32_t q = (uint32_t)(z.y >> 32);
-    const uint32_t qspan = (uint32_t)(z.x & 0xff), qpos = (uint32_t)z.y >> 1, qz = (uint32_t)z.y & 1;
-    const uint32_t rq = a.rank_q[q];
-    uint32_t c = 0;
-    uint64_t w = FILL ? aoff[m] : 0;
-    for (size_t e = lower_bound_u64(a.ikey, a.n_idx, key); e < a.n_idx && a.ikey[e] == key; ++e) {
-        const uint64_t y = a.iy[e];
-        const uint32_t t = (uint32_t)(y >> 32);
-        if (a.iocc[e] > a.mid_occ[a.chunk_of_t[t]]) continue;    // too frequent inside that chunk
-        if (rq >= a.rank_t[t]) continue;                          // pair once (and never self)
-        if (FILL) {
-            const uint32_t tpos = (uint32_t)y >> 1, strand = qz ^ ((uint32_t)y & 1);
-            const uint32_t qp = strand ? a.qlen[q] - (qpos + 1 - qspan) - 1 : qpos;
-            okey[w] = (uint64_t)(q - a.q_lo) << (T_BITS + 1 + TPOS_BITS) | (uint64_t)t << (1 + TPOS_BITS) |
-                      (uint64_t)strand << TPOS_BITS | tpos;
-            oval[w] = (uint64_t)qp << 32 | (uint64_t)qspan << 24;
-            ++w;
-        }
-        ++c;
+__global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, const uint64_t *aoff, uint64_t *okey,
+                                                   uint64_t *oval) {
+    const int lane = threadIdx.x & 63;
+    const size_t m = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const bool live = m < a.n_mz;
+    Mz z{0, 0};
+    size_t lo = 0, hi = 0;
+    uint32_t rq = 0, ql = 0;
+    uint64_t w0 = 0;
+    if (live) {
+        z = a.qmz[m];
+        const uint64_t key = z.x >> 8;
+        lo = lower_bound_u64(a.ikey, a.n_idx, key);
+        hi = lo;
+        if (lo < a.n_idx && a.ikey[lo] == key) hi = lower_bound_u64(a.ikey + lo, a.n_idx - lo, key + 1) + lo;
+        const uint32_t q = (uint32_t)(z.y >> 32);
+        rq = a.rank_q[q];
+        if (FILL) { ql = a.qlen[q]; w0 = aoff[m]; }
     }
-    if (!FILL) cnt[m] = c;
+    uint32_t my_cnt = 0;
+    for (int b = 0; b < 64; ++b) {
+        const unsigned long long lo_b = __shfl((unsigned long long)lo, b, 64), hi_b = __shfl((unsigned long long)hi, b, 64);
+        if (hi_b == lo_b) continue;                     // wave-uniform
+        const uint32_t rq_b = __shfl(rq, b, 64);
+        const unsigned long long zx = __shfl((unsigned long long)z.x, b, 64), zy = __shfl((unsigned long long)z.y, b, 64);
+        unsigned long long w = FILL ? __shfl((unsigned long long)w0, b, 64) : 0;
+        const uint32_t ql_b = FILL ? __shfl(ql, b, 64) : 0;
+        uint32_t c = 0;
+        for (unsigned long long e0 = lo_b; e0 < hi_b; e0 += 64) {
+            const unsigned long long e = e0 + lane;
+            bool ok = false;
+            uint64_t y = 0;
+            if (e < hi_b) {
+                y = a.iy[e];
+                const uint32_t t = (uint32_t)(y >> 32);
+                ok = !(a.iocc[e] > a.mid_occ[a.chunk_of_t[t]])      // not too frequent inside that chunk
+                     && rq_b < a.rank_t[t];                          // pair once (and never self)
+            }
+            const unsigned long long mask = __ballot(ok);
+            if (FILL && ok) {
+                const uint32_t qspan = (uint32_t)(zx & 0xff), qpos = (uint32_t)zy >> 1, qz = (uint32_t)zy & 1;
+                const uint32_t q = (uint32_t)(zy >> 32), t = (uint32_t)(y >> 32);
+                const uint32_t tpos = (uint32_t)y >> 1, strand = qz ^ ((uint32_t)y & 1);
+                const uint32_t qp = strand ? ql_b - (qpos + 1 - qspan) - 1 : qpos;
+                const unsigned long long at = w + __popcll(mask & ((1ull << lane) - 1));
+                okey[at] = (uint64_t)(q - a.q_lo) << (T_BITS + 1 + TPOS_BITS) | (uint64_t)t << (1 + TPOS_BITS) |
+                           (uint64_t)strand << TPOS_BITS | tpos;
+                oval[at] = (uint64_t)qp << 32 | (uint64_t)qspan << 24;
+            }
+            const uint32_t n = (uint32_t)__popcll(mask);
+            w += n;
+            c += n;
+        }
+        if (lane == b) my_cnt = c;
+    }
+    if (!FILL && live) cnt[m] = my_cnt;
 }
 
 __global__ void gather_u64_at_kernel(const uint64_t *src, const uint64_t *idx, uint64_t *dst, size_t n) {
@@ -352,63 +386,55 @@ static SeedArgs make_seed_args(const AvaInput &in, const DevIndex &ix, const uin
     return sa;
 }
 
-std::vector<uint64_t> count_anchors_per_query(const AvaInput &in, const DevIndex &ix, size_t q_lo, size_t q_hi) {
-    std::vector<uint64_t> per_q(q_hi - q_lo, 0);
-    SeedArgs sa = make_seed_args(in, ix, nullptr, q_lo, q_hi);
-    if (!sa.n_mz || !ix.n) return per_q;
-    DBuf<uint32_t> cnt(sa.n_mz);
-    DBuf<uint64_t> aoff(sa.n_mz + 1);
-    hipLaunchKernelGGL(seed_kernel<false>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, cnt.p, nullptr, nullptr, nullptr);
-    HIP_CHECK(hipGetLastError());
-    exclusive_scan_u32_to_u64(cnt.p, aoff.p, sa.n_mz);
-    // cumulative anchors at the query boundaries
-    std::vector<uint64_t> bidx(q_hi - q_lo);
-    for (size_t q = q_lo; q < q_hi; ++q) bidx[q - q_lo] = in.qmz_off[q] - in.qmz_off[q_lo];
-    // the boundary of the last query needs the total
-    const uint64_t total = (uint64_t)download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt.p + (sa.n_mz - 1));
-    DBuf<uint64_t> d_bidx, d_b(q_hi - q_lo);
-    d_bidx.upload(bidx);
-    // boundaries equal to n_mz (queries without minimizers at the end) read the total instead
-    std::vector<uint64_t> cum(q_hi - q_lo + 1, total);
+void plan_seeds(const AvaInput &in, const DevIndex &ix, SeedPlan &plan) {
+    const size_t nQ = in.Q->n;
+    plan.per_query.assign(nQ, 0);
+    SeedArgs sa = make_seed_args(in, ix, nullptr, 0, nQ);
+    plan.cnt.alloc(sa.n_mz ? sa.n_mz : 1);
+    if (!sa.n_mz || !ix.n) { plan.cnt.zero(); return; }
     {
-        std::vector<uint64_t> safe = bidx;
-        for (auto &v : safe) if (v >= sa.n_mz) v = sa.n_mz - 1;
-        d_bidx.upload(safe);
-        hipLaunchKernelGGL(gather_u64_at_kernel, grid1(safe.size()), dim3(WG), 0, stream(), aoff.p, d_bidx.p, d_b.p, safe.size());
-        std::vector<uint64_t> hb = d_b.download(safe.size());
-        for (size_t i = 0; i < hb.size(); ++i) cum[i] = bidx[i] >= sa.n_mz ? total : hb[i];
+        KTimer kt("seed_count");
+        hipLaunchKernelGGL(seed_kernel<false>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, plan.cnt.p, nullptr, nullptr, nullptr);
     }
-    for (size_t i = 0; i + 1 < cum.size(); ++i) per_q[i] = cum[i + 1] - cum[i];
-    return per_q;
+    HIP_CHECK(hipGetLastError());
+    DBuf<uint64_t> aoff(sa.n_mz);
+    exclusive_scan_u32_to_u64(plan.cnt.p, aoff.p, sa.n_mz);
+    const uint64_t total = (uint64_t)download_one(aoff.p + (sa.n_mz - 1)) + download_one(plan.cnt.p + (sa.n_mz - 1));
+    // cumulative anchors at the query boundaries (queries without minimizers at the very end read the total)
+    std::vector<uint64_t> safe(nQ);
+    for (size_t q = 0; q < nQ; ++q) safe[q] = std::min<uint64_t>(in.qmz_off[q], sa.n_mz - 1);
+    DBuf<uint64_t> d_bidx, d_b(nQ);
+    d_bidx.upload(safe);
+    hipLaunchKernelGGL(gather_u64_at_kernel, grid1(nQ), dim3(WG), 0, stream(), aoff.p, d_bidx.p, d_b.p, nQ);
+    std::vector<uint64_t> cum = d_b.download(nQ);
+    cum.push_back(total);
+    for (size_t q = 0; q < nQ; ++q) if (in.qmz_off[q] >= sa.n_mz) cum[q] = total;
+    for (size_t q = 0; q < nQ; ++q) plan.per_query[q] = cum[q + 1] - cum[q];
 }
 
-void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const uint32_t *d_qlen,
-                    const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out, SeedStats &st) {
+void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const SeedPlan &plan,
+                    const uint32_t *d_qlen, const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out,
+                    SeedStats &st) {
     (void)d_tlen;
     out = ChainOut();
     if (q_hi - q_lo > (1u << QL_BITS)) fail(HLMI_EINVAL, "query batch larger than %d", 1 << QL_BITS);
     if (in.T->n > (1u << T_BITS)) fail(HLMI_EINVAL, "more than %d targets in one run", 1 << T_BITS);
     SeedArgs sa = make_seed_args(in, ix, d_qlen, q_lo, q_hi);
     if (!sa.n_mz || !ix.n) return;
-    DBuf<uint32_t> cnt(sa.n_mz);
+    const uint32_t *cnt = plan.cnt.p + in.qmz_off[q_lo];
     DBuf<uint64_t> aoff(sa.n_mz);
-    {
-        KTimer kt("seed_count");
-        hipLaunchKernelGGL(seed_kernel<false>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, cnt.p, nullptr, nullptr, nullptr);
-    }
-    HIP_CHECK(hipGetLastError());
-    exclusive_scan_u32_to_u64(cnt.p, aoff.p, sa.n_mz);
-    const size_t A = (size_t)(download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt.p + (sa.n_mz - 1)));
+    exclusive_scan_u32_to_u64(cnt, aoff.p, sa.n_mz);
+    const size_t A = (size_t)(download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt + (sa.n_mz - 1)));
     st.anchors += A;
     if (!A) return;
     if (A >= (1ull << 32)) fail(HLMI_EINVAL, "anchor batch too large");
+    HostTimer *ht_s = new HostTimer("seed_sort_phase");
     DBuf<uint64_t> akey(A), aval(A);
     {
         KTimer kt("seed_fill");
         hipLaunchKernelGGL(seed_kernel<true>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, nullptr, aoff.p, akey.p, aval.p);
     }
     HIP_CHECK(hipGetLastError());
-    cnt.release();
     aoff.release();
     const int qbits = bits_for((uint64_t)(q_hi - q_lo - 1 ? q_hi - q_lo - 1 : 1));
     {
@@ -421,7 +447,9 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     const size_t G = select_flagged_indices(head.p, gstart.p, A);
     head.release();
     st.groups += G;
+    delete ht_s;
 
+    HostTimer ht_c("chain_phase");
     DBuf<int32_t> f(A), p(A);
     DBuf<unsigned long long> bck(A);
     bck.zero();

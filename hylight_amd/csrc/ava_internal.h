@@ -32,11 +32,16 @@ struct ChainOut {
     DBuf<FixPt> fps;
 };
 struct SeedStats { uint64_t anchors = 0, groups = 0; };
+// one counting pass over ALL query minimizers: anchors per minimizer (device) and per query (host)
+struct SeedPlan {
+    DBuf<uint32_t> cnt;                 // per query minimizer
+    std::vector<uint64_t> per_query;    // per query read
+};
+void plan_seeds(const AvaInput &in, const DevIndex &ix, SeedPlan &plan);
 // seeds + chains queries [q_lo,q_hi)
-void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const uint32_t *d_qlen,
-                    const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out, SeedStats &st);
-// number of anchors each query of [q_lo, q_hi) generates (host vector), for batching
-std::vector<uint64_t> count_anchors_per_query(const AvaInput &in, const DevIndex &ix, size_t q_lo, size_t q_hi);
+void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const SeedPlan &plan,
+                    const uint32_t *d_qlen, const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out,
+                    SeedStats &st);
 
 // ---- S5: alignment of the pieces -> PAF rows -------------------------------------------------------
 struct AlignOut {

@@ -53,6 +53,16 @@ void stat_add(const std::string &k, double v);
 std::map<std::string, double> &stats();
 
 // ------------------------------------------------------------------------------------------
+// device memory: size-binned pool in front of hipMalloc / hipFree.  The stage works in query batches
+// whose multi-GB scratch buffers have the same sizes batch after batch; hipMalloc + hipFree of those
+// cost more than the kernels between them.  Everything runs on one stream, so a block can be handed
+// out again as soon as its owner releases it.
+// ------------------------------------------------------------------------------------------
+void *dev_alloc(size_t bytes);
+void dev_free(void *p);
+void dev_pool_trim();            // give every cached block back to the driver
+
+// ------------------------------------------------------------------------------------------
 // device buffer (RAII)
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -72,10 +82,10 @@ struct DBuf {
     void alloc(size_t count) {
         release();
         n = count;
-        if (count) HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        if (count) p = (T *)dev_alloc(count * sizeof(T));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p);
         p = nullptr; n = 0;
     }
     void zero() { if (n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), stream())); }
@@ -107,6 +117,14 @@ struct KTimer {
     size_t slot;
 };
 void ktimer_flush();
+
+// Host wall-clock of a scope (stream drained at both ends) -> stats "host_s.<name>"
+struct HostTimer {
+    explicit HostTimer(const char *name);
+    ~HostTimer();
+    const char *name;
+    double t0;
+};
 
 template <typename T>
 T download_one(const T *dev) {

@@ -35,6 +35,7 @@ void init_device(int device, int threads) {
 
 void shutdown_device() {
     std::lock_guard<std::mutex> lk(g_mu);
+    dev_pool_trim();
     if (g_stream) {
         (void)hipStreamSynchronize(g_stream);
         (void)hipStreamDestroy(g_stream);
@@ -77,6 +78,71 @@ void ktimer_flush() {
         (void)hipEventDestroy(r.b);
     }
     g_krecs.clear();
+}
+
+// ---- pooled device allocator -----------------------------------------------------------------------
+namespace {
+std::multimap<size_t, void *> g_free_blocks;            // size -> block
+std::unordered_map<void *, size_t> g_block_size;         // every live or cached block
+size_t g_pooled_bytes = 0;
+constexpr size_t POOL_CAP = 160ull << 30;                // keep at most this much cached (288 GB HBM)
+constexpr size_t GRAN = 2ull << 20;
+}  // namespace
+
+void *dev_alloc(size_t bytes) {
+    const size_t want = (bytes + GRAN - 1) / GRAN * GRAN;
+    auto it = g_free_blocks.lower_bound(want);
+    if (it != g_free_blocks.end() && it->first <= want + want / 2) {
+        void *p = it->second;
+        g_pooled_bytes -= it->first;
+        g_free_blocks.erase(it);
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {                                // out of memory: drop the cache and retry once
+        dev_pool_trim();
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) fail(HLMI_ENOMEM, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+    g_block_size[p] = want;
+    return p;
+}
+
+void dev_free(void *p) {
+    auto it = g_block_size.find(p);
+    if (it == g_block_size.end()) { (void)hipFree(p); return; }
+    if (g_pooled_bytes + it->second > POOL_CAP) {
+        (void)hipFree(p);
+        g_block_size.erase(it);
+        return;
+    }
+    g_free_blocks.emplace(it->second, p);
+    g_pooled_bytes += it->second;
+}
+
+void dev_pool_trim() {
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (auto &kv : g_free_blocks) {
+        (void)hipFree(kv.second);
+        g_block_size.erase(kv.second);
+    }
+    g_free_blocks.clear();
+    g_pooled_bytes = 0;
+}
+
+static double wall_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+HostTimer::HostTimer(const char *n) : name(n) {
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    t0 = wall_s();
+}
+HostTimer::~HostTimer() {
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    g_stats[std::string("host_s.") + name] += wall_s() - t0;
 }
 
 void stat_reset() { g_stats.clear(); }
