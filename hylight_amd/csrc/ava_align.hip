@@ -16,6 +16,7 @@
 
 #include "ava_internal.h"
 #include "dev_prims.h"
+#include "wave_ops.h"
 
 namespace hlmi {
 
@@ -83,6 +84,9 @@ __global__ void task_bases_kernel(const Task *tasks, size_t n, unsigned long lon
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
 }
 
+struct TaskOut;
+__global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long long *acc);
+
 struct AlignArgs {
     const Task *tasks;
     size_t n_tasks;
@@ -109,6 +113,24 @@ __device__ __forceinline__ int wave_prefix_max_excl(int v, int lane) {
     return lane == 0 ? NEG_INF * 2 : r;
 }
 
+// CIGAR-run pool: a wave reserves RUN_CHUNK entries with ONE global atomic and hands them out locally
+// (a single contended counter word saturates near 90 M atomics/s - more than 100 M tasks per step would
+// serialise on it).  Only lane 0 allocates.
+constexpr uint32_t RUN_CHUNK = 4096;
+__device__ __forceinline__ uint32_t pool_take(const AlignArgs &a, uint32_t n, uint32_t &chunk_off, uint32_t &chunk_left,
+                                              bool &ok) {
+    if (n > chunk_left) {
+        const uint32_t want = n > RUN_CHUNK ? n : RUN_CHUNK;
+        chunk_off = atomicAdd(&a.counters[0], want);
+        chunk_left = want;
+        if ((unsigned long long)chunk_off + want > a.cap_runs) { a.counters[1] = 1; chunk_left = 0; ok = false; return 0; }
+    }
+    const uint32_t off = chunk_off;
+    chunk_off += n;
+    chunk_left -= n;
+    return off;
+}
+
 __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     __shared__ unsigned long long s_tb[WAVES][TB_ROWS][4];
     __shared__ uint8_t s_q[WAVES][EXT_MAX];
@@ -119,6 +141,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     unsigned long long(*tb)[4] = s_tb[wv];
     uint8_t *sq = s_q[wv], *st = s_t[wv], *su = s_u[wv];
+    uint32_t chunk_off = 0, chunk_left = 0;
     for (size_t ti = wave; ti < a.n_tasks; ti += n_waves) {
         const Task tk = a.tasks[ti];
         TaskOut res{0, 0, 0, 0, 0, 0};
@@ -179,12 +202,11 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
                     }
                     if (xrun_start >= 0) { runs[nr++] = (uint32_t)(xrun_end - xrun_start) << 4 | OP_X; prev = xrun_end; }
                     if (m > prev) runs[nr++] = (uint32_t)(m - prev) << 4 | OP_EQ;
-                    uint32_t off = atomicAdd(&a.counters[0], nr);
-                    bool ok = off + nr <= a.cap_runs;
-                    if (!ok) a.counters[1] = 1;
-                    else for (uint32_t r = 0; r < nr; ++r) a.runs[off + r] = runs[r];
+                    bool ok = true;
+                    const uint32_t off = pool_take(a, nr, chunk_off, chunk_left, ok);
+                    if (ok) for (uint32_t r = 0; r < nr; ++r) a.runs[off + r] = runs[r];
                     res.score = a.match * (m - k) - a.mismatch * k;
-                    res.bi = m; res.bj = n; res.runs_off = off; res.n_runs = ok ? nr : 0;
+                    res.bi = m; res.bj = n; res.runs_off = off; res.n_runs = ok ? nr : 0; res.pad = 1;
                     a.out[ti] = res;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -198,8 +220,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         for (int i = 0; i <= m; ++i) {
             const int j = i + dlo + lane;
             const bool valid = j >= 0 && j <= n;
-            int Hup = __shfl_down(Hp, 1, 64), Fup = __shfl_down(Fp, 1, 64);
-            if (lane == 63) { Hup = NEG_INF; Fup = NEG_INF; }
+            const int Hup = wave_shl1(Hp, NEG_INF), Fup = wave_shl1(Fp, NEG_INF);   // lane d+1 of the previous row
             int mm = NEG_INF, f = NEG_INF;
             bool flagF = false;
             if (valid && i > 0) {
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             int ht = mm > f ? mm : f;
             if (i == 0 && j == 0) ht = 0;
             if (!valid) ht = NEG_INF;
-            const int pm = wave_prefix_max_excl(ht + ge * lane, lane);
+            const int pm = wave_shr1(wave_prefix_max_incl_dpp(ht + ge * lane, NEG_INF * 2), NEG_INF * 2);
             int e = NEG_INF;
             if (valid && j > 0 && lane > 0) e = pm - go - ge * lane;
             int h, src;
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             else if (e >= f) { h = e; src = 1; }
             else { h = f; src = 2; }
             if (!valid) { h = NEG_INF; f = NEG_INF; e = NEG_INF; }
-            const int Hl = __shfl_up(h, 1, 64), El = __shfl_up(e, 1, 64);
+            const int Hl = wave_shr1(h, NEG_INF), El = wave_shr1(e, NEG_INF);
             const bool flagE = lane > 0 && !(Hl - go - ge >= El - ge);
             const unsigned long long b0 = __ballot(src & 1), b1 = __ballot(src & 2), b2 = __ballot(flagE), b3 = __ballot(flagF);
             if (lane == 0) { tb[i][0] = b0; tb[i][1] = b1; tb[i][2] = b2; tb[i][3] = b3; }
@@ -285,10 +306,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             }
             uint32_t off = 0;
             bool ok = true;
-            if (n_runs) {
-                off = atomicAdd(&a.counters[0], n_runs);
-                if (off + n_runs > a.cap_runs) { a.counters[1] = 1; ok = false; }
-            }
+            if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
             if (ok && n_runs) {
                 uint32_t w = off, len = 0;
                 uint8_t code = 0;
@@ -300,11 +318,20 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
                 }
                 a.runs[w++] = len << 4 | code;
             }
-            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0;
+            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0; res.pad = 2u | (uint32_t)m << 2;
             a.out[ti] = res;
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+__global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long long *acc) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    unsigned long long f = 0, d = 0, r = 0;
+    if (i < n) { const uint32_t p = out[i].pad; f = p == 1; d = (p & 3) == 2; r = d ? p >> 2 : 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); d += __shfl_xor(d, o, 64); r += __shfl_xor(r, o, 64); }
+    if ((threadIdx.x & 63) == 0) { if (f) atomicAdd(&acc[0], f); if (d) atomicAdd(&acc[1], d); if (r) atomicAdd(&acc[2], r); }
 }
 
 // ---- assembly of the task results into PAF rows ----------------------------------------------------------
@@ -401,7 +428,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
     DBuf<uint32_t> counters(2);
-    size_t cap_runs = std::max<size_t>(NT * 24, 1 << 16);
+    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + (size_t)256 * 16 * WAVES * RUN_CHUNK;   // + one open chunk per wave
     DBuf<uint32_t> runs;
     for (int attempt = 0;; ++attempt) {
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
@@ -430,6 +457,15 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         cap_runs *= 4;
     }
     stat_add("align_tasks", (double)NT);
+    {   // how many tasks took the diagonal fast path / the DP (and how many DP rows)
+        DBuf<unsigned long long> acc(3);
+        acc.zero();
+        hipLaunchKernelGGL(task_kind_kernel, grid1(NT), dim3(WG), 0, stream(), tout.p, NT, acc.p);
+        std::vector<unsigned long long> h = acc.download(3);
+        stat_add("align_tasks_fast", (double)h[0]);
+        stat_add("align_tasks_dp", (double)h[1]);
+        stat_add("align_dp_rows", (double)h[2]);
+    }
     {
         DBuf<unsigned long long> sum(1);
         sum.zero();

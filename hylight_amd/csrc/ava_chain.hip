@@ -16,6 +16,7 @@
 
 #include "ava_internal.h"
 #include "dev_prims.h"
+#include "wave_ops.h"
 
 namespace hlmi {
 
@@ -183,59 +184,86 @@ struct ChainArgs {
     size_t n_groups, n_anchors;
     int32_t *f, *p;
     unsigned long long *bck;          // best child: f << 32 | ~index
+    int *mem;                         // member lists of the chains (phase C scratch, one slot per anchor)
     int k, max_gap, bw, min_score, min_cnt;
     uint32_t q_lo;
     Piece *pieces;
     FixPt *fps;
     uint32_t cap_pieces, cap_fps;
     uint32_t *counters;               // [0] pieces, [1] fixed points, [2] overflow flag
+    int dbg_phases;                   // timing ablation only (HLMI_CHAIN_PHASES): 1 = A, 3 = A+B, 7 = all
 };
 
-// walks one chain (start s, first `len` anchors along best-child links) and either counts or writes
-// its alignment pieces; mirrors oracle/ava_oracle.c:align_chain's fixed-point selection
+// Chain walk (phase C).  A 64-anchor window of the group is held in registers (lane l = anchor base+l):
+// chains only move forward through the group (children have larger indices, a best child is at most
+// CHAIN_PRED ahead), so a walk touches every anchor once, window loads are coalesced and the walk itself runs
+// on v_readlane instead of dependent global loads.  All lanes execute it uniformly.
+__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return (unsigned long long)hi << 32 | lo;
+}
+
+// Fixed-point selection over the member list mem[0..len) of one chain (oracle/ava_oracle.c:align_chain).
+// 64 members at a time sit in registers; the next fixed point = first later member that is >= BLOCK_MIN away
+// in both sequences (or the last member) comes from one ballot instead of a scan over ~16 anchors.
 template <bool WRITE>
-__device__ void emit_chain(const ChainArgs &a, size_t b, int s, int len, uint32_t q, uint32_t t, uint32_t strand,
-                           uint32_t &n_pieces, uint32_t &n_fps, uint32_t piece_base, uint32_t fp_base) {
-    int cur = s, prev = -1;
+__device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *mem, int s, int len, uint32_t q, uint32_t t,
+                           uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t piece_base, uint32_t fp_base) {
     bool open = false;
     int cq = 0, ct = 0;
     uint32_t np = 0, nf = 0, piece_fp0 = 0;
+    const bool wr = WRITE && lane == 0;
+    int base = -(1 << 30), te_l = 0, qe_l = 0, sp_l = 0;
     for (int x = 0; x < len;) {
-        const uint64_t key = a.key[b + cur], val = a.val[b + cur];
-        const int te = (int)(key & 0x7fffffffu) + 1, qe = (int)(val >> 32) + 1, sp = (int)((val >> 24) & 0xff);
-        bool advance = true;
-        if (!open) {
+        if (x < base || x >= base + 64) {                      // load the window of members x .. x+63
+            base = x;
+            te_l = qe_l = sp_l = 0;
+            if (x + lane < len) {
+                const int idx = mem[x + lane];
+                const uint64_t key = a.key[b + idx], val = a.val[b + idx];
+                te_l = (int)(key & 0x7fffffffu) + 1; qe_l = (int)(val >> 32) + 1; sp_l = (int)((val >> 24) & 0xff);
+            }
+        }
+        if (!open) {                                           // a piece starts at the START of member x
+            const int l = x - base;
+            const int te = __builtin_amdgcn_readlane(te_l, l), qe = __builtin_amdgcn_readlane(qe_l, l),
+                      sp = __builtin_amdgcn_readlane(sp_l, l);
             int q0 = qe - sp, t0 = te - sp;
             if (q0 < 0 || t0 < 0) { int sh = q0 < t0 ? -q0 : -t0; q0 += sh; t0 += sh; }
             if (q0 < 0) q0 = 0;
             if (t0 < 0) t0 = 0;
             if (block_ok(q0, t0, qe, te)) {
                 piece_fp0 = nf;
-                if (WRITE) { a.fps[fp_base + nf] = FixPt{(uint32_t)q0, (uint32_t)t0}; a.fps[fp_base + nf + 1] = FixPt{(uint32_t)qe, (uint32_t)te}; }
+                if (wr) { a.fps[fp_base + nf] = FixPt{(uint32_t)q0, (uint32_t)t0}; a.fps[fp_base + nf + 1] = FixPt{(uint32_t)qe, (uint32_t)te}; }
                 nf += 2;
                 cq = qe; ct = te; open = true;
             }
-        } else if (((qe - cq >= BLOCK_MIN && te - ct >= BLOCK_MIN) || x == len - 1) && qe > cq && te > ct) {
-            if (block_ok(cq, ct, qe, te)) {
-                if (WRITE) a.fps[fp_base + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
-                ++nf;
-                cq = qe; ct = te;
-            } else {                                   // split: close here, reopen at this anchor
-                if (WRITE) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
-                ++np;
-                open = false;
-                advance = false;
-            }
-        }
-        if (advance) {
             ++x;
-            prev = cur;
-            if (x < len) cur = (int)(0xffffffffu - (uint32_t)(a.bck[b + cur] & 0xffffffffull));
+            continue;
+        }
+        // open piece: first member j >= x in the window that qualifies as the next fixed point
+        const int j_l = base + lane;
+        const bool ok = j_l >= x && j_l < len && qe_l > cq && te_l > ct &&
+                        ((qe_l - cq >= BLOCK_MIN && te_l - ct >= BLOCK_MIN) || j_l == len - 1);
+        const unsigned long long m = __ballot(ok);
+        if (!m) { x = base + 64; continue; }                   // nothing in this window
+        const int l = __ffsll((long long)m) - 1;
+        const int te = __builtin_amdgcn_readlane(te_l, l), qe = __builtin_amdgcn_readlane(qe_l, l);
+        if (block_ok(cq, ct, qe, te)) {
+            if (wr) a.fps[fp_base + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
+            ++nf;
+            cq = qe; ct = te;
+            x = base + l + 1;
+        } else {                                               // split: close here, reopen at this member
+            if (wr) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
+            ++np;
+            open = false;
+            x = base + l;
         }
     }
-    (void)prev;
     if (open) {
-        if (WRITE) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
+        if (wr) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
         ++np;
     }
     n_pieces = np;
@@ -264,7 +292,8 @@ __global__ __launch_bounds__(WG) void chain_kernel(ChainArgs a) {
             const int nb = n - i0 < 64 ? n - i0 : 64;
             for (int bb = 0; bb < nb; ++bb) {
                 const int i = i0 + bb;
-                const int ti = __shfl(my_t, bb, 64), qi = __shfl(my_q, bb, 64), si = __shfl(my_s, bb, 64);
+                const int ti = __builtin_amdgcn_readlane(my_t, bb), qi = __builtin_amdgcn_readlane(my_q, bb),
+                          si = __builtin_amdgcn_readlane(my_s, bb);
                 const int dr = ti - r_t, dq = qi - r_q;
                 uint32_t k32 = 0;
                 if (lane < i && dr <= a.max_gap && dq > 0 && dq <= a.max_gap && dr != 0) {
@@ -277,20 +306,20 @@ __global__ __launch_bounds__(WG) void chain_kernel(ChainArgs a) {
                         k32 = (uint32_t)(cand + 1024) << 6 | (uint32_t)(63 - lane);
                     }
                 }
-                const uint32_t best = wave_max_u32(k32);
+                const uint32_t best = wave_max_u32_dpp(k32);
                 int bf = si, bp = -1;
                 if (best) {
                     const int c = (int)(best >> 6) - 1024;
                     if (c > si) { bf = c; bp = i - 1 - (63 - (int)(best & 63)); }
                 }
                 if (lane == 0) { a.f[b + i] = bf; a.p[b + i] = bp; }
-                r_t = __shfl_up(r_t, 1, 64);
-                r_q = __shfl_up(r_q, 1, 64);
-                r_f = __shfl_up(r_f, 1, 64);
-                if (lane == 0) { r_t = ti; r_q = qi; r_f = bf; }
+                r_t = wave_shr1(r_t, ti);       // ring: lane l <- lane l-1, lane 0 <- anchor i
+                r_q = wave_shr1(r_q, qi);
+                r_f = wave_shr1(r_f, bf);
             }
         }
         __threadfence_block();
+        if (!(a.dbg_phases & 2)) continue;
         // ---- phase B: best child of every anchor -------------------------------------------------------------
         for (int i = lane; i < n; i += 64) {
             const int pi = a.p[b + i];
@@ -298,32 +327,71 @@ __global__ __launch_bounds__(WG) void chain_kernel(ChainArgs a) {
                 atomicMax(&a.bck[b + pi], (unsigned long long)(uint32_t)a.f[b + i] << 32 | (0xffffffffu - (uint32_t)i));
         }
         __threadfence_block();
-        // ---- phase C: every lane walks the chains that start at its anchors ------------------------------------
+        if (!(a.dbg_phases & 4)) continue;
+        // ---- phase C: chain starts are found 64 anchors at a time; the wave walks each chain together --------------
         const uint64_t key0 = a.key[b];
         const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (T_BITS + 1 + TPOS_BITS));
         const uint32_t tg = (uint32_t)(key0 >> (1 + TPOS_BITS)) & ((1u << T_BITS) - 1);
         const uint32_t strand = (uint32_t)(key0 >> TPOS_BITS) & 1u;
-        for (int s = lane; s < n; s += 64) {
-            const int ps = a.p[b + s];
-            if (ps >= 0 && (0xffffffffu - (uint32_t)(a.bck[b + ps] & 0xffffffffull)) == (uint32_t)s) continue;
-            int len = 1, best_len = 1, cur = s;
-            int best_f = a.f[b + s];
-            while (true) {
-                const unsigned long long bc = a.bck[b + cur];
-                if (!bc) break;
-                cur = (int)(0xffffffffu - (uint32_t)(bc & 0xffffffffull));
-                ++len;
-                const int fc = (int)(bc >> 32);            // = f[cur]
-                if (fc > best_f) { best_f = fc; best_len = len; }
+        int moff = 0;                                      // member lists of the group's chains are disjoint
+        for (int s0 = 0; s0 < n; s0 += 64) {
+            int ps = -1, fs = 0, fps_ = 0;
+            bool cand = false;
+            if (s0 + lane < n) {
+                const int s = s0 + lane;
+                ps = a.p[b + s];
+                fs = a.f[b + s];
+                bool start = true;
+                if (ps >= 0) {
+                    start = (0xffffffffu - (uint32_t)(a.bck[b + ps] & 0xffffffffull)) != (uint32_t)s;
+                    fps_ = a.f[b + ps];
+                }
+                // a childless start is a one-anchor chain: it can only survive when min_cnt <= 1
+                cand = start && (a.min_cnt <= 1 || a.bck[b + s] != 0);
             }
-            const int sc = best_f - (ps >= 0 ? a.f[b + ps] : 0);
-            if (sc < a.min_score || best_len < a.min_cnt) continue;
-            uint32_t np = 0, nf = 0;
-            emit_chain<false>(a, b, s, best_len, qg, tg, strand, np, nf, 0, 0);
-            if (!np) continue;
-            const uint32_t pb = atomicAdd(&a.counters[0], np), fb = atomicAdd(&a.counters[1], nf);
-            if (pb + np > a.cap_pieces || fb + nf > a.cap_fps) { a.counters[2] = 1; continue; }
-            emit_chain<true>(a, b, s, best_len, qg, tg, strand, np, nf, pb, fb);
+            unsigned long long cm = __ballot(cand);
+            while (cm) {
+                const int l = __ffsll((long long)cm) - 1;
+                cm &= cm - 1;
+                const int s = s0 + l;
+                const int ps_s = __builtin_amdgcn_readlane(ps, l), f_s = __builtin_amdgcn_readlane(fs, l),
+                          f_ps = __builtin_amdgcn_readlane(fps_, l);
+                // walk 1: member list (into mem[moff..]) and the peak
+                int len = 1, best_len = 1, cur = s, best_f = f_s;
+                int *mem = a.mem + b + moff;
+                int wbase = -(1 << 30), pend = 0;                  // pend: members gathered in `mreg`, not stored yet
+                unsigned long long wbck = 0;
+                int mreg = 0;
+                while (true) {
+                    if (lane == (pend & 63)) mreg = cur;            // member #pend of this 64-batch
+                    ++pend;
+                    if ((pend & 63) == 0) mem[pend - 64 + lane] = mreg;
+                    if (cur < wbase || cur >= wbase + 64) {
+                        wbase = cur;
+                        wbck = cur + lane < n ? a.bck[b + cur + lane] : 0ull;
+                    }
+                    const unsigned long long bc = rl64(wbck, cur - wbase);
+                    if (!bc) break;
+                    cur = (int)(0xffffffffu - (uint32_t)(bc & 0xffffffffull));
+                    ++len;
+                    const int fc = (int)(bc >> 32);            // = f[cur]
+                    if (fc > best_f) { best_f = fc; best_len = len; }
+                }
+                if ((pend & 63) && lane < (pend & 63)) mem[(pend & ~63) + lane] = mreg;
+                moff += len;
+                const int sc = best_f - (ps_s >= 0 ? f_ps : 0);
+                if (sc < a.min_score || best_len < a.min_cnt) continue;
+                __threadfence_block();
+                uint32_t np = 0, nf = 0;
+                emit_chain<false>(a, b, lane, mem, s, best_len, qg, tg, strand, np, nf, 0, 0);
+                if (!np) continue;
+                uint32_t pb = 0, fb = 0;
+                if (lane == 0) { pb = atomicAdd(&a.counters[0], np); fb = atomicAdd(&a.counters[1], nf); }
+                pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pb);
+                fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb);
+                if (pb + np > a.cap_pieces || fb + nf > a.cap_fps) { if (lane == 0) a.counters[2] = 1; continue; }
+                emit_chain<true>(a, b, lane, mem, s, best_len, qg, tg, strand, np, nf, pb, fb);
+            }
         }
     }
 }
@@ -457,9 +525,11 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     counters.zero();
     ChainArgs ca{};
     ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.n_groups = G; ca.n_anchors = A;
-    ca.f = f.p; ca.p = p.p; ca.bck = bck.p;
+    DBuf<int> mem(A);
+    ca.f = f.p; ca.p = p.p; ca.bck = bck.p; ca.mem = mem.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
+    ca.dbg_phases = getenv("HLMI_CHAIN_PHASES") ? atoi(getenv("HLMI_CHAIN_PHASES")) : 7;
     ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);
     ca.cap_fps = (uint32_t)std::min<size_t>(2 * A + 1024, 0xfffffff0u);
     out.pieces.alloc(ca.cap_pieces);

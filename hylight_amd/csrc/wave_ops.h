@@ -1,0 +1,52 @@
+// wave_ops.h - wave64 cross-lane primitives on DPP (gfx950 / GFX9 DPP controls).
+//
+// `__shfl*` lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~50-100 cycles of latency each); the
+// reductions / scans / one-lane shifts the DP kernels need per row are dependent chains of those.  The DPP
+// forms below are plain VALU instructions with a lane-select modifier.
+//   row_shr:n   0x110+n   lane i reads lane i-n inside its row of 16
+//   row_bcast15 0x142     lane 15 of each row -> every lane of the next row   (row_mask selects rows)
+//   row_bcast31 0x143     lane 31 -> rows 2,3
+//   wave_shr:1  0x138     lane i reads lane i-1 across the whole wave
+//   wave_shl:1  0x130     lane i reads lane i+1
+// Lanes whose source does not exist, or whose row/bank is masked off, keep `old`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hlmi {
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_i32(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// max over the 64 lanes (unsigned, identity 0), returned to every lane
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+    int x = (int)v;
+    auto mx = [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); };
+    x = mx(x, dpp_i32<0x111>(0, x));
+    x = mx(x, dpp_i32<0x112>(0, x));
+    x = mx(x, dpp_i32<0x114>(0, x));
+    x = mx(x, dpp_i32<0x118>(0, x));
+    x = mx(x, dpp_i32<0x142, 0xa>(0, x));
+    x = mx(x, dpp_i32<0x143, 0xc>(0, x));
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
+// inclusive prefix max over the 64 lanes (signed, `ident` = value smaller than every input)
+__device__ __forceinline__ int wave_prefix_max_incl_dpp(int x, int ident) {
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    x = mx(x, dpp_i32<0x111>(ident, x));
+    x = mx(x, dpp_i32<0x112>(ident, x));
+    x = mx(x, dpp_i32<0x114>(ident, x));
+    x = mx(x, dpp_i32<0x118>(ident, x));
+    x = mx(x, dpp_i32<0x142, 0xa>(ident, x));
+    x = mx(x, dpp_i32<0x143, 0xc>(ident, x));
+    return x;
+}
+
+// lane i <- lane i-1 (lane 0 keeps `lane0`)
+__device__ __forceinline__ int wave_shr1(int x, int lane0) { return dpp_i32<0x138>(lane0, x); }
+// lane i <- lane i+1 (lane 63 keeps `lane63`)
+__device__ __forceinline__ int wave_shl1(int x, int lane63) { return dpp_i32<0x130>(lane63, x); }
+
+}  // namespace hlmi
