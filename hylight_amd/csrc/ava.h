@@ -16,6 +16,9 @@ constexpr int BLOCK_MIN = 64;
 constexpr int BLOCK_MAX = 256;
 constexpr int BAND_W = 64;
 constexpr int BAND_PAD = 12;
+constexpr int NARROW_W = 16;        // blocks with |delta| <= NARROW_DELTA use a 16-diagonal band
+constexpr int NARROW_PAD = 5;
+constexpr int NARROW_DELTA = 5;
 constexpr int EXT_MAX = 256;
 constexpr int MIN_DP_SCORE = 80;
 constexpr int MAX_MID_OCC = 1000000;

@@ -34,7 +34,7 @@ struct Task {               // 32 B
     int32_t q0, t0;         // block: start fixed point; extensions: the fixed point extended from
     int32_t m, n;           // rows (query), cols (target)
     int32_t dlo;            // first diagonal of the band
-    uint32_t pad;
+    uint32_t narrow;        // 1: 16-diagonal band (block with |delta| <= NARROW_DELTA), 0: 64 diagonals
 };
 struct TaskOut {            // 24 B
     int32_t score;
@@ -64,7 +64,9 @@ __global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const u
     for (uint32_t b = 0; b + 1 < p.n_fp; ++b) {
         const int q0 = (int)fp[b].q, t0 = (int)fp[b].t, m = (int)fp[b + 1].q - q0, n2 = (int)fp[b + 1].t - t0;
         const int delta = n2 - m;
-        Task t{(uint32_t)i, 0u, q0, t0, m, n2, (delta < 0 ? delta : 0) - BAND_PAD, 0};
+        // band rule: near-diagonal blocks use the 16-diagonal band
+        const bool narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
+        Task t{(uint32_t)i, 0u, q0, t0, m, n2, (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD), narrow ? 1u : 0u};
         out[1 + b] = t;
     }
     {   // right extension
@@ -90,6 +92,8 @@ __global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long lon
 struct AlignArgs {
     const Task *tasks;
     size_t n_tasks;
+    const uint32_t *list;   // task ids this launch works on (n_list of them)
+    size_t n_list;
     const Piece *pieces;
     const uint8_t *qcodes, *tcodes;
     const uint64_t *qoff, *toff;
@@ -117,10 +121,11 @@ __device__ __forceinline__ int wave_prefix_max_excl(int v, int lane) {
 // (a single contended counter word saturates near 90 M atomics/s - more than 100 M tasks per step would
 // serialise on it).  Only lane 0 allocates.
 constexpr uint32_t RUN_CHUNK = 4096;
+constexpr uint32_t RUN_CHUNK_SMALL = 256;       // per 16-lane group leader (classify / narrow kernels)
 __device__ __forceinline__ uint32_t pool_take(const AlignArgs &a, uint32_t n, uint32_t &chunk_off, uint32_t &chunk_left,
-                                              bool &ok) {
+                                              bool &ok, uint32_t chunk = RUN_CHUNK) {
     if (n > chunk_left) {
-        const uint32_t want = n > RUN_CHUNK ? n : RUN_CHUNK;
+        const uint32_t want = n > chunk ? n : chunk;
         chunk_off = atomicAdd(&a.counters[0], want);
         chunk_left = want;
         if ((unsigned long long)chunk_off + want > a.cap_runs) { a.counters[1] = 1; chunk_left = 0; ok = false; return 0; }
@@ -142,7 +147,8 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     unsigned long long(*tb)[4] = s_tb[wv];
     uint8_t *sq = s_q[wv], *st = s_t[wv], *su = s_u[wv];
     uint32_t chunk_off = 0, chunk_left = 0;
-    for (size_t ti = wave; ti < a.n_tasks; ti += n_waves) {
+    for (size_t li = wave; li < a.n_list; li += n_waves) {
+        const size_t ti = a.list[li];
         const Task tk = a.tasks[ti];
         TaskOut res{0, 0, 0, 0, 0, 0};
         const int n = tk.n;
@@ -325,6 +331,219 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     }
 }
 
+// ---- pass 1: classification + diagonal fast path, one 16-lane group per task --------------------------------
+// cls[task] = 0 done here (empty task or fast path), 1 DP in the 16-diagonal band, 2 DP in the 64-diagonal band
+__device__ __forceinline__ uint8_t load_q(const AlignArgs &a, const Piece &pc, const uint8_t *qb, int ql, int pos) {
+    uint8_t c;
+    if (pc.strand) { c = qb[ql - 1 - pos]; c = c < 4 ? 3 - c : 4; } else c = qb[pos];
+    return c;
+}
+
+__global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+    const size_t grp = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4;
+    const size_t n_grp = ((size_t)gridDim.x * blockDim.x) >> 4;
+    uint32_t chunk_off = 0, chunk_left = 0;
+    const size_t rounds = (a.n_tasks + n_grp - 1) / n_grp;            // uniform trip count: ballots need every lane
+    for (size_t r = 0; r < rounds; ++r) {
+        const size_t ti = r * n_grp + grp;
+        const bool live = ti < a.n_tasks;
+        Task tk{};
+        if (live) tk = a.tasks[ti];
+        const int m = tk.m, n = tk.n;
+        uint8_t c = 2;
+        bool try_fast = false;
+        if (live) {
+            if (m <= 0 || n <= 0) c = 0;
+            else if (tk.kind == 0) { c = tk.narrow ? 1 : 2; try_fast = (m == n); }
+        }
+        // mismatch positions of square blocks, 16 bases per step; stop as soon as a group has too many
+        int k = 0, mpos[4] = {0, 0, 0, 0};
+        bool ambig = false;
+        const uint8_t *qb = nullptr, *tb = nullptr;
+        Piece pc{};
+        int ql = 0;
+        if (try_fast) {
+            pc = a.pieces[tk.piece];
+            qb = a.qcodes + a.qoff[pc.q];
+            tb = a.tcodes + a.toff[pc.t] + tk.t0;
+            ql = (int)a.qlen[pc.q];
+        }
+        int steps = try_fast ? (m + 15) >> 4 : 0;
+        steps = (int)wave_max_u32_dpp((uint32_t)steps);
+        for (int s = 0; s < steps; ++s) {
+            const int x = s * 16 + l;
+            bool ne = false;
+            if (try_fast && x < m && k <= a.kmax && !ambig) {
+                const uint8_t qa = load_q(a, pc, qb, ql, tk.q0 + x), t2 = tb[x];
+                ne = qa != t2;
+                ambig = qa > 3 || t2 > 3;
+            }
+            const unsigned long long bm = __ballot(ne), am = __ballot(ambig);
+            uint32_t bits = (uint32_t)(bm >> (16 * g)) & 0xffffu;
+            if ((am >> (16 * g)) & 0xffffull) ambig = true;
+            while (bits) {
+                const int b = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                if (k < 4) mpos[k] = s * 16 + b;
+                ++k;
+            }
+        }
+        if (try_fast && !ambig && k <= a.kmax) {
+            c = 0;
+            if (l == 0) {
+                uint32_t runs[8];
+                uint32_t nr = 0;
+                int prev = 0, xs = -1, xe = -1;
+                for (int i = 0; i < k; ++i) {
+                    const int x = mpos[i];
+                    if (x == xe) { xe = x + 1; continue; }
+                    if (xs >= 0) { runs[nr++] = (uint32_t)(xe - xs) << 4 | OP_X; prev = xe; }
+                    if (x > prev) runs[nr++] = (uint32_t)(x - prev) << 4 | OP_EQ;
+                    xs = x; xe = x + 1;
+                }
+                if (xs >= 0) { runs[nr++] = (uint32_t)(xe - xs) << 4 | OP_X; prev = xe; }
+                if (m > prev) runs[nr++] = (uint32_t)(m - prev) << 4 | OP_EQ;
+                bool ok = true;
+                const uint32_t off = pool_take(a, nr, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
+                if (ok) for (uint32_t q = 0; q < nr; ++q) a.runs[off + q] = runs[q];
+                TaskOut res{a.match * (m - k) - a.mismatch * k, m, n, off, ok ? nr : 0, 1};
+                a.out[ti] = res;
+            }
+        } else if (live && c == 0 && l == 0) {
+            a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
+        }
+        if (live && l == 0) cls[ti] = c;
+    }
+}
+
+__global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, uint8_t *f2) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) { f1[i] = cls[i] == 1; f2[i] = cls[i] == 2; }
+}
+
+// ---- pass 2a: DP of near-diagonal blocks, FOUR tasks per wave (one per row of 16 lanes) --------------------------
+// Same recurrences and tie rules as align_kernel with W = 16; every cross-lane step is a DPP row operation, so
+// the four groups of a wave never interact.  Traceback bits: one u64 per DP row and group (4 planes x 16 bits).
+constexpr int N_ROWS = BLOCK_MAX + 1;
+constexpr int N_T = BLOCK_MAX + NARROW_DELTA + 3;
+constexpr int N_U = 2 * BLOCK_MAX + NARROW_DELTA + 8;
+__global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
+    __shared__ unsigned long long s_tb[WAVES * 4][N_ROWS];
+    __shared__ uint8_t s_q[WAVES * 4][BLOCK_MAX];
+    __shared__ uint8_t s_t[WAVES * 4][N_T];
+    __shared__ uint8_t s_u[WAVES * 4][N_U];
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15, wv = threadIdx.x >> 6;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long *tb = s_tb[wv * 4 + g];
+    uint8_t *sq = s_q[wv * 4 + g], *st = s_t[wv * 4 + g], *su = s_u[wv * 4 + g];
+    uint32_t chunk_off = 0, chunk_left = 0;
+    const size_t n_quads = (a.n_list + 3) / 4;
+    for (size_t qd = wave; qd < n_quads; qd += n_waves) {
+        const size_t li = qd * 4 + g;
+        const bool live = li < a.n_list;
+        size_t ti = 0;
+        Task tk{};
+        if (live) { ti = a.list[li]; tk = a.tasks[ti]; }
+        const int m = tk.m, n = tk.n, dlo = tk.dlo;
+        if (live) {
+            const Piece pc = a.pieces[tk.piece];
+            const uint8_t *qb = a.qcodes + a.qoff[pc.q];
+            const uint8_t *tbs = a.tcodes + a.toff[pc.t] + tk.t0;
+            const int ql = (int)a.qlen[pc.q];
+            for (int x = l; x < m; x += 16) sq[x] = load_q(a, pc, qb, ql, tk.q0 + x);
+            for (int x = l; x < n; x += 16) st[x] = tbs[x];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int rows = (int)wave_max_u32_dpp(live ? (uint32_t)m : 0u);
+        const int go = a.go, ge = a.ge;
+        int Hp = NEG_INF, Fp = NEG_INF, Hend = NEG_INF;
+        for (int i = 0; i <= rows; ++i) {
+            const bool on = live && i <= m;
+            const int j = i + dlo + l;
+            const bool valid = on && j >= 0 && j <= n;
+            const int Hup = row_shl1(Hp, NEG_INF), Fup = row_shl1(Fp, NEG_INF);
+            int mm = NEG_INF, f = NEG_INF;
+            bool flagF = false;
+            if (valid && i > 0) {
+                if (j > 0) {
+                    const int qa = sq[i - 1], t2 = st[j - 1];
+                    mm = Hp + ((qa > 3 || t2 > 3) ? -a.ambi : (qa == t2 ? a.match : -a.mismatch));
+                }
+                if (l < 15) {
+                    const int fo = Hup - go - ge, fe = Fup - ge;
+                    if (fo >= fe) f = fo; else { f = fe; flagF = true; }
+                }
+            }
+            int ht = mm > f ? mm : f;
+            if (i == 0 && j == 0) ht = 0;
+            if (!valid) ht = NEG_INF;
+            const int pm = row_shr1(row_prefix_max_incl_dpp(ht + ge * l, NEG_INF * 2), NEG_INF * 2);
+            int e = NEG_INF;
+            if (valid && j > 0 && l > 0) e = pm - go - ge * l;
+            int h, src;
+            if (i == 0 && j == 0) { h = 0; src = 0; }
+            else if (mm >= e && mm >= f) { h = mm; src = 0; }
+            else if (e >= f) { h = e; src = 1; }
+            else { h = f; src = 2; }
+            if (!valid) { h = NEG_INF; f = NEG_INF; e = NEG_INF; }
+            const int Hl = row_shr1(h, NEG_INF), El = row_shr1(e, NEG_INF);
+            const bool flagE = l > 0 && !(Hl - go - ge >= El - ge);
+            const unsigned long long b0 = __ballot(src & 1), b1 = __ballot(src & 2), b2 = __ballot(flagE), b3 = __ballot(flagF);
+            if (on && l == 0) {
+                const int sh = 16 * g;
+                tb[i] = ((b0 >> sh) & 0xffffull) | ((b1 >> sh) & 0xffffull) << 16 | ((b2 >> sh) & 0xffffull) << 32 |
+                        ((b3 >> sh) & 0xffffull) << 48;
+            }
+            if (on) { Hp = h; Fp = f; if (i == m) Hend = h; }
+        }
+        const int score = __shfl(Hend, g * 16 + (n - m - dlo), 64);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (live && l == 0) {
+            int i = m, j = n, state = 0, nr = 0;
+            while (i > 0 || j > 0) {
+                const unsigned long long w = tb[i] >> (j - i - dlo);
+                if (state == 0) {
+                    const int src = (int)(w & 1) | (int)((w >> 16) & 1) << 1;
+                    if (src == 0) {
+                        su[nr++] = sq[i - 1] == st[j - 1] ? (uint8_t)OP_EQ : (uint8_t)OP_X;
+                        --i; --j;
+                    } else state = src;
+                } else if (state == 1) {
+                    su[nr++] = (uint8_t)OP_D;
+                    if (!((w >> 32) & 1)) state = 0;
+                    --j;
+                } else {
+                    su[nr++] = (uint8_t)OP_I;
+                    if (!((w >> 48) & 1)) state = 0;
+                    --i;
+                }
+            }
+            uint32_t n_runs = 0;
+            for (int x = 0; x < nr; ++x) if (x == 0 || su[nr - 1 - x] != su[nr - x]) ++n_runs;
+            uint32_t off = 0;
+            bool ok = true;
+            if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
+            if (ok && n_runs) {
+                uint32_t w = off, len = 0;
+                uint8_t code = 0;
+                for (int x = 0; x < nr; ++x) {
+                    const uint8_t c = su[nr - 1 - x];
+                    if (x && c != code) { a.runs[w++] = len << 4 | code; len = 0; }
+                    code = c;
+                    ++len;
+                }
+                a.runs[w++] = len << 4 | code;
+            }
+            a.out[ti] = TaskOut{score, m, n, off, ok ? n_runs : 0, 2u | (uint32_t)m << 2};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long long *acc) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     unsigned long long f = 0, d = 0, r = 0;
@@ -428,7 +647,8 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
     DBuf<uint32_t> counters(2);
-    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + (size_t)256 * 16 * WAVES * RUN_CHUNK;   // + one open chunk per wave
+    // runs + one open chunk per allocating lane of every launch (classify: 16 leaders per block ...)
+    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + (size_t)256 * 16 * (32 * RUN_CHUNK_SMALL + WAVES * RUN_CHUNK);
     DBuf<uint32_t> runs;
     for (int attempt = 0;; ++attempt) {
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
@@ -445,11 +665,32 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             if (o.match <= 0 || o.gap_open < 0 || o.gap_ext <= 0) aa.kmax = -1;   // proof needs sane scores
         }
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
-        const unsigned nb = (unsigned)std::min<size_t>((NT + WAVES - 1) / WAVES, 256 * 16);
+        // pass 1: classify every task, finish the diagonal fast path right away
+        DBuf<uint8_t> cls(NT), f1(NT), f2(NT);
         {
-            KTimer kt("align");
+            KTimer kt("align_classify");
+            const unsigned nbc = (unsigned)std::min<size_t>((NT + 15) / 16, 256 * 16);
+            hipLaunchKernelGGL(classify_kernel, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p);
+        }
+        hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p);
+        HIP_CHECK(hipGetLastError());
+        DBuf<uint32_t> list1(NT), list2(NT);
+        const size_t n1 = select_flagged_indices(f1.p, list1.p, NT), n2 = select_flagged_indices(f2.p, list2.p, NT);
+        // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
+        if (n1) {
+            KTimer kt("align_narrow");
+            aa.list = list1.p; aa.n_list = n1;
+            const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
+            hipLaunchKernelGGL(align_narrow_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+        }
+        // pass 2b: the rest (wide blocks, end extensions) in the 64-diagonal band
+        if (n2) {
+            KTimer kt("align_wide");
+            aa.list = list2.p; aa.n_list = n2;
+            const unsigned nb = (unsigned)std::min<size_t>((n2 + WAVES - 1) / WAVES, 256 * 16);
             hipLaunchKernelGGL(align_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
+        if (attempt == 0) { stat_add("align_tasks_narrow", (double)n1); stat_add("align_tasks_wide", (double)n2); }
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> hc = counters.download(2);
         if (!hc[1]) break;

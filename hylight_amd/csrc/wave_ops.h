@@ -44,6 +44,21 @@ __device__ __forceinline__ int wave_prefix_max_incl_dpp(int x, int ident) {
     return x;
 }
 
+// ---- the same inside rows of 16 lanes (four independent 16-lane groups per wave) -------------------
+// lane l <- lane l+1 of its row (l == 15 keeps `last`)
+__device__ __forceinline__ int row_shl1(int x, int last) { return dpp_i32<0x101>(last, x); }
+// lane l <- lane l-1 of its row (l == 0 keeps `first`)
+__device__ __forceinline__ int row_shr1(int x, int first) { return dpp_i32<0x111>(first, x); }
+// inclusive prefix max inside every row of 16
+__device__ __forceinline__ int row_prefix_max_incl_dpp(int x, int ident) {
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    x = mx(x, dpp_i32<0x111>(ident, x));
+    x = mx(x, dpp_i32<0x112>(ident, x));
+    x = mx(x, dpp_i32<0x114>(ident, x));
+    x = mx(x, dpp_i32<0x118>(ident, x));
+    return x;
+}
+
 // lane i <- lane i-1 (lane 0 keeps `lane0`)
 __device__ __forceinline__ int wave_shr1(int x, int lane0) { return dpp_i32<0x138>(lane0, x); }
 // lane i <- lane i+1 (lane 63 keeps `lane63`)

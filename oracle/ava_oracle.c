@@ -30,6 +30,9 @@ typedef struct {
 #define BLOCK_MAX    256     /* max rows / cols of one alignment block                      */
 #define BAND_W       64      /* diagonals per block                                         */
 #define BAND_PAD     12      /* padding around [min(0,delta), max(0,delta)]                 */
+#define NARROW_W     16      /* blocks with |delta| <= NARROW_DELTA use a 16-diagonal band  */
+#define NARROW_PAD   5
+#define NARROW_DELTA 5
 #define EXT_MAX      256     /* max rows of an end extension                                */
 #define MIN_DP_SCORE 80      /* alignment pieces below this DP score are dropped            */
 #define MAX_MID_OCC  1000000
@@ -297,8 +300,8 @@ static inline int sub_score(const ava_opts_t *o, int a, int b) {
  * Cells: H = max(M, E, F) with priority M, E, F on ties; E (gap in query, consumes target, 'D'),
  * F (gap in target, consumes query, 'I'); open preferred over extend on ties. */
 static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, const uint8_t *t, int tstride, int n,
-                   int dlo, int mode, int *bi, int *bj, uint32_t *rev_ops, int *n_rev) {
-    const int W = BAND_W, go = o->gap_open, ge = o->gap_ext;
+                   int dlo, int W, int mode, int *bi, int *bj, uint32_t *rev_ops, int *n_rev) {
+    const int go = o->gap_open, ge = o->gap_ext;
     int rows = m + 1;
     uint8_t *tb = (uint8_t *)malloc((size_t)rows * W);
     int32_t *H = (int32_t *)malloc((size_t)rows * W * 4), *E = (int32_t *)malloc((size_t)rows * W * 4),
@@ -389,8 +392,11 @@ static int block_ok(int q0, int t0, int q1, int t1) {
 static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, int q0, int t0, int q1, int t1,
                         piece_t *p, uint32_t *scratch) {
     int m = q1 - q0, n = t1 - t0, delta = n - m, nr;
-    int dlo = (delta < 0 ? delta : 0) - BAND_PAD;
-    p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, 0, 0, 0, scratch, &nr);
+    /* band rule: near-diagonal blocks get the narrow band, the rest the wide one */
+    int narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
+    int W = narrow ? NARROW_W : BAND_W;
+    int dlo = (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD);
+    p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, W, 0, 0, 0, scratch, &nr);
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
 }
 
@@ -420,7 +426,7 @@ static void emit_piece(FILE *out, const seqset_t *Q, int qi, const seqset_t *T, 
 static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, piece_t *p, uint32_t *scratch) {
     int m = p->qs < EXT_MAX ? p->qs : EXT_MAX, n = p->ts < EXT_MAX + BAND_W ? p->ts : EXT_MAX + BAND_W, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(BAND_W / 2 - 1), 1, &bi, &bj, scratch, &nr);
+    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(BAND_W / 2 - 1), BAND_W, 1, &bi, &bj, scratch, &nr);
     if (sc <= 0 || nr == 0) return;
     /* rev_ops run from the far end towards the fixed point on reversed sequences = forward order */
     cigar_t pre = {0, 0, 0};
@@ -436,7 +442,7 @@ static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const ui
     int m = ql - p->qe < EXT_MAX ? ql - p->qe : EXT_MAX;
     int n = tl - p->te < EXT_MAX + BAND_W ? tl - p->te : EXT_MAX + BAND_W, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(BAND_W / 2 - 1), 1, &bi, &bj, scratch, &nr);
+    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(BAND_W / 2 - 1), BAND_W, 1, &bi, &bj, scratch, &nr);
     if (sc <= 0 || nr == 0) return;
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
     p->qe += bi; p->te += bj; p->score += sc;
