@@ -164,8 +164,10 @@ def main():
     # algorithmic bytes per kernel for the whole step (DESIGN.md "Algorithmic bytes")
     A, P = stats.get("anchors", 0.0), stats.get("pieces", 0.0)
     algo = {
-        "chain": 16 * A + 8 * A,                       # read anchors (16 B) + write f,p (8 B)
-        "align": stats.get("align_dp_bases", 0.0) + 4 * stats.get("cigar_ops", 0.0) + 64 * stats.get("ava_rows", 0.0),
+        "chain": 16 * A + 8 * A + 8 * A + 4 * A,       # read anchors (16 B); write f,p (8 B), best child (8 B), member list (4 B)
+        "align_narrow": stats.get("align_bases_narrow", 0.0) + 4 * stats.get("cigar_ops", 0.0) + 32 * stats.get("align_tasks_narrow", 0.0),
+        "align_wide": stats.get("align_bases_wide", 0.0) + 32 * stats.get("align_tasks_wide", 0.0),
+        "align_classify": stats.get("align_bases_classify", 0.0) + (32 + 24 + 1) * stats.get("align_tasks", 0.0),
         "anchor_sort": 32 * A,                         # one read + one write of 16 B per anchor
         "seed_fill": 16 * stats.get("sketch_minimizers", 0.0) / 2 + 8 * A + 16 * A,
         "seed_count": 16 * stats.get("sketch_minimizers", 0.0) / 2 + 8 * A,

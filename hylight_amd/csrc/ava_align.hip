@@ -77,13 +77,23 @@ __global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const u
     }
 }
 
-__global__ void task_bases_kernel(const Task *tasks, size_t n, unsigned long long *sum) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    unsigned long long v = 0;
-    if (i < n && tasks[i].m > 0 && tasks[i].n > 0) v = (unsigned long long)(tasks[i].m + tasks[i].n);
+// bases (Lq + Lt) per pass: [0] all tasks, [1] square blocks the classify pass compares, [2] narrow DP, [3] wide DP
+__global__ void task_bases_kernel(const Task *tasks, const uint8_t *cls, size_t n, unsigned long long *sum) {
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (tasks[i].m <= 0 || tasks[i].n <= 0) continue;
+        const unsigned long long b = (unsigned long long)(tasks[i].m + tasks[i].n);
+        v[0] += b;
+        if (tasks[i].kind == 0 && tasks[i].m == tasks[i].n) v[1] += b;
+        if (cls[i] == 1) v[2] += b;
+        if (cls[i] == 2) v[3] += b;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&sum[k], v[k]);
+    }
 }
 
 struct TaskOut;
@@ -545,9 +555,12 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
 }
 
 __global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long long *acc) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     unsigned long long f = 0, d = 0, r = 0;
-    if (i < n) { const uint32_t p = out[i].pad; f = p == 1; d = (p & 3) == 2; r = d ? p >> 2 : 0; }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t p = out[i].pad;
+        f += p == 1;
+        if ((p & 3) == 2) { ++d; r += p >> 2; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); d += __shfl_xor(d, o, 64); r += __shfl_xor(r, o, 64); }
     if ((threadIdx.x & 63) == 0) { if (f) atomicAdd(&acc[0], f); if (d) atomicAdd(&acc[1], d); if (r) atomicAdd(&acc[2], r); }
@@ -646,6 +659,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
                        tasks.p);
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
+    DBuf<uint8_t> cls_keep;
     DBuf<uint32_t> counters(2);
     // runs + one open chunk per allocating lane of every launch (classify: 16 leaders per block ...)
     size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + (size_t)256 * 16 * (32 * RUN_CHUNK_SMALL + WAVES * RUN_CHUNK);
@@ -667,6 +681,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         // pass 1: classify every task, finish the diagonal fast path right away
         DBuf<uint8_t> cls(NT), f1(NT), f2(NT);
+        struct KeepCls { DBuf<uint8_t> *dst; DBuf<uint8_t> *src; ~KeepCls() { *dst = std::move(*src); } } keep{&cls_keep, &cls};
         {
             KTimer kt("align_classify");
             const unsigned nbc = (unsigned)std::min<size_t>((NT + 15) / 16, 256 * 16);
@@ -701,17 +716,21 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     {   // how many tasks took the diagonal fast path / the DP (and how many DP rows)
         DBuf<unsigned long long> acc(3);
         acc.zero();
-        hipLaunchKernelGGL(task_kind_kernel, grid1(NT), dim3(WG), 0, stream(), tout.p, NT, acc.p);
+        hipLaunchKernelGGL(task_kind_kernel, dim3(1024), dim3(WG), 0, stream(), tout.p, NT, acc.p);
         std::vector<unsigned long long> h = acc.download(3);
         stat_add("align_tasks_fast", (double)h[0]);
         stat_add("align_tasks_dp", (double)h[1]);
         stat_add("align_dp_rows", (double)h[2]);
     }
     {
-        DBuf<unsigned long long> sum(1);
+        DBuf<unsigned long long> sum(4);
         sum.zero();
-        hipLaunchKernelGGL(task_bases_kernel, grid1(NT), dim3(WG), 0, stream(), tasks.p, NT, sum.p);
-        stat_add("align_dp_bases", (double)download_one(sum.p));   // bases staged by the DP tasks (Lq + Lt)
+        hipLaunchKernelGGL(task_bases_kernel, dim3(1024), dim3(WG), 0, stream(), tasks.p, cls_keep.p, NT, sum.p);
+        std::vector<unsigned long long> hs = sum.download(4);
+        stat_add("align_dp_bases", (double)hs[0]);            // Lq + Lt over all tasks
+        stat_add("align_bases_classify", (double)hs[1]);
+        stat_add("align_bases_narrow", (double)hs[2]);
+        stat_add("align_bases_wide", (double)hs[3]);
     }
     // assemble
     AsmArgs as{};
