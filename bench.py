@@ -48,6 +48,26 @@ def make_workload(name, path):
     return sum(len(r.seq) for r in reads)
 
 
+KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_narrow_kernel", "align_wide": "hlmi::align_kernel",
+                   "align_classify": "hlmi::classify_kernel", "seed_fill": "hlmi::seed_kernel<true>",
+                   "seed_count": "hlmi::seed_kernel<false>", "anchor_sort": "rocprim::radix_sort_onesweep_config"}
+
+
+def pmc_traffic(timer, workload):
+    """HBM bytes per launch of the kernel behind `timer`, from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, see tools/summarize_pmc.py).  Those passes were run
+    on the C2 workload; any other workload reports null."""
+    if workload != "C2":
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    k = d.get(KERNEL_OF_TIMER.get(timer, ""))
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def cpu_baseline(fa, nsplit, budget_s=25.0):
     """Oracle (CPU port) timed on a bounded sample of the same workload: as many --nsplit target chunks
     (each vs ALL query reads, exactly like one reference worker) as fit the budget, one process per
@@ -178,7 +198,8 @@ def main():
     bytes_per_launch = algo.get(dom, 0.0) / launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                traffic=None, avg_launch_ms=avg_ms, launches_per_step=launches,
+                traffic=pmc_traffic(dom, args.workload), algorithmic_bytes_per_launch=bytes_per_launch,
+                avg_launch_ms=avg_ms, launches_per_step=launches,
                 kernel_ms_per_step={k: round(v, 3) for k, v in sorted(kms.items(), key=lambda kv: -kv[1])})
 
     line = dict(metric="long-read all-vs-all overlaps/sec", value=value, unit="overlaps/s", n_gpus=world,
