@@ -211,6 +211,15 @@ def main():
                             overlaps_out=rows, candidate_rows=stats.get("ava_rows"), anchors=A),
                 roofline=roof,
                 stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})
+    # second half of the BASELINE metric: overlap-graph build seconds (PAF on disk -> GFA on disk), not part of `value`
+    try:
+        t_g = time.time()
+        api.miniasm(out_paf, fa, os.path.join(work, "contigs1.gfa"), bub_dist=10000, n_rounds_arg=1, max_ext=1, min_dp=1)
+        line["graph_build_s"] = round(time.time() - t_g, 4)
+        line["graph_unitigs"] = sum(1 for l in open(os.path.join(work, "contigs1.gfa")) if l.startswith("S\t"))
+    except Exception as e:                                    # the stage number stays valid without it
+        line["graph_build_s"] = None
+        line["graph_error"] = str(e)[:200]
     if os.environ.get("HL_BENCH_STATS"):
         sys.stderr.write("STATS " + json.dumps({k: round(v, 4) for k, v in sorted(stats.items())}) + "\n")
     if not args.no_cpu_baseline and world == 1:

@@ -21,7 +21,7 @@ class AvaOpts(C.Structure):
                 ("max_gap", C.c_int), ("bandwidth", C.c_int), ("min_cnt", C.c_int),
                 ("min_mid_occ", C.c_int), ("mid_occ_frac", C.c_double),
                 ("match", C.c_int), ("mismatch", C.c_int), ("gap_open", C.c_int), ("gap_ext", C.c_int),
-                ("ambi", C.c_int)]
+                ("ambi", C.c_int), ("min_dp_score", C.c_int), ("end_bonus", C.c_int), ("pair_once", C.c_int)]
 
 
 # every symbol include/hylight_mi.h declares: name -> (restype, argtypes)
@@ -39,6 +39,7 @@ SYMBOLS = {
                                     C.c_int]),
     "hlmi_paf_window_filter": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
     "hlmi_ava_opts_long": (None, [C.POINTER(AvaOpts)]),
+    "hlmi_ava_opts_short": (None, [C.POINTER(AvaOpts)]),
     "hlmi_ava": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(AvaOpts), C.c_char_p]),
     "hlmi_miniasm": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
     "hlmi_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
@@ -137,6 +138,12 @@ def merge_scored_paf(in_pafs, out_paf):
 def ava_opts_long():
     o = AvaOpts()
     load().hlmi_ava_opts_long(C.byref(o))
+    return o
+
+
+def ava_opts_short():
+    o = AvaOpts()
+    load().hlmi_ava_opts_short(C.byref(o))
     return o
 
 

@@ -20,11 +20,11 @@ constexpr int NARROW_W = 16;        // blocks with |delta| <= NARROW_DELTA use a
 constexpr int NARROW_PAD = 5;
 constexpr int NARROW_DELTA = 5;
 constexpr int EXT_MAX = 256;
-constexpr int MIN_DP_SCORE = 80;
 constexpr int MAX_MID_OCC = 1000000;
 constexpr int NEG_INF = -(1 << 29);
 
-hlmi_ava_opts ava_opts_long();
+hlmi_ava_opts ava_opts_long();    // filter_overlap_slr2.py:51
+hlmi_ava_opts ava_opts_short();   // filter_overlap_slr2.py:55
 
 struct Mz {                 // one minimizer, 16 B (the unit all-gathered between GPUs)
     uint64_t x;             // hash << 8 | span

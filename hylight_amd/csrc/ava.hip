@@ -48,6 +48,20 @@ hlmi_ava_opts ava_opts_long() {
     o.min_chain_score = 100; o.max_gap = 10000; o.bandwidth = 2000; o.min_cnt = 3;
     o.min_mid_occ = 10; o.mid_occ_frac = 2e-4;
     o.match = 2; o.mismatch = 4; o.gap_open = 4; o.gap_ext = 2; o.ambi = 1;
+    o.min_dp_score = 80; o.end_bonus = 0; o.pair_once = 1;
+    return o;
+}
+
+hlmi_ava_opts ava_opts_short() {
+    // script/filter_overlap_slr2.py:55: --sr -DP --no-long-join -k21 -w11 -s60 -m30 -n2 -A4 -B2 --end-bonus=100
+    // (+ what the --sr preset leaves in place: no HPC, -g200, -r50, -O12 -E2, -f1000; no -X, so both directions
+    // of a pair are reported)
+    hlmi_ava_opts o{};
+    o.k = 21; o.w = 11; o.hpc = 0;
+    o.min_chain_score = 30; o.max_gap = 200; o.bandwidth = 50; o.min_cnt = 2;
+    o.min_mid_occ = 1000; o.mid_occ_frac = 0.0;
+    o.match = 4; o.mismatch = 2; o.gap_open = 12; o.gap_ext = 2; o.ambi = 1;
+    o.min_dp_score = 60; o.end_bonus = 100; o.pair_once = 0;
     return o;
 }
 

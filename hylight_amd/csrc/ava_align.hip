@@ -58,7 +58,9 @@ __global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const u
     const int ql = (int)qlen[p.q], tl = (int)tlen[p.t];
     {   // left extension
         const int qs = (int)fp[0].q, ts = (int)fp[0].t;
-        Task t{(uint32_t)i, 1u, qs, ts, qs < EXT_MAX ? qs : EXT_MAX, ts < SEQ_T_MAX ? ts : SEQ_T_MAX, -(BAND_W / 2 - 1), 0};
+        // extensions: bits 1.. of `narrow` = (row that reaches the query end) + 1, 0 when it is out of reach
+        Task t{(uint32_t)i, 1u, qs, ts, qs < EXT_MAX ? qs : EXT_MAX, ts < SEQ_T_MAX ? ts : SEQ_T_MAX, -(BAND_W / 2 - 1),
+               qs <= EXT_MAX ? (uint32_t)(qs + 1) << 1 : 0u};
         out[0] = t;
     }
     for (uint32_t b = 0; b + 1 < p.n_fp; ++b) {
@@ -72,7 +74,7 @@ __global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const u
     {   // right extension
         const int qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
         const int m = ql - qe < EXT_MAX ? ql - qe : EXT_MAX, n2 = tl - te < SEQ_T_MAX ? tl - te : SEQ_T_MAX;
-        Task t{(uint32_t)i, 2u, qe, te, m, n2, -(BAND_W / 2 - 1), 0};
+        Task t{(uint32_t)i, 2u, qe, te, m, n2, -(BAND_W / 2 - 1), ql - qe <= EXT_MAX ? (uint32_t)(ql - qe + 1) << 1 : 0u};
         out[p.n_fp] = t;
     }
 }
@@ -109,6 +111,7 @@ struct AlignArgs {
     const uint64_t *qoff, *toff;
     const uint32_t *qlen;
     int match, mismatch, go, ge, ambi;
+    int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     TaskOut *out;
     uint32_t *runs;
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         }
         // ---- DP ------------------------------------------------------------------------------------------------
         const int dlo = tk.dlo, go = a.go, ge = a.ge;
+        const int end_row = tk.kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
         int Hp = NEG_INF, Fp = NEG_INF;
         unsigned long long best = 0;
         for (int i = 0; i <= m; ++i) {
@@ -267,7 +271,9 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             const unsigned long long b0 = __ballot(src & 1), b1 = __ballot(src & 2), b2 = __ballot(flagE), b3 = __ballot(flagF);
             if (lane == 0) { tb[i][0] = b0; tb[i][1] = b1; tb[i][2] = b2; tb[i][3] = b3; }
             if (tk.kind != 0 && valid && h > NEG_INF / 2) {
-                const unsigned long long key = (unsigned long long)(uint32_t)(h + (1 << 20)) << 32 |
+                // cells in the row that reaches the query end are ranked with the end bonus (ksw2 --end-bonus)
+                const int hb = h + (i == end_row ? a.end_bonus : 0);
+                const unsigned long long key = (unsigned long long)(uint32_t)(hb + (1 << 20)) << 32 |
                                                (unsigned long long)(0xffffu - (uint32_t)(i + j)) << 16 |
                                                (unsigned long long)(0xffffu - (uint32_t)i);
                 best = key > best ? key : best;
@@ -285,9 +291,9 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
                 unsigned long long u = __shfl_xor(best, o, 64);
                 best = u > best ? u : best;
             }
-            score = (int)(uint32_t)(best >> 32) - (1 << 20);
             ei = (int)(0xffffu - (uint32_t)(best & 0xffff));
             ej = (int)(0xffffu - (uint32_t)((best >> 16) & 0xffff)) - ei;
+            score = (int)(uint32_t)(best >> 32) - (1 << 20) - (ei == end_row ? a.end_bonus : 0);   // the bonus only ranks
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
                 }
                 a.runs[w++] = len << 4 | code;
             }
-            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0; res.pad = 2u | (uint32_t)m << 2;
+            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0; res.pad = 2u | ((uint32_t)m & 0xfffffu) << 2 | (tk.kind != 0 && ei == end_row ? 0x80000000u : 0u);
             a.out[ti] = res;
         }
         __builtin_amdgcn_wave_barrier();
@@ -559,7 +565,7 @@ __global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long lon
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t p = out[i].pad;
         f += p == 1;
-        if ((p & 3) == 2) { ++d; r += p >> 2; }
+        if ((p & 3) == 2) { ++d; r += (p >> 2) & 0xfffffu; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); d += __shfl_xor(d, o, 64); r += __shfl_xor(r, o, 64); }
@@ -575,6 +581,7 @@ struct AsmArgs {
     const uint32_t *runs;
     size_t n_pieces;
     const uint32_t *qlen, *tlen, *rank_q, *rank_t, *chunk_of_t;
+    int min_dp_score, end_bonus;
 };
 
 template <bool WRITE>
@@ -596,7 +603,8 @@ __global__ void assemble_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, cons
         const TaskOut r = to[t];
         const bool is_ext = t == 0 || t == n_tasks - 1;
         if (is_ext) {
-            if (r.score <= 0 || r.n_runs == 0) continue;
+            // an extension counts when it gains something; the end bonus counts for that decision, not for the score
+            if (r.score + ((r.pad & 0x80000000u) ? a.end_bonus : 0) <= 0 || r.n_runs == 0) continue;
             if (t == 0) { qs -= r.bi; ts -= r.bj; } else { qe += r.bi; te += r.bj; }
         }
         score += r.score;
@@ -614,7 +622,7 @@ __global__ void assemble_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, cons
         }
     }
     if (!WRITE) {
-        const bool ok = cnt > 0 && score >= MIN_DP_SCORE;
+        const bool ok = cnt > 0 && score >= a.min_dp_score;
         valid[i] = ok ? 1 : 0;
         n_ops[i] = ok ? cnt : 0;
         return;
@@ -672,6 +680,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.tasks = tasks.p; aa.n_tasks = NT; aa.pieces = ch.pieces.p;
         aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p; aa.qoff = in.Q->off.p; aa.toff = in.T->off.p;
         aa.qlen = d_qlen;
+        aa.end_bonus = o.end_bonus;
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
         {   // largest k with k*(match+mismatch) < match + 2*(open+ext), capped at 3 (7 runs)
             const int den = o.match + o.mismatch, num = o.match + 2 * (o.gap_open + o.gap_ext);
@@ -735,6 +744,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     // assemble
     AsmArgs as{};
     as.pieces = ch.pieces.p; as.fps = ch.fps.p; as.task_off = toff.p; as.tout = tout.p; as.runs = runs.p; as.n_pieces = P;
+    as.min_dp_score = o.min_dp_score; as.end_bonus = o.end_bonus;
     as.qlen = d_qlen; as.tlen = d_tlen; as.rank_q = in.d_rank_q; as.rank_t = in.d_rank_t; as.chunk_of_t = in.d_chunk_of_t;
     DBuf<uint32_t> nops(P);
     DBuf<uint8_t> valid(P);

@@ -85,6 +85,7 @@ struct SeedArgs {
     const uint32_t *iocc, *mid_occ, *chunk_of_t, *rank_q, *rank_t, *qlen;
     size_t n_idx;
     uint32_t q_lo;
+    int pair_once;              // 1: only strcmp(qname,tname) < 0; 0: every pair except self
 };
 
 // Wave-cooperative: a wave owns 64 consecutive query minimizers.  Every lane binary-searches the
@@ -127,8 +128,9 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
             if (e < hi_b) {
                 y = a.iy[e];
                 const uint32_t t = (uint32_t)(y >> 32);
+                const uint32_t rt = a.rank_t[t];
                 ok = !(a.iocc[e] > a.mid_occ[a.chunk_of_t[t]])      // not too frequent inside that chunk
-                     && rq_b < a.rank_t[t];                          // pair once (and never self)
+                     && (a.pair_once ? rq_b < rt : rq_b != rt);      // pair once / never self
             }
             const unsigned long long mask = __ballot(ok);
             if (FILL && ok) {
@@ -405,6 +407,7 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_
                  DevIndex &ix) {
     const size_t n = tsk.n;
     ix.n = n;
+    ix.pair_once = o.pair_once;
     ix.key.alloc(n ? n : 1);
     ix.y.alloc(n ? n : 1);
     ix.occ.alloc(n ? n : 1);
@@ -423,7 +426,7 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_
                            d_chunk_of_t, hist.p);
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> h = hist.download();
-        for (uint32_t c = 0; c < n_chunks; ++c) {
+        for (uint32_t c = 0; c < n_chunks && o.mid_occ_frac > 0; ++c) {   // frac <= 0: fixed cut-off (-f INT)
             uint64_t nd = 0;
             for (int v = 0; v < HB; ++v) nd += h[(size_t)c * HB + v];
             if (!nd) continue;
@@ -445,6 +448,7 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_
 
 static SeedArgs make_seed_args(const AvaInput &in, const DevIndex &ix, const uint32_t *d_qlen, size_t q_lo, size_t q_hi) {
     SeedArgs sa{};
+    sa.pair_once = ix.pair_once;
     sa.qmz = in.d_qmz + in.qmz_off[q_lo];
     sa.n_mz = in.qmz_off[q_hi] - in.qmz_off[q_lo];
     sa.ikey = ix.key.p; sa.iy = ix.y.p; sa.iocc = ix.occ.p; sa.mid_occ = ix.mid_occ.p;

@@ -11,6 +11,7 @@ struct DevIndex {
     DBuf<uint64_t> y;        // target << 32 | pos << 1 | strand
     DBuf<uint32_t> occ;      // occurrences of this key inside the entry's chunk
     DBuf<uint32_t> mid_occ;  // per chunk: occurrence cut-off
+    int pair_once = 1;       // seeding rule carried with the index (hlmi_ava_opts::pair_once)
 };
 void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_chunks, const hlmi_ava_opts &o,
                  DevIndex &ix);

@@ -176,6 +176,10 @@ void hlmi_ava_opts_long(hlmi_ava_opts *o) {
     if (!o) return;
     *o = ava_opts_long();
 }
+void hlmi_ava_opts_short(hlmi_ava_opts *o) {
+    if (!o) return;
+    *o = ava_opts_short();
+}
 
 int hlmi_ava(const char *target_fa, const char *query_fa, const hlmi_ava_opts *opts, const char *out_paf) {
     return guarded([&] {

@@ -33,11 +33,8 @@ static double now_s() {
 
 Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode) : impl_(new Impl) {
     Impl &m = *impl_;
-    if (!long_mode)
-        fail(HLMI_ESTATE, "short-read mode (minimap2 --sr, filter_overlap_slr2.py:55) is not built yet: long_mode=0 "
-                          "is SURVEY.md section 8f rank 1");
     m.long_mode = long_mode;
-    m.opts = ava_opts_long();
+    m.opts = long_mode ? ava_opts_long() : ava_opts_short();   // filter_overlap_slr2.py:51 / :55
     read_seqs(reads_fa, m.Q);
     if (std::string(reads_fa) == ref_fa) m.T = m.Q; else read_seqs(ref_fa, m.T);
     name_ranks(m.T.names, m.Q.names, m.rank_t, m.rank_q, m.name_of_rank);

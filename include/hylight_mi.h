@@ -78,10 +78,14 @@ typedef struct {
     int bandwidth;         /* chaining band, 2000 */
     int min_cnt;           /* 3 minimizers per chain (-n default) */
     int min_mid_occ;       /* 10 */
-    double mid_occ_frac;   /* 2e-4 */
+    double mid_occ_frac;   /* 2e-4; <= 0: the cut-off is min_mid_occ itself (-f INT) */
     int match, mismatch, gap_open, gap_ext, ambi;   /* 2 4 4 2 1 */
+    int min_dp_score;      /* alignment pieces below this DP score are dropped: 80 (long), 60 (-s 60, short) */
+    int end_bonus;         /* bonus for an end extension that reaches the query end: 0 (long), 100 (short) */
+    int pair_once;         /* 1: report a pair only with strcmp(qname,tname) < 0 (ava-pb -X); 0: every non-self pair */
 } hlmi_ava_opts;
-void hlmi_ava_opts_long(hlmi_ava_opts *o);   /* the constants of slr2:51 */
+void hlmi_ava_opts_long(hlmi_ava_opts *o);    /* the constants of slr2:51 (ava-pb -Hk19 -m100 -g10000) */
+void hlmi_ava_opts_short(hlmi_ava_opts *o);   /* the constants of slr2:55 (--sr -k21 -w11 -s60 -m30 -n2 -A4 -B2 --end-bonus=100) */
 /* target_fa = one chunk, query_fa = all reads; writes minimap2-style PAF rows (12 columns +
  * NM, tp, cg:Z: tags, cg last) in query-file order. */
 int hlmi_ava(const char *target_fa, const char *query_fa, const hlmi_ava_opts *opts,

@@ -22,6 +22,7 @@ typedef struct {
     int k, w, hpc, min_chain_score, max_gap, bandwidth, min_cnt, min_mid_occ;
     double mid_occ_frac;
     int match, mismatch, gap_open, gap_ext, ambi;
+    int min_dp_score, end_bonus, pair_once;
 } ava_opts_t;   /* same layout as hlmi_ava_opts (include/hylight_mi.h) */
 
 /* ---- fixed constants of the spec -------------------------------------------- */
@@ -34,7 +35,6 @@ typedef struct {
 #define NARROW_PAD   5
 #define NARROW_DELTA 5
 #define EXT_MAX      256     /* max rows of an end extension                                */
-#define MIN_DP_SCORE 80      /* alignment pieces below this DP score are dropped            */
 #define MAX_MID_OCC  1000000
 #define NEG_INF      (-(1 << 29))
 
@@ -245,7 +245,7 @@ static void index_build(const seqset_t *T, const ava_opts_t *o, index_t *ix) {
         i = j;
     }
     ix->mid_occ = o->min_mid_occ;
-    if (nd) {
+    if (nd && o->mid_occ_frac > 0) {
         qsort(cnt, nd, 4, cmp_u32);
         int64_t q = (int64_t)(uint32_t)((1.0 - o->mid_occ_frac) * (double)nd);
         if (q >= nd) q = nd - 1;
@@ -299,14 +299,15 @@ static inline int sub_score(const ava_opts_t *o, int a, int b) {
  * mode 1: extension, best cell (max H; ties: smaller i+j, then smaller i); *bi,*bj returned.
  * Cells: H = max(M, E, F) with priority M, E, F on ties; E (gap in query, consumes target, 'D'),
  * F (gap in target, consumes query, 'I'); open preferred over extend on ties. */
+static __thread int g_last_rank;
 static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, const uint8_t *t, int tstride, int n,
-                   int dlo, int W, int mode, int *bi, int *bj, uint32_t *rev_ops, int *n_rev) {
+                   int dlo, int W, int mode, int end_row, int *bi, int *bj, uint32_t *rev_ops, int *n_rev) {
     const int go = o->gap_open, ge = o->gap_ext;
     int rows = m + 1;
     uint8_t *tb = (uint8_t *)malloc((size_t)rows * W);
     int32_t *H = (int32_t *)malloc((size_t)rows * W * 4), *E = (int32_t *)malloc((size_t)rows * W * 4),
             *F = (int32_t *)malloc((size_t)rows * W * 4);
-    int best = NEG_INF, best_i = 0, best_j = 0;
+    int best = NEG_INF, best_i = 0, best_j = 0, best_h = NEG_INF;   /* best: score + end bonus (ranking), best_h: score */
     for (int i = 0; i <= m; ++i)
         for (int dd = 0; dd < W; ++dd) {
             int j = i + dlo + dd, idx = i * W + dd;
@@ -336,8 +337,9 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
                     if (h < NEG_INF) h = NEG_INF;
                 }
                 if (mode == 1 && h > NEG_INF) {
-                    if (h > best || (h == best && (i + j < best_i + best_j || (i + j == best_i + best_j && i < best_i)))) {
-                        best = h; best_i = i; best_j = j;
+                    int hb = h + (i == end_row ? o->end_bonus : 0);   /* reaching the query end earns the bonus */
+                    if (hb > best || (hb == best && (i + j < best_i + best_j || (i + j == best_i + best_j && i < best_i)))) {
+                        best = hb; best_i = i; best_j = j; best_h = h;
                     }
                 }
             }
@@ -345,7 +347,7 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
         }
     int ei, ej, score;
     if (mode == 0) { ei = m; ej = n; score = H[m * W + (n - m - dlo)]; }
-    else { ei = best_i; ej = best_j; score = best; }
+    else { ei = best_i; ej = best_j; score = best_h; }
     /* traceback */
     int i = ei, j = ej, state = 0, nr = 0;
     while (i > 0 || j > 0) {
@@ -369,6 +371,7 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
         }
     }
     *n_rev = nr;
+    g_last_rank = mode == 1 ? best : score;   /* extension: score + end bonus of the chosen cell */
     if (bi) *bi = ei;
     if (bj) *bj = ej;
     free(tb); free(H); free(E); free(F);
@@ -396,13 +399,13 @@ static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t,
     int narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
     int W = narrow ? NARROW_W : BAND_W;
     int dlo = (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD);
-    p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, W, 0, 0, 0, scratch, &nr);
+    p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, W, 0, -1, 0, 0, scratch, &nr);
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
 }
 
 /* one chain (anchors ascending) -> alignment pieces -> PAF rows */
-static void emit_piece(FILE *out, const seqset_t *Q, int qi, const seqset_t *T, int ti, int strand, piece_t *p) {
-    if (p->cg.n && p->score >= MIN_DP_SCORE) {
+static void emit_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const seqset_t *T, int ti, int strand, piece_t *p) {
+    if (p->cg.n && p->score >= o->min_dp_score) {
         long nm = 0, bl = 0;
         for (int x = 0; x < p->cg.n; ++x) {
             long l = p->cg.op[x] >> 4;
@@ -426,8 +429,9 @@ static void emit_piece(FILE *out, const seqset_t *Q, int qi, const seqset_t *T, 
 static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, piece_t *p, uint32_t *scratch) {
     int m = p->qs < EXT_MAX ? p->qs : EXT_MAX, n = p->ts < EXT_MAX + BAND_W ? p->ts : EXT_MAX + BAND_W, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(BAND_W / 2 - 1), BAND_W, 1, &bi, &bj, scratch, &nr);
-    if (sc <= 0 || nr == 0) return;
+    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(BAND_W / 2 - 1), BAND_W, 1, p->qs <= EXT_MAX ? p->qs : -1,
+                     &bi, &bj, scratch, &nr);
+    if (g_last_rank <= 0 || nr == 0) return;   /* nothing gained (the end bonus counts here, not in the score) */
     /* rev_ops run from the far end towards the fixed point on reversed sequences = forward order */
     cigar_t pre = {0, 0, 0};
     for (int x = 0; x < nr; ++x) cig_push(&pre, (int)scratch[x], 1);
@@ -442,8 +446,9 @@ static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const ui
     int m = ql - p->qe < EXT_MAX ? ql - p->qe : EXT_MAX;
     int n = tl - p->te < EXT_MAX + BAND_W ? tl - p->te : EXT_MAX + BAND_W, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(BAND_W / 2 - 1), BAND_W, 1, &bi, &bj, scratch, &nr);
-    if (sc <= 0 || nr == 0) return;
+    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(BAND_W / 2 - 1), BAND_W, 1, ql - p->qe <= EXT_MAX ? ql - p->qe : -1,
+                     &bi, &bj, scratch, &nr);
+    if (g_last_rank <= 0 || nr == 0) return;   /* nothing gained (the end bonus counts here, not in the score) */
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
     p->qe += bi; p->te += bj; p->score += sc;
 }
@@ -480,7 +485,7 @@ static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
             p.qe = cq; p.te = ct;
             extend_left(o, qa, t, &p, scratch);
             extend_right(o, qa, ql, t, tl, &p, scratch);
-            emit_piece(out, Q, qi, T, ti, strand, &p);
+            emit_piece(out, o, Q, qi, T, ti, strand, &p);
             open = 0;
             --x;        /* revisit this anchor as the start of a new piece */
         }
@@ -489,7 +494,7 @@ static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
         p.qe = cq; p.te = ct;
         extend_left(o, qa, t, &p, scratch);
         extend_right(o, qa, ql, t, tl, &p, scratch);
-        emit_piece(out, Q, qi, T, ti, strand, &p);
+        emit_piece(out, o, Q, qi, T, ti, strand, &p);
     }
     free(p.cg.op);
     free(scratch);
@@ -590,7 +595,7 @@ int oracle_ava(const char *target_fa, const char *query_fa, const ava_opts_t *o,
             uint32_t qspan = (uint32_t)(qm[x].x & 0xff), qpos = (uint32_t)qm[x].y >> 1, qz = (uint32_t)qm[x].y & 1;
             for (int64_t e = s; e < s + cnt; ++e) {
                 uint32_t t = (uint32_t)(ix.e[e].y >> 32), tpos = (uint32_t)ix.e[e].y >> 1, tz = (uint32_t)ix.e[e].y & 1;
-                if (Q->rank[qi] >= T->rank[t]) continue;   /* pair once: strcmp(q,t) < 0 only; self skipped */
+                if (o->pair_once ? Q->rank[qi] >= T->rank[t] : Q->rank[qi] == T->rank[t]) continue;   /* pair once: strcmp(q,t) < 0 only; self always skipped */
                 if (na == an_cap) { an_cap = an_cap ? an_cap * 2 : 4096; an = (anchor_t *)realloc(an, an_cap * sizeof(anchor_t)); }
                 anchor_t *a = &an[na++];
                 a->t = t; a->strand = qz ^ tz; a->tpos = tpos; a->qspan = qspan; a->gen = (uint32_t)(na - 1);
