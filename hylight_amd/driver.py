@@ -206,8 +206,19 @@ def main(argv=None):
                 num += 1
     if args.stop_after == "polish":
         return 0
-    raise SystemExit("long-read path finished (tmp/long_con_polished.fa).  The short-read branch (HyLight.py:198-280) "
-                     "needs the --sr overlapper mode, which is not built yet (SURVEY.md section 8f rank 1).")
+    if not args.short_reads:
+        raise SystemExit("long-read path finished (tmp/long_con_polished.fa); no --short_reads given")
+    short_reads = os.path.abspath(args.short_reads) if args.corrected else os.path.join(tmp, "cor_short_reads.fq")
+    # the two short-read calls of the same path (HyLight.py:200,207: len_over 70, mc 3, short mode)
+    ov_short = stage(short_reads, long_con2, nsplit, tmp + "shortr1.paf", 70, 3, iden, long=False)
+    long_con3 = os.path.join(outdir, "long_con_polished.fa")
+    _run(f"{racon} --no-trimming -u -t 30 {short_reads} {ov_short} {long_con2} > {long_con3}", cwd=outdir)
+    remain_short = pick_up(ov_short, tmp, short_reads)
+    if os.path.getsize(remain_short):
+        stage(short_reads, remain_short, nsplit, tmp + "shortr2.paf", 70, 3, iden, long=False)
+    raise SystemExit("overlap path finished (tmp/shortr1.paf, tmp/shortr2.paf, long_con_polished.fa).  Short-read "
+                     "clustering, POLYTE and stage b (HyLight.py:211-280) are outside this implementation's scope "
+                     "(SURVEY.md section 2).")
 
 
 if __name__ == "__main__":
