@@ -34,6 +34,13 @@ WORKLOADS = {
     # small variant for quick checks (not a bench line)
     "C2mini": dict(seed=20241008, n_strains=5, genome_len=40_000, n_reads=1_000, mean_len=8_000, min_len=1_000,
                    max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001, nsplit=100),
+    # scale / robustness probes (not bench lines): 4x the reads of C2 at the same depth; a high-divergence mix in
+    # the spirit of BASELINE.json configs[4] (strain indels, 1 % / 0.5 % / 0.5 % read errors)
+    "C3s": dict(seed=20241008, n_strains=5, genome_len=1_600_000, n_reads=40_000, mean_len=8_000, min_len=1_000,
+                max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001, nsplit=200),
+    "C5s": dict(seed=20241008, n_strains=8, genome_len=200_000, n_reads=5_000, mean_len=10_000, min_len=1_000,
+                max_len=40_000, snp_rate=0.02, strain_indel_rate=0.001, err_sub=0.01, err_ins=0.005, err_del=0.005,
+                nsplit=100, stage=dict(len_over=1500, mc=2, iden=0.90)),
 }
 STAGE = dict(len_over=6000, mc=2, iden=0.95)     # script/HyLight.py:130
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
@@ -43,6 +50,7 @@ def make_workload(name, path):
     from hylight_amd import simulate as S
     w = dict(WORKLOADS[name])
     w.pop("nsplit")
+    w.pop("stage", None)
     reads, _ = S.simulate_reads(**w)
     S.write_fasta(reads, path)
     return sum(len(r.seq) for r in reads)
@@ -146,7 +154,7 @@ def main():
     out_paf = os.path.join(work, f"out.rank{rank}.paf")
 
     def step():
-        return runner.run(out_paf, **STAGE)
+        return runner.run(out_paf, **wl.get("stage", STAGE))
 
     def fence():
         if world > 1:

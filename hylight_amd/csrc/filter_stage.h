@@ -17,6 +17,7 @@ struct FilterCfg {
     double thre = 0.0025;
     int min_o = 4;
     bool long_mode = true;
+    uint32_t chunk_id_bound = 0;   // 1 + largest PafRec::chunk value that can occur (0: number of chunks of the call)
 };
 
 // Rows kept by pass 2 BEFORE the score2 >= iden test (that test needs the "%.4f" text and is
@@ -35,6 +36,9 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
 // a4/a17 alone: keep[i] = 1 for rows the window filter prints.  variant 3 or 4.
 void window_filter_device(const PafRec *d_recs, size_t n, const std::vector<uint64_t> &chunk_row_start,
                           int variant, int min_len, double min_iden, int min_o, uint8_t *d_keep);
+
+// CIGAR ops per chunk id (sizes the chunk groups a caller filters at a time)
+std::vector<uint64_t> ops_per_chunk(const PafRec *d_recs, size_t n, uint32_t n_chunk_ids);
 
 // host copies of the rows recs[idx[i]]
 std::vector<PafRec> download_rows(const PafRec *d_recs, const std::vector<uint32_t> &idx);

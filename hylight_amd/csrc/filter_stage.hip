@@ -348,6 +348,22 @@ std::vector<uint64_t> make_windows(const std::vector<uint64_t> &chunk_row_start,
 
 }  // namespace
 
+namespace {
+__global__ void chunk_ops_kernel(const PafRec *recs, size_t n, unsigned long long *ops_of_chunk) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n && recs[i].cig_n) atomicAdd(&ops_of_chunk[recs[i].chunk], (unsigned long long)recs[i].cig_n);
+}
+}  // namespace
+
+std::vector<uint64_t> ops_per_chunk(const PafRec *d_recs, size_t n, uint32_t n_chunk_ids) {
+    DBuf<unsigned long long> acc(n_chunk_ids ? n_chunk_ids : 1);
+    acc.zero();
+    if (n) hipLaunchKernelGGL(chunk_ops_kernel, grid1(n), dim3(WG), 0, stream(), d_recs, n, acc.p);
+    HIP_CHECK(hipGetLastError());
+    std::vector<unsigned long long> h = acc.download(n_chunk_ids);
+    return std::vector<uint64_t>(h.begin(), h.end());
+}
+
 std::vector<PafRec> download_rows(const PafRec *d_recs, const std::vector<uint32_t> &idx) {
     std::vector<PafRec> out;
     if (idx.empty()) return out;
@@ -384,7 +400,9 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
                          const std::vector<uint64_t> &chunk_row_start, const FilterCfg &cfg, FilterOut &out) {
     out = FilterOut();
     if (!n) return;
-    const uint32_t n_chunks = (uint32_t)(chunk_row_start.size() - 1);
+    // chunk ids inside the rows may be global (a caller filtering a sub-range of chunks): size the chunk sort by the
+    // largest id, not by the number of chunks in this call
+    const uint32_t n_chunks = std::max<uint32_t>((uint32_t)(chunk_row_start.size() - 1), cfg.chunk_id_bound);
     const int lm = cfg.long_mode ? 1 : 0;
 
     // ---- a4 ------------------------------------------------------------------------------

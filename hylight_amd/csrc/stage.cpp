@@ -135,14 +135,33 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         const double t1 = now_s();
         FilterCfg cfg;
         cfg.len_over = len_over; cfg.mc = mc; cfg.long_mode = m.long_mode;
+        cfg.chunk_id_bound = n_my;
+        // The chunks are independent (the reference runs one worker per chunk); filter them in groups whose SNP
+        // events (<= 2 per X op) stay below the 32-bit offsets the event arrays use.
+        const std::vector<uint64_t> chunk_ops = ops_per_chunk(rows.recs.p, rows.n_rows, n_my);
         FilterOut fo;
-        filter_stage_device(rows.recs.p, rows.n_rows, rows.ops.p, rows.chunk_row_start, cfg, fo);
-        const double t2 = now_s();
-        std::vector<PafRec> kept = download_rows(rows.recs.p, fo.rows);
         std::string s;
-        for (size_t i = 0; i < kept.size(); ++i)
-            if (format_scored_row(kept[i], m.name_of_rank[kept[i].qid], m.name_of_rank[kept[i].tid], fo.x_digit_sum[i], iden, s))
-                lines.push_back(s);
+        size_t n_v4 = 0, n_ev = 0, n_pairs = 0;
+        double t_fmt = 0;
+        for (uint32_t c0 = 0; c0 < n_my;) {
+            uint32_t c1 = c0;
+            uint64_t ops = 0;
+            while (c1 < n_my && (c1 == c0 || ops + chunk_ops[c1] <= (1ull << 30))) ops += chunk_ops[c1++];
+            const uint64_t r0 = rows.chunk_row_start[c0], r1 = rows.chunk_row_start[c1];
+            std::vector<uint64_t> crs(rows.chunk_row_start.begin() + c0, rows.chunk_row_start.begin() + c1 + 1);
+            for (auto &v : crs) v -= r0;
+            filter_stage_device(rows.recs.p + r0, (size_t)(r1 - r0), rows.ops.p, crs, cfg, fo);
+            n_v4 += fo.n_after_v4; n_ev += fo.n_events; n_pairs += fo.n_pairs;
+            const double tf = now_s();
+            std::vector<PafRec> kept = download_rows(rows.recs.p + r0, fo.rows);
+            for (size_t i = 0; i < kept.size(); ++i)
+                if (format_scored_row(kept[i], m.name_of_rank[kept[i].qid], m.name_of_rank[kept[i].tid], fo.x_digit_sum[i], iden, s))
+                    lines.push_back(s);
+            t_fmt += now_s() - tf;
+            c0 = c1;
+        }
+        const double t2 = now_s() - t_fmt;
+        fo.n_after_v4 = n_v4; fo.n_events = n_ev; fo.n_pairs = n_pairs;
         stat_set("rows_after_v4", (double)fo.n_after_v4);
         stat_set("snp_events", (double)fo.n_events);
         stat_set("pairs", (double)fo.n_pairs);
