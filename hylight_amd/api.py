@@ -38,6 +38,8 @@ SYMBOLS = {
     "hlmi_filter_chunk": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                     C.c_int]),
     "hlmi_paf_window_filter": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+    "hlmi_filter_ovlp_inline": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_double]),
+    "hlmi_minimap22sfo": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_double]),
     "hlmi_ava_opts_long": (None, [C.POINTER(AvaOpts)]),
     "hlmi_ava_opts_short": (None, [C.POINTER(AvaOpts)]),
     "hlmi_ava": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(AvaOpts), C.c_char_p]),
@@ -121,6 +123,14 @@ def filter_chunk(paf_in, out_paf, len_over, mc, iden, thre=0.0025, min_o=4, long
 
 def paf_window_filter(variant, in_paf, out_path, min_len=60, min_iden=-1.0, min_o=0, sfo=False):
     _check(load().hlmi_paf_window_filter(variant, min_len, min_iden, min_o, int(sfo), _b(in_paf), _b(out_path)))
+
+
+def filter_ovlp_inline(in_paf, out_paf, min_ovlp_len, min_identity, o=1000, r=0.8):
+    _check(load().hlmi_filter_ovlp_inline(_b(in_paf), _b(out_paf), min_ovlp_len, min_identity, o, r))
+
+
+def minimap22sfo(in_paf, out_sfo, min_overlap_len=0, min_pident=0.0):
+    _check(load().hlmi_minimap22sfo(_b(in_paf), _b(out_sfo), min_overlap_len, min_pident))
 
 
 def split_reads2(reads_fa, ref_fa, nsplit, out_dir, out_paf, threads=30, len_over=3000, mc=2, iden=0.95,

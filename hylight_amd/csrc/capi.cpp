@@ -134,6 +134,59 @@ int hlmi_paf_window_filter(int variant, int min_len, double min_iden, int min_o,
     });
 }
 
+int hlmi_filter_ovlp_inline(const char *in_paf, const char *out_paf, int min_ovlp_len, double min_identity, int o, double r) {
+    return guarded([&] {
+        if (!in_paf || !out_paf) fail(HLMI_EINVAL, "hlmi_filter_ovlp_inline: NULL path");
+        require_device();
+        PafText pt;
+        read_paf(in_paf, pt, false);
+        const size_t n = pt.recs.size();
+        std::vector<std::string> lines;
+        if (n) {
+            DBuf<PafRec> d_recs;
+            d_recs.upload(pt.recs);
+            DBuf<uint8_t> keep(n);
+            DBuf<uint32_t> first_of(n);
+            ovlp_inline_device(d_recs.p, n, min_ovlp_len, min_identity, o, r, keep.p, first_of.p);
+            std::vector<uint8_t> hk = keep.download(n);
+            std::vector<uint32_t> hf = first_of.download(n);
+            std::vector<std::pair<uint32_t, uint32_t>> order;      // (print position, row)
+            for (size_t i = 0; i < n; ++i) if (hk[i]) order.emplace_back(hf[i], (uint32_t)i);
+            std::sort(order.begin(), order.end());
+            for (auto &pr : order) lines.emplace_back(pt.line(pr.second));
+        }
+        write_lines(out_paf, lines);
+    });
+}
+
+int hlmi_minimap22sfo(const char *in_paf, const char *out_sfo, int min_overlap_len, double min_pident) {
+    return guarded([&] {                                         // script/minimap22sfo.py:28-75 - a text converter
+        if (!in_paf || !out_sfo) fail(HLMI_EINVAL, "hlmi_minimap22sfo: NULL path");
+        PafText pt;
+        read_paf(in_paf, pt, false);
+        std::vector<std::string> lines;
+        for (const PafRec &rc : pt.recs) {
+            if ((int64_t)rc.blen < (int64_t)min_overlap_len) continue;
+            if ((double)rc.nmatch / (double)rc.blen < min_pident / 100.0) continue;
+            const bool rev = rc.flags & PF_REV;
+            int64_t ql = rc.qlen, qs = rc.qs, tl = rc.tlen, ts = rc.ts, te = rc.te, oha, ohb;
+            if (!rev) { oha = qs - ts; ohb = tl - ts - (ql - qs); }
+            else { oha = qs - (tl - te); ohb = te - (ql - qs); }
+            const int64_t ola = oha >= 0 ? std::min(ql - oha, tl) : std::min(tl + oha, ql);
+            const std::string *a = &pt.dict.names[rc.qid], *b = &pt.dict.names[rc.tid];
+            if (*a > *b) {                                       // ids in string order; read A forward
+                std::swap(a, b);
+                if (!rev) { oha = -oha; ohb = -ohb; } else std::swap(oha, ohb);
+            }
+            char buf[160];
+            snprintf(buf, sizeof buf, "\t%c\t%lld\t%lld\t%lld\t%lld\t%lld", rev ? 'I' : 'N', (long long)oha, (long long)ohb,
+                     (long long)ola, (long long)ola, (long long)rc.blen - (long long)rc.nmatch);
+            lines.push_back(*a + "\t" + *b + buf);
+        }
+        write_lines(out_sfo, lines);
+    });
+}
+
 int hlmi_merge_scored_paf(const char *const *in_pafs, int n_in, const char *out_paf) {
     return guarded([&] {
         std::vector<std::string> lines;

@@ -37,6 +37,11 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
 void window_filter_device(const PafRec *d_recs, size_t n, const std::vector<uint64_t> &chunk_row_start,
                           int variant, int min_len, double min_iden, int min_o, uint8_t *d_keep);
 
+// filter_ovlp_inline.py: keep[i] = 1 for the longest overlap of each pair per window;
+// first_of[i] = row index of the pair's first surviving row (the position the kept row is printed at)
+void ovlp_inline_device(const PafRec *d_recs, size_t n, int min_len, double min_iden, int o, double r, uint8_t *d_keep,
+                        uint32_t *d_first_of);
+
 // CIGAR ops per chunk id (sizes the chunk groups a caller filters at a time)
 std::vector<uint64_t> ops_per_chunk(const PafRec *d_recs, size_t n, uint32_t n_chunk_ids);
 

@@ -111,6 +111,55 @@ __global__ __launch_bounds__(WG) void window_filter_kernel(const PafRec *__restr
     }
 }
 
+// script/filter_ovlp_inline.py:12-106: per 1000-row window, rows that survive the length /
+// identity / overhang tests and are not self hits compete per unordered pair; the longest (column 11, earlier
+// row on ties) is kept and takes the output position of the pair's first surviving row (first_of).
+__global__ __launch_bounds__(WG) void ovlp_inline_kernel(const PafRec *__restrict__ recs, const uint64_t *__restrict__ win_start,
+                                                         const uint32_t *__restrict__ win_len, int min_len, double min_iden,
+                                                         int o, double r, uint8_t *__restrict__ keep,
+                                                         uint32_t *__restrict__ first_of) {
+    __shared__ uint64_t s_key[1024];
+    __shared__ uint32_t s_len[1024];
+    const uint64_t base = win_start[blockIdx.x];
+    const int m = (int)win_len[blockIdx.x];
+    for (int i = threadIdx.x; i < 1024; i += WG) {
+        uint64_t key = ~0ull;
+        uint32_t len = 0;
+        if (i < m) {
+            const PafRec rc = recs[base + i];
+            bool ok = !(rc.flags & PF_BAD) && !((int64_t)rc.blen < (int64_t)min_len);
+            if (ok) ok = !((double)rc.nmatch / (double)rc.blen < min_iden);
+            if (ok) {                                   // rm_intermatch: overhang > min(o, maplen * r)
+                int64_t ql = rc.qlen, qs = rc.qs, qe = rc.qe, tl = rc.tlen, ts = rc.ts, te = rc.te;
+                if (rc.flags & PF_REV) { const int64_t s2 = tl - te, e2 = tl - ts; ts = s2; te = e2; }
+                const int64_t overhang = (qs < ts ? qs : ts) + ((ql - qe) < (tl - te) ? (ql - qe) : (tl - te));
+                const int64_t maplen = (qe - qs) > (te - ts) ? (qe - qs) : (te - ts);
+                const double lim = (double)maplen * r, thr = (double)o < lim ? (double)o : lim;
+                ok = !((double)overhang > thr);
+            }
+            if (ok && rc.qid != rc.tid) { key = pair_key(rc.qid, rc.tid); len = rc.blen; }
+        }
+        s_key[i] = key;
+        s_len[i] = len;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += WG) {
+        const uint64_t key = s_key[i];
+        bool best = key != ~0ull;
+        int first = i;
+        if (best) {
+            const uint32_t len = s_len[i];
+            for (int j = 0; j < m; ++j) {
+                if (j == i || s_key[j] != key) continue;
+                if (j < first) first = j;
+                if (s_len[j] > len || (s_len[j] == len && j < i)) best = false;
+            }
+        }
+        keep[base + i] = best ? 1 : 0;
+        first_of[base + i] = (uint32_t)(base + first);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------
@@ -392,6 +441,21 @@ void window_filter_device(const PafRec *d_recs, size_t n, const std::vector<uint
                            d_wl.p, min_len, min_iden, min_o, d_keep);
     else
         fail(HLMI_EINVAL, "window filter variant must be 3 or 4");
+    HIP_CHECK(hipGetLastError());
+    sync();
+}
+
+void ovlp_inline_device(const PafRec *d_recs, size_t n, int min_len, double min_iden, int o, double r, uint8_t *d_keep,
+                        uint32_t *d_first_of) {
+    if (!n) return;
+    std::vector<uint32_t> wlen;
+    std::vector<uint64_t> wstart = make_windows({0, (uint64_t)n}, wlen);
+    DBuf<uint64_t> d_ws;
+    DBuf<uint32_t> d_wl;
+    d_ws.upload(wstart);
+    d_wl.upload(wlen);
+    hipLaunchKernelGGL(ovlp_inline_kernel, dim3((unsigned)wstart.size()), dim3(WG), 0, stream(), d_recs, d_ws.p, d_wl.p, min_len,
+                       min_iden, o, r, d_keep, d_first_of);
     HIP_CHECK(hipGetLastError());
     sync();
 }

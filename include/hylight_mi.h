@@ -68,6 +68,16 @@ int hlmi_filter_chunk(const char *paf_in, const char *out_overlap4_paf, int len_
 int hlmi_paf_window_filter(int variant, int min_len, double min_iden, int min_o, int sfo,
                            const char *in_paf, const char *out_path);
 
+/* ---- the short-read cluster path's filter and converter ----------------- */
+/* filter_ovlp_inline.py <min_ovlp_len> <min_identity> <o> <r> (script/filter_ovlp_inline.py:12-106,
+ * called at polyte.tune_params.py:507-511): 1000-row windows, internal-match test, longest overlap per
+ * pair.  Runs on the GPU. */
+int hlmi_filter_ovlp_inline(const char *in_paf, const char *out_paf, int min_ovlp_len, double min_identity,
+                            int o, double r);
+/* minimap22sfo.py --in --out -m <min_overlap_len> -p <min_pident> (script/minimap22sfo.py:28-75): PAF -> SFO with
+ * the ids in string order.  Pure text conversion (host). */
+int hlmi_minimap22sfo(const char *in_paf, const char *out_sfo, int min_overlap_len, double min_pident);
+
 /* ---- a3: the overlapper (replaces the external minimap2 call, slr2:51 / slr2:55) -------- */
 typedef struct {
     int k;                 /* 19 (long, -Hk19) */

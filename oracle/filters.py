@@ -299,6 +299,56 @@ def stage(chunk_raw_lines, long_mode, min_ovlp_len, mc, iden):
 
 
 # --------------------------------------------------------------------------------------------
+# the short-read cluster path's filter and converter
+# --------------------------------------------------------------------------------------------
+def ovlp_inline_filter(lines, min_ovlp_len, min_identity, o=1000, r=0.8):
+    """script/filter_ovlp_inline.py:12-106.  Per window of 1000 rows: drop short / divergent / internal rows
+    (rm_intermatch), then drop self hits and keep, per unordered pair, the LONGEST overlap (column 11; the
+    earlier row wins ties) - printed at the position where the pair first appeared (rm_dupovlp)."""
+    out = []
+    for w0 in range(0, len(lines), WINDOW):
+        best, order = {}, []
+        for line in lines[w0:w0 + WINDOW]:
+            q, ql, qs, qe, strand, t, tl, ts, te, mc, ln = _cols(line)
+            if ln < min_ovlp_len or mc / ln < min_identity:
+                continue
+            if strand == "-":
+                ts, te = tl - te, tl - ts
+            if min(qs, ts) + min(ql - qe, tl - te) > min(o, max(qe - qs, te - ts) * r):
+                continue
+            if q == t:
+                continue
+            pk = pair_key(q, t)
+            if pk not in best:
+                best[pk] = (ln, line)
+                order.append(pk)
+            elif ln > best[pk][0]:
+                best[pk] = (ln, line)
+        out += [best[pk][1] for pk in order]
+    return out
+
+
+def minimap22sfo(lines, min_overlap_len=0, min_pident=0.0):
+    """script/minimap22sfo.py:28-75: PAF -> SFO with the ids put in (string) order."""
+    out = []
+    for line in lines:
+        q, ql, qs, qe, strand, t, tl, ts, te, mc, ln = _cols(line)
+        if ln < min_overlap_len or mc / float(ln) < min_pident / 100.0:
+            continue
+        if strand == "+":
+            ori, oha, ohb = "N", qs - ts, tl - ts - (ql - qs)
+        else:
+            ori, oha, ohb = "I", qs - (tl - te), te - (ql - qs)
+        ola = min(ql - oha, tl) if oha >= 0 else min(tl + oha, ql)
+        a, b = q, t
+        if a > b:
+            a, b = b, a
+            oha, ohb = (-oha, -ohb) if ori == "N" else (ohb, oha)
+        out.append("\t".join(map(str, (a, b, ori, oha, ohb, ola, ola, ln - mc))))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # a18 : SFO -> SAVAGE overlaps (single-end reads only: HyLight passes --num_pairs 0)
 # --------------------------------------------------------------------------------------------
 def sfo2overlaps(sfo_lines):

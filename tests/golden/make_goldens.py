@@ -175,6 +175,13 @@ def main():
         run(f"{mini} {flags} -f {fa} {paf} > {HERE}/fxA_miniasm_{tag}.gfa 2>/dev/null")
         for p in ("paf", "bed", "sg"):
             run(f"{mini} {flags} -p {p} {paf} > {HERE}/fxA_miniasm_{tag}.{p} 2>/dev/null")
+    # filter_ovlp_inline.py + minimap22sfo.py as polyte.tune_params.py:507-515 chains them
+    # (`cut -f 1-12 | filter_ovlp_inline.py <len> <iden> <o> <r>` then `minimap22sfo.py -m 0 -p 0`)
+    for tag, a in (("len90_oh30", "90 0.9 30 0.8"), ("len90_oh1", "90 0.98 1 0.8")):
+        run(f"python {SCRIPT}/filter_ovlp_inline.py {a} < {HERE}/fxC_contigs.paf > {HERE}/fxC_inline_{tag}.paf", env=env)
+        run(f"python {SCRIPT}/minimap22sfo.py --in {HERE}/fxC_inline_{tag}.paf --out {HERE}/fxC_inline_{tag}.sfo -m 0 -p 0", env=env)
+    run(f"python {SCRIPT}/minimap22sfo.py --in {HERE}/fxC_contigs.paf --out {HERE}/fxC_m22sfo_m200_p99.sfo -m 200 -p 99", env=env)
+
     # fixture D: imperfect overlaps -> tips, bubbles, bi-loops, internal cuts, short-overlap removal
     for seed in (1, 2, 3):
         readsD, pafD = S.messy_graph_paf(seed)

@@ -72,6 +72,22 @@ def test_filter_chunk_against_oracle_on_dense_bidirectional_input(golden, tmp_pa
     assert _lines(out) == want and len(want) > 100
 
 
+@pytest.mark.parametrize("tag,args", [("len90_oh30", (90, 0.9, 30, 0.8)), ("len90_oh1", (90, 0.98, 1, 0.8))])
+def test_filter_ovlp_inline_then_minimap22sfo(golden, tmp_path, tag, args):
+    # SURVEY 8f rank 2, chained as polyte.tune_params.py:507-515 does
+    paf, sfo = tmp_path / "o.paf", tmp_path / "o.sfo"
+    api.filter_ovlp_inline(_plain(golden, "fxC_contigs.paf", tmp_path), paf, *args)
+    assert _lines(paf) == golden.lines(f"fxC_inline_{tag}.paf")
+    api.minimap22sfo(paf, sfo, 0, 0)
+    assert _lines(sfo) == golden.lines(f"fxC_inline_{tag}.sfo")
+
+
+def test_minimap22sfo_thresholds(golden, tmp_path):
+    sfo = tmp_path / "o.sfo"
+    api.minimap22sfo(_plain(golden, "fxC_contigs.paf", tmp_path), sfo, 200, 99)
+    assert _lines(sfo) == golden.lines("fxC_m22sfo_m200_p99.sfo")
+
+
 def test_empty_input(tmp_path):
     src = tmp_path / "empty.paf"
     src.write_text("")

@@ -36,6 +36,18 @@ def test_sfo2overlaps(golden, tag):
     assert F.sfo2overlaps(golden.lines(tag + ".sfo")) == golden.lines(tag + ".savage")
 
 
+@pytest.mark.parametrize("tag,args", [("len90_oh30", (90, 0.9, 30, 0.8)), ("len90_oh1", (90, 0.98, 1, 0.8))])
+def test_filter_ovlp_inline_and_minimap22sfo(golden, tag, args):
+    # reference CLIs chained as in polyte.tune_params.py:507-515
+    kept = F.ovlp_inline_filter(golden.lines("fxC_contigs.paf"), *args)
+    assert kept == golden.lines(f"fxC_inline_{tag}.paf")
+    assert F.minimap22sfo(kept, 0, 0) == golden.lines(f"fxC_inline_{tag}.sfo")
+
+
+def test_minimap22sfo_thresholds(golden):
+    assert F.minimap22sfo(golden.lines("fxC_contigs.paf"), 200, 99) == golden.lines("fxC_m22sfo_m200_p99.sfo")
+
+
 def test_intermediate_sort(golden):
     assert F.sort_intermediate(golden.lines("fxA_v4.paf")) == golden.lines("fxA_v4_sorted.paf")
 
