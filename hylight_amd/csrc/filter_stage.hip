@@ -324,11 +324,14 @@ __global__ void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const u
 // ---------------------------------------------------------------------------------------
 // a6: support test per SNP key, then per-pair counts
 // ---------------------------------------------------------------------------------------
-__global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_key, const uint32_t *ev_partner,
-                                   const uint32_t *ev_perm, const uint32_t *kseg_start, size_t n_kseg, size_t n_ev,
-                                   const uint32_t *ivs_chunk, const uint64_t *ivs_key, const uint32_t *ive_chunk,
-                                   const uint64_t *ive_key, size_t n_iv, const uint32_t *pseg_chunk,
-                                   const uint64_t *pseg_key, size_t n_pseg, int mc, uint32_t *pair_mut) {
+// Two balanced kernels: (1) one thread per distinct SNP key decides "supported" (v >= mc supporters and >= mc
+// further spanning reads) and writes the verdict over the key's event range; (2) one thread per EVENT of a
+// supported key looks its pair group up and bumps the pair's counter.  (A key on a deeply covered read has
+// hundreds of events; a single thread walking them all was the long pole of the filter stage.)
+__global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_key, const uint32_t *kseg_start,
+                                   size_t n_kseg, size_t n_ev, const uint32_t *ivs_chunk, const uint64_t *ivs_key,
+                                   const uint32_t *ive_chunk, const uint64_t *ive_key, size_t n_iv, int mc,
+                                   uint8_t *ev_supported) {
     size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (s >= n_kseg) return;
     size_t b = kseg_start[s], e = (s + 1 < n_kseg) ? kseg_start[s + 1] : n_ev;
@@ -344,13 +347,19 @@ __global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_
                        (int64_t)lower_bound_ck(ive_chunk, ive_key, n_iv, c, read0);
     int64_t con = n_start_lt - n_end_le;
     if (con - v < mc) return;
-    const uint32_t read = (uint32_t)(key >> 32);
-    for (size_t i = b; i < e; ++i) {
-        uint32_t other = ev_partner[ev_perm[i]];
-        uint64_t pk = pair_key(read, other);
-        size_t p = lower_bound_ck(pseg_chunk, pseg_key, n_pseg, c, pk);
-        if (p < n_pseg && pseg_chunk[p] == c && pseg_key[p] == pk) atomicAdd(&pair_mut[p], 1u);
-    }
+    for (size_t i = b; i < e; ++i) ev_supported[i] = 1;      // contiguous bytes; v is at most the read depth
+}
+
+__global__ void snp_pair_count_kernel(const uint32_t *ev_chunk, const uint64_t *ev_key, const uint32_t *ev_partner,
+                                      const uint32_t *ev_perm, const uint8_t *ev_supported, size_t n_ev,
+                                      const uint32_t *pseg_chunk, const uint64_t *pseg_key, size_t n_pseg,
+                                      uint32_t *pair_mut) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n_ev || !ev_supported[i]) return;
+    const uint32_t c = ev_chunk[i], read = (uint32_t)(ev_key[i] >> 32), other = ev_partner[ev_perm[i]];
+    const uint64_t pk = pair_key(read, other);
+    size_t p = lower_bound_ck(pseg_chunk, pseg_key, n_pseg, c, pk);
+    if (p < n_pseg && pseg_chunk[p] == c && pseg_key[p] == pk) atomicAdd(&pair_mut[p], 1u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -523,9 +532,12 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
         DBuf<uint32_t> kseg_start(E);
         const size_t n_kseg = select_flagged_indices(khead.p, kseg_start.p, E);
         // ---- a6 ---------------------------------------------------------------------------------
-        hipLaunchKernelGGL(snp_support_kernel, grid1(n_kseg), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p,
-                           ev_partner.p, sev.perm.p, kseg_start.p, n_kseg, E, sis.chunk.p, sis.key.p, sie.chunk.p,
-                           sie.key.p, I, pseg_chunk.p, pseg_key.p, n_pseg, cfg.mc, pair_mut.p);
+        DBuf<uint8_t> ev_sup(E);
+        ev_sup.zero();
+        hipLaunchKernelGGL(snp_support_kernel, grid1(n_kseg), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p, kseg_start.p,
+                           n_kseg, E, sis.chunk.p, sis.key.p, sie.chunk.p, sie.key.p, I, cfg.mc, ev_sup.p);
+        hipLaunchKernelGGL(snp_pair_count_kernel, grid1(E), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p, ev_partner.p,
+                           sev.perm.p, ev_sup.p, E, pseg_chunk.p, pseg_key.p, n_pseg, pair_mut.p);
         HIP_CHECK(hipGetLastError());
         sync();
     }
