@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             int ht = mm > f ? mm : f;
             if (i == 0 && j == 0) ht = 0;
             if (!valid) ht = NEG_INF;
-            const int pm = wave_shr1(wave_prefix_max_incl_dpp(ht + ge * lane, NEG_INF * 2), NEG_INF * 2);
+            const int pm = wave_shr1(wave_prefix_max_incl_dpp(ht + ge * lane), NEG_INF * 2);
             int e = NEG_INF;
             if (valid && j > 0 && lane > 0) e = pm - go - ge * lane;
             int h, src;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
             int ht = mm > f ? mm : f;
             if (i == 0 && j == 0) ht = 0;
             if (!valid) ht = NEG_INF;
-            const int pm = row_shr1(row_prefix_max_incl_dpp(ht + ge * l, NEG_INF * 2), NEG_INF * 2);
+            const int pm = row_shr1(row_prefix_max_incl_dpp(ht + ge * l), NEG_INF * 2);
             int e = NEG_INF;
             if (valid && j > 0 && l > 0) e = pm - go - ge * l;
             int h, src;

@@ -6,9 +6,9 @@
 //             pair-once rule strcmp(qname,tname) < 0 (ava "no dual / no diagonal"), anchors packed as
 //             key = qlocal | target:tb | strand:1 | tpos:pb (widths per batch) ,  val = qpos:32 | qspan:8
 //   order   : one stable 64-bit radix sort per query batch (generation order breaks ties)
-//   chains  : one wavefront per (query,target,strand) group.  The DP keeps the previous 64 anchors in
-//             a register ring (lane l = predecessor i-1-l), every lane scores one predecessor and a
-//             wave max-reduction picks the best (Li 2018 eq. 1-2, integer gap cost); chain extraction
+//   chains  : one wavefront per (query,target,strand) group.  The DP keeps the current and the previous
+//             block of 64 anchors in registers (lane = index mod 64), every lane scores one predecessor and
+//             a wave max-reduction picks the best (Li 2018 eq. 1-2, integer gap cost); chain extraction
 //             hands each anchor's trunk to its best child (64-bit atomicMax) and lets every lane walk
 //             one chain: cut at the peak, split into alignment pieces of fixed points.
 // Integer / index work throughout: HBM- and latency-bound, no MFMA.
@@ -25,7 +25,7 @@ constexpr int WG = 256;
 constexpr int HB = 1024;             // occurrence histogram bins per chunk
 // anchor key = qlocal | target | strand | tpos, packed with the bit widths the batch actually needs (pb bits of
 // target position, tb bits of target id): the anchor radix sort then runs 5 passes instead of 8 on C2
-constexpr int QL_BITS = 11, T_BITS_MAX = 21, TPOS_BITS_MAX = 31;
+constexpr int QL_BITS = 11, T_BITS_MAX = 21, TPOS_BITS_MAX = 24;     // chain scores (<= target length) carry 6 tie-break bits in 32
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 
 __device__ __forceinline__ size_t lower_bound_u64(const uint64_t *a, size_t n, uint64_t v) {
@@ -277,19 +277,40 @@ __device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *me
     n_fps = nf;
 }
 
-__global__ __launch_bounds__(WG) void chain_kernel(ChainArgs a) {
-    const int lane = threadIdx.x & 63;
-    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
-    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t g = wave; g < a.n_groups; g += n_waves) {
-        const size_t b = a.gstart[g];
-        const size_t e = g + 1 < a.n_groups ? a.gstart[g + 1] : a.n_anchors;
+constexpr int PEN_TAB = 2048;         // gap-cost table entries (bandwidth + 2 must fit; else the VALU form runs)
+
+// Phase A keeps two 64-anchor blocks in registers, lane = anchor index mod 64: the 64 predecessors of anchor
+// i0+bb are the lanes below bb of the current block and the lanes from bb up of the previous one, so nothing is
+// shifted per anchor and f / p leave as coalesced 256-byte stores.  The gap cost is an LDS table look-up
+// (dd*k/100 would be two quarter-rate multiplies per lane).
+// One wave per workgroup, CHAIN_GROUPS consecutive groups per workgroup: group sizes span three orders of
+// magnitude, so the balancing is left to the hardware dispatcher (a fixed grid-stride split of the groups
+// left the SIMDs at 3 of 8 resident waves on average).
+constexpr int CHAIN_GROUPS = 4;
+template <bool TAB>
+__global__ __launch_bounds__(64) void chain_kernel(ChainArgs a) {
+    __shared__ uint16_t pen_tab[TAB ? PEN_TAB : 1];
+    const int lane = threadIdx.x;
+    if (TAB) {
+        for (int d = lane; d < a.bw + 2; d += 64)
+            pen_tab[d] = (uint16_t)(d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const size_t g_lo = (size_t)blockIdx.x * CHAIN_GROUPS;
+    const size_t g_hi = g_lo + CHAIN_GROUPS < a.n_groups ? g_lo + CHAIN_GROUPS : a.n_groups;
+    for (size_t g = g_lo; g < g_hi; ++g) {
+        const size_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g]);
+        const size_t e = g + 1 < a.n_groups ? (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g + 1]) : a.n_anchors;
         const int n = (int)(e - b);
         if (n < a.min_cnt) continue;
-        // ---- phase A: DP -------------------------------------------------------------------------------
-        int r_t = 0, r_q = 0, r_f = 0;                   // ring: lane l holds predecessor i-1-l
+        // ---- phase A: DP;  phase B: best child of every anchor (64-bit atomicMax of f << 32 | ~index) ----------
+        // R_t / R_q / R_f: lane l = the latest anchor with index = l mod 64, i.e. the 64 predecessors of the anchor
+        // about to be scored.  Everything that does not depend on f (gap geometry, gap cost look-up) is computed
+        // one anchor ahead, so it fills the wait states of the reduction of the anchor before it.
+        int R_t = 0, R_q = 0x3fffffff, R_f = 0;               // "no predecessor": dq < 0 fails the gap test
         for (int i0 = 0; i0 < n; i0 += 64) {
-            int my_t = 0, my_q = 0, my_s = 0;
+            int my_t = 0, my_q = 0, my_s = 0, my_p = -1;
             if (i0 + lane < n) {
                 const uint64_t key = a.key[b + i0 + lane], val = a.val[b + i0 + lane];
                 my_t = (int)(key & a.pmask);
@@ -297,41 +318,44 @@ __global__ __launch_bounds__(WG) void chain_kernel(ChainArgs a) {
                 my_s = (int)((val >> 24) & 0xff);
             }
             const int nb = n - i0 < 64 ? n - i0 : 64;
+            int w_cur = 0, si_cur = 0;
+            auto prepare = [&](int bb, int &w, int &si) {
+                const int ti = __builtin_amdgcn_readlane(my_t, bb), qi = __builtin_amdgcn_readlane(my_q, bb);
+                si = __builtin_amdgcn_readlane(my_s, bb);
+                const int dr = ti - R_t, dq = qi - R_q;       // dr >= 0: the group is sorted by target position
+                const int dg = dr < dq ? dr : dq, mx = dr < dq ? dq : dr, dd = mx - dg;
+                const bool ok = (dg >= 1) & (mx <= a.max_gap) & (dd <= a.bw);
+                int pen;
+                if (TAB) {
+                    const uint32_t di = (uint32_t)dd < (uint32_t)(a.bw + 1) ? (uint32_t)dd : (uint32_t)(a.bw + 1);
+                    pen = pen_tab[di];
+                } else {
+                    pen = dd ? (dd * a.k) / 100 + (ilog2_u32((uint32_t)dd) >> 1) : 0;
+                }
+                // ties go to the closest predecessor: code = 64 - distance
+                const int v = ((dg < si ? dg : si) - pen + 1024) << 6 | (int)((uint32_t)(lane - bb) & 63u);
+                w = ok ? v : -(1 << 30);
+                R_t = writelane_i32(R_t, ti, bb);
+                R_q = writelane_i32(R_q, qi, bb);
+            };
+            prepare(0, w_cur, si_cur);
             for (int bb = 0; bb < nb; ++bb) {
-                const int i = i0 + bb;
-                const int ti = __builtin_amdgcn_readlane(my_t, bb), qi = __builtin_amdgcn_readlane(my_q, bb),
-                          si = __builtin_amdgcn_readlane(my_s, bb);
-                const int dr = ti - r_t, dq = qi - r_q;
-                uint32_t k32 = 0;
-                if (lane < i && dr <= a.max_gap && dq > 0 && dq <= a.max_gap && dr != 0) {
-                    const int dd = dr > dq ? dr - dq : dq - dr;
-                    if (dd <= a.bw) {
-                        const int dg = dr < dq ? dr : dq;
-                        const int sc = dg < si ? dg : si;
-                        const int pen = dd ? (dd * a.k) / 100 + (ilog2_u32((uint32_t)dd) >> 1) : 0;
-                        const int cand = r_f + sc - pen;
-                        k32 = (uint32_t)(cand + 1024) << 6 | (uint32_t)(63 - lane);
-                    }
-                }
-                const uint32_t best = wave_max_u32_dpp(k32);
-                int bf = si, bp = -1;
-                if (best) {
-                    const int c = (int)(best >> 6) - 1024;
-                    if (c > si) { bf = c; bp = i - 1 - (63 - (int)(best & 63)); }
-                }
-                if (lane == 0) { a.f[b + i] = bf; a.p[b + i] = bp; }
-                r_t = wave_shr1(r_t, ti);       // ring: lane l <- lane l-1, lane 0 <- anchor i
-                r_q = wave_shr1(r_q, qi);
-                r_f = wave_shr1(r_f, bf);
+                int w_nxt, si_nxt;
+                prepare(bb + 1 < nb ? bb + 1 : bb, w_nxt, si_nxt);
+                const int best = wave_max_i32_dpp((R_f << 6) + w_cur);     // (f + sc - pen + 1024) << 6 | code
+                const int c = (best >> 6) - 1024;
+                const int bf = c > si_cur ? c : si_cur;
+                const int bp = c > si_cur ? i0 + bb - 64 + (best & 63) : -1;
+                R_f = writelane_i32(R_f, bf, bb);
+                my_p = writelane_i32(my_p, bp, bb);
+                w_cur = w_nxt; si_cur = si_nxt;
             }
-        }
-        __threadfence_block();
-        if (!(a.dbg_phases & 2)) continue;
-        // ---- phase B: best child of every anchor -------------------------------------------------------------
-        for (int i = lane; i < n; i += 64) {
-            const int pi = a.p[b + i];
-            if (pi >= 0)
-                atomicMax(&a.bck[b + pi], (unsigned long long)(uint32_t)a.f[b + i] << 32 | (0xffffffffu - (uint32_t)i));
+            if (i0 + lane < n) {
+                a.f[b + i0 + lane] = R_f;
+                a.p[b + i0 + lane] = my_p;
+                if ((a.dbg_phases & 2) && my_p >= 0)
+                    atomicMax(&a.bck[b + my_p], (unsigned long long)(uint32_t)R_f << 32 | (0xffffffffu - (uint32_t)(i0 + lane)));
+            }
         }
         __threadfence_block();
         if (!(a.dbg_phases & 4)) continue;
@@ -498,7 +522,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (in.T->n > (1u << T_BITS_MAX)) fail(HLMI_EINVAL, "more than %d targets in one run", 1 << T_BITS_MAX);
     uint64_t max_tlen = 1;
     for (size_t t = 0; t < in.T->n; ++t) max_tlen = std::max<uint64_t>(max_tlen, in.T->h_off[t + 1] - in.T->h_off[t]);
-    if (max_tlen >= (1ull << TPOS_BITS_MAX)) fail(HLMI_EINVAL, "target longer than 2^31 bases");
+    if (max_tlen >= (1ull << TPOS_BITS_MAX)) fail(HLMI_EINVAL, "target longer than 2^24 bases");
     const int pb = bits_for(max_tlen), tb = bits_for(in.T->n > 1 ? in.T->n - 1 : 1);
     SeedArgs sa = make_seed_args(in, ix, d_qlen, q_lo, q_hi);
     sa.pb = pb; sa.tb = tb;
@@ -550,10 +574,13 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     out.pieces.alloc(ca.cap_pieces);
     out.fps.alloc(ca.cap_fps);
     ca.pieces = out.pieces.p; ca.fps = out.fps.p; ca.counters = counters.p;
-    const unsigned n_blocks = (unsigned)std::min<size_t>((G + 3) / 4, 256 * 8);
+    const unsigned n_blocks = (unsigned)cdiv(G, (size_t)CHAIN_GROUPS);
     {
         KTimer kt("chain");
-        hipLaunchKernelGGL(chain_kernel, dim3(n_blocks ? n_blocks : 1), dim3(WG), 0, stream(), ca);
+        if (o.bandwidth + 2 <= PEN_TAB)
+            hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks ? n_blocks : 1), dim3(64), 0, stream(), ca);
+        else
+            hipLaunchKernelGGL(chain_kernel<false>, dim3(n_blocks ? n_blocks : 1), dim3(64), 0, stream(), ca);
     }
     HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> hc = counters.download(4);

@@ -19,6 +19,8 @@ __device__ __forceinline__ int dpp_i32(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
 }
 
+constexpr int DPP_MAX_IDENT = (int)0x80000000u;   // identity of signed max: lets a dpp move fold into v_max_i32_dpp
+
 // max over the 64 lanes (unsigned, identity 0), returned to every lane
 __device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
     int x = (int)v;
@@ -32,8 +34,22 @@ __device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
-// inclusive prefix max over the 64 lanes (signed, `ident` = value smaller than every input)
-__device__ __forceinline__ int wave_prefix_max_incl_dpp(int x, int ident) {
+// max over the 64 lanes (signed), returned to every lane.  `old` = INT_MIN is the identity of signed max, which
+// is what lets the compiler fold every step into one v_max_i32_dpp (any other filler costs three instructions).
+__device__ __forceinline__ int wave_max_i32_dpp(int x) {
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    x = mx(x, dpp_i32<0x111>(DPP_MAX_IDENT, x));
+    x = mx(x, dpp_i32<0x112>(DPP_MAX_IDENT, x));
+    x = mx(x, dpp_i32<0x114>(DPP_MAX_IDENT, x));
+    x = mx(x, dpp_i32<0x118>(DPP_MAX_IDENT, x));
+    x = mx(x, dpp_i32<0x142, 0xa>(DPP_MAX_IDENT, x));
+    x = mx(x, dpp_i32<0x143, 0xc>(DPP_MAX_IDENT, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// inclusive prefix max over the 64 lanes (signed)
+__device__ __forceinline__ int wave_prefix_max_incl_dpp(int x) {
+    constexpr int ident = DPP_MAX_IDENT;
     auto mx = [](int a, int b) { return a > b ? a : b; };
     x = mx(x, dpp_i32<0x111>(ident, x));
     x = mx(x, dpp_i32<0x112>(ident, x));
@@ -50,7 +66,8 @@ __device__ __forceinline__ int row_shl1(int x, int last) { return dpp_i32<0x101>
 // lane l <- lane l-1 of its row (l == 0 keeps `first`)
 __device__ __forceinline__ int row_shr1(int x, int first) { return dpp_i32<0x111>(first, x); }
 // inclusive prefix max inside every row of 16
-__device__ __forceinline__ int row_prefix_max_incl_dpp(int x, int ident) {
+__device__ __forceinline__ int row_prefix_max_incl_dpp(int x) {
+    constexpr int ident = DPP_MAX_IDENT;
     auto mx = [](int a, int b) { return a > b ? a : b; };
     x = mx(x, dpp_i32<0x111>(ident, x));
     x = mx(x, dpp_i32<0x112>(ident, x));
@@ -58,6 +75,11 @@ __device__ __forceinline__ int row_prefix_max_incl_dpp(int x, int ident) {
     x = mx(x, dpp_i32<0x118>(ident, x));
     return x;
 }
+
+// `old` with lane `sel` replaced by the wave-uniform `v`: v_writelane_b32.  clang has no builtin for it, so the
+// LLVM intrinsic is bound by name (the way the ROCm device libraries bind theirs).
+extern "C" __device__ int hlmi_llvm_writelane(int v, int sel, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int writelane_i32(int old, int v, int sel) { return hlmi_llvm_writelane(v, sel, old); }
 
 // lane i <- lane i-1 (lane 0 keeps `lane0`)
 __device__ __forceinline__ int wave_shr1(int x, int lane0) { return dpp_i32<0x138>(lane0, x); }
