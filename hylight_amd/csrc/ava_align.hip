@@ -26,6 +26,8 @@ constexpr int WAVES = WG / 64;
 constexpr int TB_ROWS = 257;
 constexpr int SEQ_T_MAX = EXT_MAX + BAND_W;     // 320
 constexpr int UNIT_MAX = EXT_MAX + SEQ_T_MAX + 16;
+constexpr int NR_SHORT = 128;                   // rows of an align_narrow_kernel<NR_SHORT> task; longer near-diagonal
+                                                // blocks (3-4 % of them) run in the <BLOCK_MAX> instance with twice the LDS
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 
 struct Task {               // 32 B
@@ -87,7 +89,7 @@ __global__ void task_bases_kernel(const Task *tasks, const uint8_t *cls, size_t 
         const unsigned long long b = (unsigned long long)(tasks[i].m + tasks[i].n);
         v[0] += b;
         if (tasks[i].kind == 0 && tasks[i].m == tasks[i].n) v[1] += b;
-        if (cls[i] == 1) v[2] += b;
+        if (cls[i] == 1 || cls[i] == 3) v[2] += b;
         if (cls[i] == 2) v[3] += b;
     }
 #pragma unroll
@@ -110,6 +112,7 @@ struct AlignArgs {
     const uint8_t *qcodes, *tcodes;
     const uint64_t *qoff, *toff;
     const uint32_t *qlen;
+    long long q_total, t_total;   // bytes in qcodes / tcodes (4-base loads stay inside)
     int match, mismatch, go, ge, ambi;
     int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
@@ -348,7 +351,8 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
 }
 
 // ---- pass 1: classification + diagonal fast path, one 16-lane group per task --------------------------------
-// cls[task] = 0 done here (empty task or fast path), 1 DP in the 16-diagonal band, 2 DP in the 64-diagonal band
+// cls[task] = 0 done here (empty task or fast path), 1 / 3 DP in the 16-diagonal band (<= / > NR_SHORT rows),
+// 2 DP in the 64-diagonal band
 __device__ __forceinline__ uint8_t load_q(const AlignArgs &a, const Piece &pc, const uint8_t *qb, int ql, int pos) {
     uint8_t c;
     if (pc.strand) { c = qb[ql - 1 - pos]; c = c < 4 ? 3 - c : 4; } else c = qb[pos];
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls)
         bool try_fast = false;
         if (live) {
             if (m <= 0 || n <= 0) c = 0;
-            else if (tk.kind == 0) { c = tk.narrow ? 1 : 2; try_fast = (m == n); }
+            else if (tk.kind == 0) { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
         }
         // mismatch positions of square blocks, 16 bases per step; stop as soon as a group has too many
         int k = 0, mpos[4] = {0, 0, 0, 0};
@@ -433,27 +437,168 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls)
     }
 }
 
-__global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, uint8_t *f2) {
+__global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, uint8_t *f2, uint8_t *f3) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) { f1[i] = cls[i] == 1; f2[i] = cls[i] == 2; }
+    if (i < n) { f1[i] = cls[i] == 1; f2[i] = cls[i] == 2; f3[i] = cls[i] == 3; }
 }
 
 // ---- pass 2a: DP of near-diagonal blocks, FOUR tasks per wave (one per row of 16 lanes) --------------------------
 // Same recurrences and tie rules as align_kernel with W = 16; every cross-lane step is a DPP row operation, so
-// the four groups of a wave never interact.  Traceback bits: one u64 per DP row and group (4 planes x 16 bits).
-constexpr int N_ROWS = BLOCK_MAX + 1;
-constexpr int N_T = BLOCK_MAX + NARROW_DELTA + 3;
-constexpr int N_U = 2 * BLOCK_MAX + NARROW_DELTA + 8;
+// the four groups of a wave never interact.  What differs is the bookkeeping:
+//   * no validity masks: the band starts from H(0,j) and -inf elsewhere, cells left of column 0 stay -inf by
+//     themselves, cells right of column n and rows below m compute garbage that nothing valid depends on
+//     (every DP dependence goes to an equal or larger j) and that the traceback never visits;
+//   * the traceback bits stay with the lane (= diagonal) that produced them: five bit planes, one bit per
+//     row, shifted into 32-bit accumulators by v_addc (carry-in = the compare) and flushed to LDS every 32 rows
+//     (row i = bit 31 - (i-1)%32 of word (i-1)/32);
+//       DIAG  mm == h              the cell took the diagonal move (ties: M > E > F)
+//       EGEF  e >= f               otherwise E, else F
+//       EEXT  e + open > h         E of the cell to the RIGHT extends this cell's E (its flagE)
+//       FEXT  f - ext > h - o - e  F of the cell BELOW extends this cell's F (its flagF)
+//       NE    q != t               '=' or 'X' of a diagonal move
+//   * a diagonal of the traceback is then a run of ones in ONE word: count-trailing-ones finds its length, the
+//     NE word its mismatches; the walk is per event, not per base, and is done twice (count, then write) so the
+//     runs go straight into the pool in forward order.
+constexpr int NT_PAD = 16;                   // st index of target offset 0
+constexpr int NT_EXTRA = NT_PAD + NARROW_DELTA + NARROW_W + 7;     // st length = rows + NT_EXTRA
+enum { PL_DIAG = 0, PL_EGEF, PL_EEXT, PL_FEXT, PL_NE, N_PLANES };
+
+// 4 codes at base[idx .. idx+3] (little endian); bytes outside [0, total) read as 4
+__device__ __forceinline__ uint32_t load_codes4(const uint8_t *base, long long idx, long long total) {
+    if (idx >= 0 && idx + 4 <= total) {
+        uint32_t v;
+        __builtin_memcpy(&v, base + idx, 4);
+        return v;
+    }
+    uint32_t v = 0;
+    for (int k = 0; k < 4; ++k) v |= (uint32_t)(idx + k >= 0 && idx + k < total ? base[idx + k] : 4) << (8 * k);
+    return v;
+}
+// reverse complement of 4 packed codes (3 - c for ACGT, 4 stays 4), byte order reversed
+__device__ __forceinline__ uint32_t revcomp_codes4(uint32_t x) {
+    const uint32_t n = x & 0x04040404u;
+    x = (x ^ 0x03030303u) & ~((n >> 1) | (n >> 2));
+    return __builtin_bswap32(x);
+}
+// acc = 2 * acc + bit: one v_addc_co_u32 with the compare mask as carry-in
+__device__ __forceinline__ uint32_t shift_in(uint32_t acc, bool bit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long m = __ballot(bit);
+    unsigned long long co;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(co) : "v"(acc), "s"(m));
+#endif
+    return acc;
+}
+
+struct NarrowWalk {
+    const uint32_t *pl;                     // planes of this wave: word (plane, chunk, lane) at (plane * chunks + chunk) * 64 + lane
+    int chunks;
+    int lb;                                 // first lane of the group
+    int m, n, dlo;
+    __device__ __forceinline__ uint32_t word(int plane, int c, int lane) const { return pl[(plane * chunks + c) * 64 + lane]; }
+};
+// Traceback of one task by one lane.  Emits the runs in reverse (end -> start); with `out` they are written to
+// out[total-1 .. 0].  Returns the number of runs.  Every iteration consumes a row or a column or switches
+// from state 0 to a gap state, so 2 * (m + n) + 2 bounds the trip count; the cap only guards a corrupted plane.
+__device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total) {
+    int i = w.m, j = w.n, state = 0;
+    uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
+    auto emit = [&](uint32_t op, uint32_t len) {
+        if (op == cur_op) { cur_len += len; return; }
+        if (cur_len) { if (out) out[total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
+        cur_op = op; cur_len = len;
+    };
+    for (int it = 0; (i > 0 || j > 0) && it < 4 * (BLOCK_MAX + NARROW_W); ++it) {
+        if (i == 0) { emit(OP_D, (uint32_t)j); j = 0; break; }       // row 0: H(0,j) is a gap from the corner
+        const int d = w.lb + ((j - i - w.dlo) & (NARROW_W - 1));
+        const int c = (i - 1) >> 5, sh = 31 - ((i - 1) & 31);          // row i = bit sh of word c; row i-1 = bit sh+1
+        if (state == 0) {
+            const uint32_t inv = ~(w.word(PL_DIAG, c, d) >> sh);         // bit 0 = row i, bit 1 = row i-1, ... zeros above
+            const int r = inv ? __ffs((int)inv) - 1 : 32;              // diagonal moves in a row
+            if (r == 0) { state = ((w.word(PL_EGEF, c, d) >> sh) & 1u) ? 1 : 2; continue; }
+            uint32_t x = (w.word(PL_NE, c, d) >> sh) & (r == 32 ? 0xffffffffu : (1u << r) - 1u);
+            int done = 0;
+            while (x) {
+                const int p0 = __ffs((int)x) - 1;                      // next mismatch
+                if (p0 > done) emit(OP_EQ, (uint32_t)(p0 - done));
+                const uint32_t y = ~(x >> p0);
+                const int q = y ? __ffs((int)y) - 1 : 32;              // mismatches in a row
+                emit(OP_X, (uint32_t)q);
+                done = p0 + q;
+                x = done >= 32 ? 0u : x & ~((1u << done) - 1u);
+            }
+            if (r > done) emit(OP_EQ, (uint32_t)(r - done));
+            i -= r; j -= r;
+        } else if (state == 1) {
+            emit(OP_D, 1);
+            if (!((w.word(PL_EEXT, c, (d - 1) & 63) >> sh) & 1u)) state = 0;
+            --j;
+        } else {
+            emit(OP_I, 1);
+            bool ext = false;
+            if (i > 1) ext = (w.word(PL_FEXT, (i - 2) >> 5, (d + 1) & 63) >> (31 - ((i - 2) & 31))) & 1u;
+            if (!ext) state = 0;
+            --i;
+        }
+    }
+    if (cur_len) { if (out) out[total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
+    return n_runs;
+}
+
+template <bool AMBI, int NR_CHUNKS>
+__device__ __forceinline__ void narrow_rows(const AlignArgs &a, int rows, int m, int dlo, int l, const uint8_t *sq,
+                                            const uint8_t *st, uint32_t (*pl)[NR_CHUNKS][64], int lane, int &Hend) {
+    const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * l, goel = go + ge * l;
+    const int j0 = dlo + l;
+    int H = j0 == 0 ? 0 : (j0 > 0 ? -(go + ge * j0) : NEG_INF);       // row 0
+    int G = H - goe;                                                 // max(H - open - ext, F - ext) with F = -inf
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    const uint8_t *tp = st + NT_PAD + dlo + l - 1;                    // target base of row i: tp[i]
+    int qa = sq[0], t2 = tp[1];
+    for (int i = 1; i <= rows; ++i) {
+        const int qa_next = sq[i], t2_next = tp[i + 1];               // the next row's bases are in flight during this row
+        const bool ne = qa != t2;
+        int s = ne ? -a.mismatch : a.match;
+        if (AMBI) s = (qa | t2) > 3 ? -a.ambi : s;
+        const int mm = H + s;
+        const int f = row_shl1(G, NEG_INF);                           // from lane d+1 of the row above
+        const int ht = mm > f ? mm : f;
+        const int e = row_shr1(row_prefix_max_incl_dpp(ht + gel), NEG_INF * 2) - goel;
+        const int h = ht > e ? ht : e;
+        const int fo = h - goe, fe = f - ge;
+        a0 = shift_in(a0, mm == h);
+        a1 = shift_in(a1, e >= f);
+        a2 = shift_in(a2, e + go > h);
+        a3 = shift_in(a3, fe > fo);
+        a4 = shift_in(a4, ne);
+        G = fo > fe ? fo : fe;
+        H = h;
+        qa = qa_next; t2 = t2_next;
+        if (i == m) Hend = h;
+        if ((i & 31) == 0) {
+            const int c = (i >> 5) - 1;
+            pl[PL_DIAG][c][lane] = a0; pl[PL_EGEF][c][lane] = a1; pl[PL_EEXT][c][lane] = a2; pl[PL_FEXT][c][lane] = a3;
+            pl[PL_NE][c][lane] = a4;
+        }
+    }
+    if (rows & 31) {        // partial word: move its first row up to bit 31
+        const int c = rows >> 5, up = 32 - (rows & 31);
+        pl[PL_DIAG][c][lane] = a0 << up; pl[PL_EGEF][c][lane] = a1 << up; pl[PL_EEXT][c][lane] = a2 << up;
+        pl[PL_FEXT][c][lane] = a3 << up; pl[PL_NE][c][lane] = a4 << up;
+    }
+}
+
+template <int NR_MAX>
 __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
-    __shared__ unsigned long long s_tb[WAVES * 4][N_ROWS];
-    __shared__ uint8_t s_q[WAVES * 4][BLOCK_MAX];
-    __shared__ uint8_t s_t[WAVES * 4][N_T];
-    __shared__ uint8_t s_u[WAVES * 4][N_U];
+    constexpr int NR_CHUNKS = NR_MAX / 32, NQ_STEPS = NR_MAX / 64, NT_STEPS = NR_MAX / 64 + 1;
+    __shared__ uint32_t s_pl[WAVES][N_PLANES][NR_CHUNKS][64];
+    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES * 4][NR_MAX + 4];
+    __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES * 4][NR_MAX + NT_EXTRA];
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15, wv = threadIdx.x >> 6;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    unsigned long long *tb = s_tb[wv * 4 + g];
-    uint8_t *sq = s_q[wv * 4 + g], *st = s_t[wv * 4 + g], *su = s_u[wv * 4 + g];
+    uint32_t (*pl)[NR_CHUNKS][64] = s_pl[wv];
+    uint8_t *sq = s_q[wv * 4 + g], *st = s_t[wv * 4 + g];
     uint32_t chunk_off = 0, chunk_left = 0;
     const size_t n_quads = (a.n_list + 3) / 4;
     for (size_t qd = wave; qd < n_quads; qd += n_waves) {
@@ -463,97 +608,53 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         Task tk{};
         if (live) { ti = a.list[li]; tk = a.tasks[ti]; }
         const int m = tk.m, n = tk.n, dlo = tk.dlo;
-        if (live) {
+        bool ambig = false;
+        if (live) {     // stage the two windows, 4 bases per lane and step (all loads in flight together)
             const Piece pc = a.pieces[tk.piece];
-            const uint8_t *qb = a.qcodes + a.qoff[pc.q];
-            const uint8_t *tbs = a.tcodes + a.toff[pc.t] + tk.t0;
+            const long long qo = (long long)a.qoff[pc.q], to = (long long)a.toff[pc.t] + tk.t0;
             const int ql = (int)a.qlen[pc.q];
-            for (int x = l; x < m; x += 16) sq[x] = load_q(a, pc, qb, ql, tk.q0 + x);
-            for (int x = l; x < n; x += 16) st[x] = tbs[x];
+            uint32_t vq[NQ_STEPS], vt[NT_STEPS];
+#pragma unroll
+            for (int r = 0; r < NQ_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                vq[r] = 0;
+                if (x < m)
+                    vq[r] = pc.strand ? revcomp_codes4(load_codes4(a.qcodes, qo + ql - 4 - (tk.q0 + x), a.q_total))
+                                      : load_codes4(a.qcodes, qo + tk.q0 + x, a.q_total);
+            }
+#pragma unroll
+            for (int r = 0; r < NT_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                vt[r] = 0;
+                if (x < n) vt[r] = load_codes4(a.tcodes, to + x, a.t_total);
+            }
+#pragma unroll
+            for (int r = 0; r < NQ_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                if (x < m) { *(uint32_t *)(sq + x) = vq[r]; ambig |= (vq[r] & 0x04040404u) != 0; }
+            }
+#pragma unroll
+            for (int r = 0; r < NT_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                if (x < n) { *(uint32_t *)(st + NT_PAD + x) = vt[r]; ambig |= (vt[r] & 0x04040404u) != 0; }
+            }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const int rows = (int)wave_max_u32_dpp(live ? (uint32_t)m : 0u);
-        const int go = a.go, ge = a.ge;
-        int Hp = NEG_INF, Fp = NEG_INF, Hend = NEG_INF;
-        for (int i = 0; i <= rows; ++i) {
-            const bool on = live && i <= m;
-            const int j = i + dlo + l;
-            const bool valid = on && j >= 0 && j <= n;
-            const int Hup = row_shl1(Hp, NEG_INF), Fup = row_shl1(Fp, NEG_INF);
-            int mm = NEG_INF, f = NEG_INF;
-            bool flagF = false;
-            if (valid && i > 0) {
-                if (j > 0) {
-                    const int qa = sq[i - 1], t2 = st[j - 1];
-                    mm = Hp + ((qa > 3 || t2 > 3) ? -a.ambi : (qa == t2 ? a.match : -a.mismatch));
-                }
-                if (l < 15) {
-                    const int fo = Hup - go - ge, fe = Fup - ge;
-                    if (fo >= fe) f = fo; else { f = fe; flagF = true; }
-                }
-            }
-            int ht = mm > f ? mm : f;
-            if (i == 0 && j == 0) ht = 0;
-            if (!valid) ht = NEG_INF;
-            const int pm = row_shr1(row_prefix_max_incl_dpp(ht + ge * l), NEG_INF * 2);
-            int e = NEG_INF;
-            if (valid && j > 0 && l > 0) e = pm - go - ge * l;
-            int h, src;
-            if (i == 0 && j == 0) { h = 0; src = 0; }
-            else if (mm >= e && mm >= f) { h = mm; src = 0; }
-            else if (e >= f) { h = e; src = 1; }
-            else { h = f; src = 2; }
-            if (!valid) { h = NEG_INF; f = NEG_INF; e = NEG_INF; }
-            const int Hl = row_shr1(h, NEG_INF), El = row_shr1(e, NEG_INF);
-            const bool flagE = l > 0 && !(Hl - go - ge >= El - ge);
-            const unsigned long long b0 = __ballot(src & 1), b1 = __ballot(src & 2), b2 = __ballot(flagE), b3 = __ballot(flagF);
-            if (on && l == 0) {
-                const int sh = 16 * g;
-                tb[i] = ((b0 >> sh) & 0xffffull) | ((b1 >> sh) & 0xffffull) << 16 | ((b2 >> sh) & 0xffffull) << 32 |
-                        ((b3 >> sh) & 0xffffull) << 48;
-            }
-            if (on) { Hp = h; Fp = f; if (i == m) Hend = h; }
-        }
-        const int score = __shfl(Hend, g * 16 + (n - m - dlo), 64);
+        int Hend = NEG_INF;
+        if (__any(ambig)) narrow_rows<true, NR_CHUNKS>(a, rows, m, dlo, l, sq, st, pl, lane, Hend);
+        else narrow_rows<false, NR_CHUNKS>(a, rows, m, dlo, l, sq, st, pl, lane, Hend);
+        const int score = __shfl(Hend, g * 16 + ((n - m - dlo) & (NARROW_W - 1)), 64);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         if (live && l == 0) {
-            int i = m, j = n, state = 0, nr = 0;
-            while (i > 0 || j > 0) {
-                const unsigned long long w = tb[i] >> (j - i - dlo);
-                if (state == 0) {
-                    const int src = (int)(w & 1) | (int)((w >> 16) & 1) << 1;
-                    if (src == 0) {
-                        su[nr++] = sq[i - 1] == st[j - 1] ? (uint8_t)OP_EQ : (uint8_t)OP_X;
-                        --i; --j;
-                    } else state = src;
-                } else if (state == 1) {
-                    su[nr++] = (uint8_t)OP_D;
-                    if (!((w >> 32) & 1)) state = 0;
-                    --j;
-                } else {
-                    su[nr++] = (uint8_t)OP_I;
-                    if (!((w >> 48) & 1)) state = 0;
-                    --i;
-                }
-            }
-            uint32_t n_runs = 0;
-            for (int x = 0; x < nr; ++x) if (x == 0 || su[nr - 1 - x] != su[nr - x]) ++n_runs;
+            const NarrowWalk w{&pl[0][0][0], NR_CHUNKS, g * 16, m, n, dlo};
+            const uint32_t n_runs = narrow_walk(w, nullptr, 0);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
-            if (ok && n_runs) {
-                uint32_t w = off, len = 0;
-                uint8_t code = 0;
-                for (int x = 0; x < nr; ++x) {
-                    const uint8_t c = su[nr - 1 - x];
-                    if (x && c != code) { a.runs[w++] = len << 4 | code; len = 0; }
-                    code = c;
-                    ++len;
-                }
-                a.runs[w++] = len << 4 | code;
-            }
+            if (ok && n_runs) narrow_walk(w, a.runs + off, n_runs);
             a.out[ti] = TaskOut{score, m, n, off, ok ? n_runs : 0, 2u | (uint32_t)m << 2};
         }
         __builtin_amdgcn_wave_barrier();
@@ -680,6 +781,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.tasks = tasks.p; aa.n_tasks = NT; aa.pieces = ch.pieces.p;
         aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p; aa.qoff = in.Q->off.p; aa.toff = in.T->off.p;
         aa.qlen = d_qlen;
+        aa.q_total = (long long)in.Q->total; aa.t_total = (long long)in.T->total;
         aa.end_bonus = o.end_bonus;
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
         {   // largest k with k*(match+mismatch) < match + 2*(open+ext), capped at 3 (7 runs)
@@ -689,23 +791,30 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         }
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         // pass 1: classify every task, finish the diagonal fast path right away
-        DBuf<uint8_t> cls(NT), f1(NT), f2(NT);
+        DBuf<uint8_t> cls(NT), f1(NT), f2(NT), f3(NT);
         struct KeepCls { DBuf<uint8_t> *dst; DBuf<uint8_t> *src; ~KeepCls() { *dst = std::move(*src); } } keep{&cls_keep, &cls};
         {
             KTimer kt("align_classify");
             const unsigned nbc = (unsigned)std::min<size_t>((NT + 15) / 16, 256 * 16);
             hipLaunchKernelGGL(classify_kernel, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p);
         }
-        hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p);
+        hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p, f3.p);
         HIP_CHECK(hipGetLastError());
-        DBuf<uint32_t> list1(NT), list2(NT);
-        const size_t n1 = select_flagged_indices(f1.p, list1.p, NT), n2 = select_flagged_indices(f2.p, list2.p, NT);
+        DBuf<uint32_t> list1(NT), list2(NT), list3(NT);
+        const size_t n1 = select_flagged_indices(f1.p, list1.p, NT), n2 = select_flagged_indices(f2.p, list2.p, NT),
+                     n3 = select_flagged_indices(f3.p, list3.p, NT);
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
         if (n1) {
             KTimer kt("align_narrow");
             aa.list = list1.p; aa.n_list = n1;
             const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
-            hipLaunchKernelGGL(align_narrow_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+            hipLaunchKernelGGL(align_narrow_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+        }
+        if (n3) {
+            KTimer kt("align_narrow_long");
+            aa.list = list3.p; aa.n_list = n3;
+            const unsigned nb = (unsigned)std::min<size_t>(((n3 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
+            hipLaunchKernelGGL(align_narrow_kernel<BLOCK_MAX>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
         // pass 2b: the rest (wide blocks, end extensions) in the 64-diagonal band
         if (n2) {
@@ -714,7 +823,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             const unsigned nb = (unsigned)std::min<size_t>((n2 + WAVES - 1) / WAVES, 256 * 16);
             hipLaunchKernelGGL(align_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
-        if (attempt == 0) { stat_add("align_tasks_narrow", (double)n1); stat_add("align_tasks_wide", (double)n2); }
+        if (attempt == 0) { stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)n2); }
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> hc = counters.download(2);
         if (!hc[1]) break;
