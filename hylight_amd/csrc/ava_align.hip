@@ -30,14 +30,16 @@ constexpr int NR_SHORT = 128;                   // rows of an align_narrow_kerne
                                                 // blocks (3-4 % of them) run in the <BLOCK_MAX> instance with twice the LDS
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 
-struct Task {               // 32 B
+struct Task {               // 32 B, self-contained: the kernels reach the bases without touching Piece / offset tables
     uint32_t piece;
-    uint32_t kind;          // 0 block, 1 left extension, 2 right extension
-    int32_t q0, t0;         // block: start fixed point; extensions: the fixed point extended from
-    int32_t m, n;           // rows (query), cols (target)
-    int32_t dlo;            // first diagonal of the band
-    uint32_t narrow;        // 1: 16-diagonal band (block with |delta| <= NARROW_DELTA), 0: 64 diagonals
+    uint16_t kind;          // 0 block, 1 left extension, 2 right extension; bit 2: query on the reverse strand
+    uint16_t narrow;        // block: 1 = 16-diagonal band; extensions: (row that reaches the query end + 1) << 1, 0 = out of reach
+    uint64_t qa, ta;        // offsets in qcodes / tcodes of window element 0 (see load_window4 for the directions)
+    int16_t m, n;           // rows (query), cols (target)
+    int16_t dlo;            // first diagonal of the band
+    int16_t pad;
 };
+constexpr uint16_t TASK_REV = 4;
 struct TaskOut {            // 24 B
     int32_t score;
     int32_t bi, bj;         // extension: rows / cols consumed
@@ -50,19 +52,26 @@ __global__ void piece_task_count_kernel(const Piece *pieces, size_t n, uint32_t 
     if (i < n) cnt[i] = pieces[i].n_fp + 1;      // (n_fp - 1) blocks + 2 extensions
 }
 
+// Window element x of a task: query = qcodes[qa + x] (complemented and read downwards, qcodes[qa - x], when exactly one
+// of "left extension" and "reverse strand" holds; complemented whenever the strand is reverse); target =
+// tcodes[ta + x], downwards for a left extension.
 __global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const uint32_t *task_off, size_t n,
-                                  const uint32_t *qlen, const uint32_t *tlen, Task *tasks) {
+                                  const uint32_t *qlen, const uint32_t *tlen, const uint64_t *qoff, const uint64_t *toff,
+                                  Task *tasks) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Piece p = pieces[i];
     Task *out = tasks + task_off[i];
     const FixPt *fp = fps + p.fp_off;
     const int ql = (int)qlen[p.q], tl = (int)tlen[p.t];
-    {   // left extension
+    const uint64_t qo = qoff[p.q], to = toff[p.t];
+    const uint16_t rev = p.strand ? TASK_REV : 0;
+    // aligned query position pos -> offset in qcodes
+    auto qaddr = [&](int pos) { return p.strand ? qo + (uint64_t)(ql - 1 - pos) : qo + (uint64_t)pos; };
+    {   // left extension: elements run downwards from the fixed point
         const int qs = (int)fp[0].q, ts = (int)fp[0].t;
-        // extensions: bits 1.. of `narrow` = (row that reaches the query end) + 1, 0 when it is out of reach
-        Task t{(uint32_t)i, 1u, qs, ts, qs < EXT_MAX ? qs : EXT_MAX, ts < SEQ_T_MAX ? ts : SEQ_T_MAX, -(BAND_W / 2 - 1),
-               qs <= EXT_MAX ? (uint32_t)(qs + 1) << 1 : 0u};
+        Task t{(uint32_t)i, (uint16_t)(1u | rev), (uint16_t)(qs <= EXT_MAX ? (qs + 1) << 1 : 0), qaddr(qs - 1), to + (uint64_t)(ts - 1),
+               (int16_t)(qs < EXT_MAX ? qs : EXT_MAX), (int16_t)(ts < SEQ_T_MAX ? ts : SEQ_T_MAX), (int16_t)(-(BAND_W / 2 - 1)), 0};
         out[0] = t;
     }
     for (uint32_t b = 0; b + 1 < p.n_fp; ++b) {
@@ -70,48 +79,25 @@ __global__ void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const u
         const int delta = n2 - m;
         // band rule: near-diagonal blocks use the 16-diagonal band
         const bool narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
-        Task t{(uint32_t)i, 0u, q0, t0, m, n2, (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD), narrow ? 1u : 0u};
+        Task t{(uint32_t)i, rev, (uint16_t)(narrow ? 1 : 0), qaddr(q0), to + (uint64_t)t0, (int16_t)m, (int16_t)n2,
+               (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD)), 0};
         out[1 + b] = t;
     }
     {   // right extension
         const int qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
         const int m = ql - qe < EXT_MAX ? ql - qe : EXT_MAX, n2 = tl - te < SEQ_T_MAX ? tl - te : SEQ_T_MAX;
-        Task t{(uint32_t)i, 2u, qe, te, m, n2, -(BAND_W / 2 - 1), ql - qe <= EXT_MAX ? (uint32_t)(ql - qe + 1) << 1 : 0u};
+        Task t{(uint32_t)i, (uint16_t)(2u | rev), (uint16_t)(ql - qe <= EXT_MAX ? (ql - qe + 1) << 1 : 0), qaddr(qe), to + (uint64_t)te,
+               (int16_t)m, (int16_t)n2, (int16_t)(-(BAND_W / 2 - 1)), 0};
         out[p.n_fp] = t;
     }
 }
-
-// bases (Lq + Lt) per pass: [0] all tasks, [1] square blocks the classify pass compares, [2] narrow DP, [3] wide DP
-__global__ void task_bases_kernel(const Task *tasks, const uint8_t *cls, size_t n, unsigned long long *sum) {
-    unsigned long long v[4] = {0, 0, 0, 0};
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        if (tasks[i].m <= 0 || tasks[i].n <= 0) continue;
-        const unsigned long long b = (unsigned long long)(tasks[i].m + tasks[i].n);
-        v[0] += b;
-        if (tasks[i].kind == 0 && tasks[i].m == tasks[i].n) v[1] += b;
-        if (cls[i] == 1 || cls[i] == 3) v[2] += b;
-        if (cls[i] == 2) v[3] += b;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
-        if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(&sum[k], v[k]);
-    }
-}
-
-struct TaskOut;
-__global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long long *acc);
 
 struct AlignArgs {
     const Task *tasks;
     size_t n_tasks;
     const uint32_t *list;   // task ids this launch works on (n_list of them)
     size_t n_list;
-    const Piece *pieces;
     const uint8_t *qcodes, *tcodes;
-    const uint64_t *qoff, *toff;
-    const uint32_t *qlen;
     long long q_total, t_total;   // bytes in qcodes / tcodes (4-base loads stay inside)
     int match, mismatch, go, ge, ambi;
     int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
@@ -133,11 +119,23 @@ __device__ __forceinline__ int wave_prefix_max_excl(int v, int lane) {
     return lane == 0 ? NEG_INF * 2 : r;
 }
 
+// exclusive prefix sum over the wave; total = sum of all lanes
+__device__ __forceinline__ uint32_t wave_excl_sum_u32(uint32_t v, int lane, uint32_t &total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)x, o, 64);
+        if (lane >= o) x += u;
+    }
+    total = (uint32_t)__shfl((int)x, 63, 64);
+    return x - v;
+}
+
 // CIGAR-run pool: a wave reserves RUN_CHUNK entries with ONE global atomic and hands them out locally
 // (a single contended counter word saturates near 90 M atomics/s - more than 100 M tasks per step would
 // serialise on it).  Only lane 0 allocates.
 constexpr uint32_t RUN_CHUNK = 4096;
-constexpr uint32_t RUN_CHUNK_SMALL = 256;       // per 16-lane group leader (classify / narrow kernels)
+constexpr uint32_t RUN_CHUNK_SMALL = 256;       // per 16-lane group leader (narrow kernels)
 __device__ __forceinline__ uint32_t pool_take(const AlignArgs &a, uint32_t n, uint32_t &chunk_off, uint32_t &chunk_left,
                                               bool &ok, uint32_t chunk = RUN_CHUNK) {
     if (n > chunk_left) {
@@ -152,10 +150,33 @@ __device__ __forceinline__ uint32_t pool_take(const AlignArgs &a, uint32_t n, ui
     return off;
 }
 
+// 4 codes at base[idx .. idx+3] (little endian); bytes outside [0, total) read as 4
+__device__ __forceinline__ uint32_t load_codes4(const uint8_t *base, long long idx, long long total) {
+    if (idx >= 0 && idx + 4 <= total) {
+        uint32_t v;
+        __builtin_memcpy(&v, base + idx, 4);
+        return v;
+    }
+    uint32_t v = 0;
+    for (int k = 0; k < 4; ++k) v |= (uint32_t)(idx + k >= 0 && idx + k < total ? base[idx + k] : 4) << (8 * k);
+    return v;
+}
+// complement of 4 packed codes (3 - c for ACGT, 4 stays 4)
+__device__ __forceinline__ uint32_t comp_codes4(uint32_t x) {
+    const uint32_t n = x & 0x04040404u;
+    return (x ^ 0x03030303u) & ~((n >> 1) | (n >> 2));
+}
+// window elements x .. x+3 (byte 0 = element x) of a sequence whose element 0 sits at offset a0
+__device__ __forceinline__ uint32_t load_window4(const uint8_t *codes, long long total, long long a0, bool down, bool comp, int x) {
+    uint32_t v = down ? __builtin_bswap32(load_codes4(codes, a0 - x - 3, total)) : load_codes4(codes, a0 + x, total);
+    if (comp) v = comp_codes4(v);
+    return v;
+}
+
 __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     __shared__ unsigned long long s_tb[WAVES][TB_ROWS][4];
-    __shared__ uint8_t s_q[WAVES][EXT_MAX];
-    __shared__ uint8_t s_t[WAVES][SEQ_T_MAX];
+    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][EXT_MAX];
+    __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][SEQ_T_MAX];
     __shared__ uint8_t s_u[WAVES][UNIT_MAX];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
@@ -175,69 +196,25 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             if (lane == 0) a.out[ti] = res;
             continue;
         }
-        const Piece pc = a.pieces[tk.piece];
-        const uint8_t *qb = a.qcodes + a.qoff[pc.q];
-        const uint8_t *tbs = a.tcodes + a.toff[pc.t];
-        const int ql = (int)a.qlen[pc.q];
-        // ---- stage the two windows in LDS (aligned orientation, DP order) ---------------------------------
-        for (int x = lane; x < m; x += 64) {
-            const int pos = tk.kind == 1 ? tk.q0 - 1 - x : tk.q0 + x;       // aligned-orientation index
-            uint8_t c;
-            if (pc.strand) { c = qb[ql - 1 - pos]; c = c < 4 ? 3 - c : 4; } else c = qb[pos];
-            sq[x] = c;
+        // ---- stage the two windows in LDS (DP order), 4 bases per lane and step ----------------------------------
+        {
+            const bool rev = (tk.kind & TASK_REV) != 0, left = (tk.kind & 3) == 1;
+            uint32_t vq = 0, vt[2] = {0, 0};
+            if (4 * lane < m) vq = load_window4(a.qcodes, a.q_total, (long long)tk.qa, left != rev, rev, 4 * lane);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (4 * (lane + 64 * r) < n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)tk.ta, left, false, 4 * (lane + 64 * r));
+            if (4 * lane < m) *(uint32_t *)(sq + 4 * lane) = vq;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (4 * (lane + 64 * r) < n) *(uint32_t *)(st + 4 * (lane + 64 * r)) = vt[r];
         }
-        for (int x = lane; x < n; x += 64) st[x] = tbs[tk.kind == 1 ? tk.t0 - 1 - x : tk.t0 + x];
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // ---- fast path: square block, no ambiguous base, at most kmax substitutions ---------------------------
-        // With delta = 0 any gapped path has >= 1 insertion and >= 1 deletion and <= m-1 diagonal moves, i.e.
-        // scores <= match*(m-1) - 2*(open+ext); the all-diagonal path with k mismatches scores
-        // match*(m-k) - mismatch*k, which is strictly larger while k*(match+mismatch) < match + 2*(open+ext).
-        // It is then the unique optimum, so the DP + traceback would return exactly these runs.
-        if (tk.kind == 0 && m == n) {
-            unsigned long long mis[4] = {0, 0, 0, 0};
-            bool ambig = false;
-            int k = 0;
-            for (int c = 0; c * 64 < m; ++c) {
-                const int x = c * 64 + lane;
-                bool ne = false;
-                if (x < m) { const uint8_t qa = sq[x], tb2 = st[x]; ne = qa != tb2; ambig |= (qa > 3 || tb2 > 3); }
-                mis[c] = __ballot(ne);
-                k += __popcll(mis[c]);
-            }
-            if (!__any(ambig) && k <= a.kmax) {
-                if (lane == 0) {
-                    uint32_t runs[8];
-                    uint32_t nr = 0;
-                    int prev = 0;                         // start of the pending '=' run
-                    int xrun_start = -1, xrun_end = -1;   // pending X run [start, end)
-                    for (int c = 0; c * 64 < m; ++c) {
-                        unsigned long long bits = mis[c];
-                        while (bits) {
-                            const int x = c * 64 + __ffsll((long long)bits) - 1;
-                            bits &= bits - 1;
-                            if (x == xrun_end) { xrun_end = x + 1; continue; }      // adjacent mismatch extends the X run
-                            if (xrun_start >= 0) { runs[nr++] = (uint32_t)(xrun_end - xrun_start) << 4 | OP_X; prev = xrun_end; }
-                            if (x > prev) runs[nr++] = (uint32_t)(x - prev) << 4 | OP_EQ;
-                            xrun_start = x; xrun_end = x + 1;
-                        }
-                    }
-                    if (xrun_start >= 0) { runs[nr++] = (uint32_t)(xrun_end - xrun_start) << 4 | OP_X; prev = xrun_end; }
-                    if (m > prev) runs[nr++] = (uint32_t)(m - prev) << 4 | OP_EQ;
-                    bool ok = true;
-                    const uint32_t off = pool_take(a, nr, chunk_off, chunk_left, ok);
-                    if (ok) for (uint32_t r = 0; r < nr; ++r) a.runs[off + r] = runs[r];
-                    res.score = a.match * (m - k) - a.mismatch * k;
-                    res.bi = m; res.bj = n; res.runs_off = off; res.n_runs = ok ? nr : 0; res.pad = 1;
-                    a.out[ti] = res;
-                }
-                __builtin_amdgcn_wave_barrier();
-                continue;
-            }
-        }
         // ---- DP ------------------------------------------------------------------------------------------------
         const int dlo = tk.dlo, go = a.go, ge = a.ge;
-        const int end_row = tk.kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
+        const int kind = tk.kind & 3;
+        const int end_row = kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
         int Hp = NEG_INF, Fp = NEG_INF;
         unsigned long long best = 0;
         for (int i = 0; i <= m; ++i) {
@@ -273,7 +250,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             const bool flagE = lane > 0 && !(Hl - go - ge >= El - ge);
             const unsigned long long b0 = __ballot(src & 1), b1 = __ballot(src & 2), b2 = __ballot(flagE), b3 = __ballot(flagF);
             if (lane == 0) { tb[i][0] = b0; tb[i][1] = b1; tb[i][2] = b2; tb[i][3] = b3; }
-            if (tk.kind != 0 && valid && h > NEG_INF / 2) {
+            if (kind != 0 && valid && h > NEG_INF / 2) {
                 // cells in the row that reaches the query end are ranked with the end bonus (ksw2 --end-bonus)
                 const int hb = h + (i == end_row ? a.end_bonus : 0);
                 const unsigned long long key = (unsigned long long)(uint32_t)(hb + (1 << 20)) << 32 |
@@ -285,7 +262,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             Fp = f;
         }
         int ei, ej, score;
-        if (tk.kind == 0) {
+        if (kind == 0) {
             ei = m; ej = n;
             score = __shfl(Hp, n - m - dlo, 64);
         } else {
@@ -323,7 +300,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
                 }
             }
             // forward order: blocks and right extensions reverse the emission order, left extensions keep it
-            const bool fwd = tk.kind == 1;
+            const bool fwd = kind == 1;
             uint32_t n_runs = 0;
             for (int x = 0; x < nr; ++x) {
                 const int y = fwd ? x : nr - 1 - x, yp = fwd ? x - 1 : nr - x;
@@ -343,30 +320,59 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
                 }
                 a.runs[w++] = len << 4 | code;
             }
-            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0; res.pad = 2u | ((uint32_t)m & 0xfffffu) << 2 | (tk.kind != 0 && ei == end_row ? 0x80000000u : 0u);
+            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0; res.pad = 2u | ((uint32_t)m & 0xfffffu) << 2 | (kind != 0 && ei == end_row ? 0x80000000u : 0u);
             a.out[ti] = res;
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// ---- pass 1: classification + diagonal fast path, one 16-lane group per task --------------------------------
+// ---- pass 1: classification + diagonal fast path, one lane per task --------------------------------
 // cls[task] = 0 done here (empty task or fast path), 1 / 3 DP in the 16-diagonal band (<= / > NR_SHORT rows),
-// 2 DP in the 64-diagonal band
-__device__ __forceinline__ uint8_t load_q(const AlignArgs &a, const Piece &pc, const uint8_t *qb, int ql, int pos) {
-    uint8_t c;
-    if (pc.strand) { c = qb[ql - 1 - pos]; c = c < 4 ? 3 - c : 4; } else c = qb[pos];
-    return c;
+// 2 DP in the 64-diagonal band.
+// Fast path: square block, no ambiguous base, at most kmax substitutions.  With delta = 0 any gapped path has
+// >= 1 insertion and >= 1 deletion and <= m-1 diagonal moves, i.e. scores <= match*(m-1) - 2*(open+ext); the
+// all-diagonal path with k mismatches scores match*(m-k) - mismatch*k, which is strictly larger while
+// k*(match+mismatch) < match + 2*(open+ext).  It is then the unique optimum, so the DP + traceback would return
+// exactly these runs.
+
+// stats[]: 0 bases (Lq + Lt) of all tasks, 1 of the square blocks compared here, 2 of the narrow DP tasks, 3 of the
+// wide DP tasks, 4 tasks finished on the diagonal fast path, 5 DP tasks, 6 DP rows
+enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, N_ALIGN_STATS };
+
+// 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
+__device__ __forceinline__ uint64_t load_codes8(const uint8_t *base, long long idx, long long total) {
+    if (idx >= 0 && idx + 8 <= total) {
+        uint64_t v;
+        __builtin_memcpy(&v, base + idx, 8);
+        return v;
+    }
+    uint64_t v = 0;
+    for (int k = 0; k < 8; ++k) v |= (uint64_t)(idx + k >= 0 && idx + k < total ? base[idx + k] : 4) << (8 * k);
+    return v;
+}
+__device__ __forceinline__ uint64_t load_window8(const uint8_t *codes, long long total, long long a0, bool down, bool comp, int x) {
+    uint64_t v = down ? __builtin_bswap64(load_codes8(codes, a0 - x - 7, total)) : load_codes8(codes, a0 + x, total);
+    if (comp) {
+        const uint64_t n = v & 0x0404040404040404ull;
+        v = (v ^ 0x0303030303030303ull) & ~((n >> 1) | (n >> 2));
+    }
+    return v;
 }
 
-__global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
-    const size_t grp = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4;
-    const size_t n_grp = ((size_t)gridDim.x * blockDim.x) >> 4;
+// One lane per task: a square block is compared 8 bases at a time and given up at the third mismatch (kmax <= 3
+// would still pass with 3), so the typical task costs 8-9 iterations of two 8-byte loads; the runs of the tasks
+// that finish here are allocated with one pool request per wave.
+__global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls, unsigned long long *stats) {
+    __shared__ unsigned long long s_stat[WAVES][N_ALIGN_STATS];
+    const int lane = threadIdx.x & 63;
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
-    const size_t rounds = (a.n_tasks + n_grp - 1) / n_grp;            // uniform trip count: ballots need every lane
+    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0};      // < 2^32 per thread by far
+    const size_t rounds = (a.n_tasks + n_thr - 1) / n_thr;            // uniform trip count: the allocation is per wave
     for (size_t r = 0; r < rounds; ++r) {
-        const size_t ti = r * n_grp + grp;
+        const size_t ti = r * n_thr + tid;
         const bool live = ti < a.n_tasks;
         Task tk{};
         if (live) tk = a.tasks[ti];
@@ -375,66 +381,95 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls)
         bool try_fast = false;
         if (live) {
             if (m <= 0 || n <= 0) c = 0;
-            else if (tk.kind == 0) { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
+            else if ((tk.kind & 3) == 0) { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
         }
-        // mismatch positions of square blocks, 16 bases per step; stop as soon as a group has too many
-        int k = 0, mpos[4] = {0, 0, 0, 0};
+        int k = 0, mpos[3] = {0, 0, 0};
         bool ambig = false;
-        const uint8_t *qb = nullptr, *tb = nullptr;
-        Piece pc{};
-        int ql = 0;
         if (try_fast) {
-            pc = a.pieces[tk.piece];
-            qb = a.qcodes + a.qoff[pc.q];
-            tb = a.tcodes + a.toff[pc.t] + tk.t0;
-            ql = (int)a.qlen[pc.q];
-        }
-        int steps = try_fast ? (m + 15) >> 4 : 0;
-        steps = (int)wave_max_u32_dpp((uint32_t)steps);
-        for (int s = 0; s < steps; ++s) {
-            const int x = s * 16 + l;
-            bool ne = false;
-            if (try_fast && x < m && k <= a.kmax && !ambig) {
-                const uint8_t qa = load_q(a, pc, qb, ql, tk.q0 + x), t2 = tb[x];
-                ne = qa != t2;
-                ambig = qa > 3 || t2 > 3;
-            }
-            const unsigned long long bm = __ballot(ne), am = __ballot(ambig);
-            uint32_t bits = (uint32_t)(bm >> (16 * g)) & 0xffffu;
-            if ((am >> (16 * g)) & 0xffffull) ambig = true;
-            while (bits) {
-                const int b = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                if (k < 4) mpos[k] = s * 16 + b;
-                ++k;
-            }
-        }
-        if (try_fast && !ambig && k <= a.kmax) {
-            c = 0;
-            if (l == 0) {
-                uint32_t runs[8];
-                uint32_t nr = 0;
-                int prev = 0, xs = -1, xe = -1;
-                for (int i = 0; i < k; ++i) {
-                    const int x = mpos[i];
-                    if (x == xe) { xe = x + 1; continue; }
-                    if (xs >= 0) { runs[nr++] = (uint32_t)(xe - xs) << 4 | OP_X; prev = xe; }
-                    if (x > prev) runs[nr++] = (uint32_t)(x - prev) << 4 | OP_EQ;
-                    xs = x; xe = x + 1;
+            const bool rev = (tk.kind & TASK_REV) != 0;
+            for (int x = 0; x < m && k <= a.kmax && !ambig; x += 8) {
+                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
+                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
+                const int left = m - x;                        // bases of this step inside the block (>= 1)
+                const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
+                uint64_t d = (q8 ^ t8) & keep;
+                ambig = ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
+                d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;      // codes are 0..4: three bits
+                while (d) {
+                    const int y = (__ffsll((long long)d) - 1) >> 3;
+                    d &= d - 1;
+                    if (k < 3) mpos[k] = x + y;
+                    ++k;
                 }
-                if (xs >= 0) { runs[nr++] = (uint32_t)(xe - xs) << 4 | OP_X; prev = xe; }
-                if (m > prev) runs[nr++] = (uint32_t)(m - prev) << 4 | OP_EQ;
-                bool ok = true;
-                const uint32_t off = pool_take(a, nr, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
-                if (ok) for (uint32_t q = 0; q < nr; ++q) a.runs[off + q] = runs[q];
-                TaskOut res{a.match * (m - k) - a.mismatch * k, m, n, off, ok ? nr : 0, 1};
-                a.out[ti] = res;
             }
-        } else if (live && c == 0 && l == 0) {
+        }
+        const bool fast = try_fast && !ambig && k <= a.kmax;
+        uint32_t runs[7];
+        uint32_t nr = 0;
+        if (fast) {
+            c = 0;
+            int prev = 0, xs = -1, xe = -1;
+            for (int i = 0; i < k; ++i) {
+                const int x = mpos[i];
+                if (x == xe) { xe = x + 1; continue; }
+                if (xs >= 0) { runs[nr++] = (uint32_t)(xe - xs) << 4 | OP_X; prev = xe; }
+                if (x > prev) runs[nr++] = (uint32_t)(x - prev) << 4 | OP_EQ;
+                xs = x; xe = x + 1;
+            }
+            if (xs >= 0) { runs[nr++] = (uint32_t)(xe - xs) << 4 | OP_X; prev = xe; }
+            if (m > prev) runs[nr++] = (uint32_t)(m - prev) << 4 | OP_EQ;
+        }
+        uint32_t wave_total;
+        const uint32_t mine = wave_excl_sum_u32(nr, lane, wave_total);
+        uint32_t base = 0;
+        bool ok = true;
+        if (wave_total) {
+            if (lane == 0) base = pool_take(a, wave_total, chunk_off, chunk_left, ok);
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            ok = __shfl((int)ok, 0, 64) != 0;
+        }
+        if (fast) {
+            if (ok) for (uint32_t q = 0; q < nr; ++q) a.runs[base + mine + q] = runs[q];
+            a.out[ti] = TaskOut{a.match * (m - k) - a.mismatch * k, m, n, base + mine, ok ? nr : 0, 1};
+        } else if (live && c == 0) {
             a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
         }
-        if (live && l == 0) cls[ti] = c;
+        if (live) {
+            cls[ti] = c;
+            if (m > 0 && n > 0) {
+                const uint32_t bases = (uint32_t)(m + n);
+                st[ST_BASES] += bases;
+                if ((tk.kind & 3) == 0 && m == n) st[ST_BASES_SQUARE] += bases;
+                if (c == 0) ++st[ST_FAST];
+                else {
+                    ++st[ST_DP];
+                    if (c == 2) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
+                    else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m; }
+                }
+            }
+        }
     }
+    // counters: wave sum -> block sum -> one atomic per block and counter
+#pragma unroll
+    for (int k = 0; k < N_ALIGN_STATS; ++k) {
+        unsigned long long v = st[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_stat[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N_ALIGN_STATS) {
+        unsigned long long v = 0;
+        for (int w = 0; w < WAVES; ++w) v += s_stat[w][threadIdx.x];
+        if (v) atomicAdd(&stats[threadIdx.x], v);
+    }
+}
+
+// sort key of a DP task list: rows / 4, so the four tasks of a wave of align_narrow_kernel run about equally long
+// (the sort is stable: inside a bucket the tasks keep their order, neighbours in the reads stay neighbours)
+__global__ void task_rows_key_kernel(const Task *tasks, const uint32_t *list, size_t n, uint32_t *key) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) key[i] = (uint32_t)tasks[list[i]].m >> 2;
 }
 
 __global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, uint8_t *f2, uint8_t *f3) {
@@ -463,23 +498,6 @@ constexpr int NT_PAD = 16;                   // st index of target offset 0
 constexpr int NT_EXTRA = NT_PAD + NARROW_DELTA + NARROW_W + 7;     // st length = rows + NT_EXTRA
 enum { PL_DIAG = 0, PL_EGEF, PL_EEXT, PL_FEXT, PL_NE, N_PLANES };
 
-// 4 codes at base[idx .. idx+3] (little endian); bytes outside [0, total) read as 4
-__device__ __forceinline__ uint32_t load_codes4(const uint8_t *base, long long idx, long long total) {
-    if (idx >= 0 && idx + 4 <= total) {
-        uint32_t v;
-        __builtin_memcpy(&v, base + idx, 4);
-        return v;
-    }
-    uint32_t v = 0;
-    for (int k = 0; k < 4; ++k) v |= (uint32_t)(idx + k >= 0 && idx + k < total ? base[idx + k] : 4) << (8 * k);
-    return v;
-}
-// reverse complement of 4 packed codes (3 - c for ACGT, 4 stays 4), byte order reversed
-__device__ __forceinline__ uint32_t revcomp_codes4(uint32_t x) {
-    const uint32_t n = x & 0x04040404u;
-    x = (x ^ 0x03030303u) & ~((n >> 1) | (n >> 2));
-    return __builtin_bswap32(x);
-}
 // acc = 2 * acc + bit: one v_addc_co_u32 with the compare mask as carry-in
 __device__ __forceinline__ uint32_t shift_in(uint32_t acc, bool bit) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -610,23 +628,19 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         const int m = tk.m, n = tk.n, dlo = tk.dlo;
         bool ambig = false;
         if (live) {     // stage the two windows, 4 bases per lane and step (all loads in flight together)
-            const Piece pc = a.pieces[tk.piece];
-            const long long qo = (long long)a.qoff[pc.q], to = (long long)a.toff[pc.t] + tk.t0;
-            const int ql = (int)a.qlen[pc.q];
+            const bool rev = (tk.kind & TASK_REV) != 0;
             uint32_t vq[NQ_STEPS], vt[NT_STEPS];
 #pragma unroll
             for (int r = 0; r < NQ_STEPS; ++r) {
                 const int x = 4 * (l + 16 * r);
                 vq[r] = 0;
-                if (x < m)
-                    vq[r] = pc.strand ? revcomp_codes4(load_codes4(a.qcodes, qo + ql - 4 - (tk.q0 + x), a.q_total))
-                                      : load_codes4(a.qcodes, qo + tk.q0 + x, a.q_total);
+                if (x < m) vq[r] = load_window4(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
             }
 #pragma unroll
             for (int r = 0; r < NT_STEPS; ++r) {
                 const int x = 4 * (l + 16 * r);
                 vt[r] = 0;
-                if (x < n) vt[r] = load_codes4(a.tcodes, to + x, a.t_total);
+                if (x < n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
             }
 #pragma unroll
             for (int r = 0; r < NQ_STEPS; ++r) {
@@ -661,18 +675,6 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
     }
 }
 
-__global__ void task_kind_kernel(const TaskOut *out, size_t n, unsigned long long *acc) {
-    unsigned long long f = 0, d = 0, r = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t p = out[i].pad;
-        f += p == 1;
-        if ((p & 3) == 2) { ++d; r += (p >> 2) & 0xfffffu; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { f += __shfl_xor(f, o, 64); d += __shfl_xor(d, o, 64); r += __shfl_xor(r, o, 64); }
-    if ((threadIdx.x & 63) == 0) { if (f) atomicAdd(&acc[0], f); if (d) atomicAdd(&acc[1], d); if (r) atomicAdd(&acc[2], r); }
-}
-
 // ---- assembly of the task results into PAF rows ----------------------------------------------------------
 struct AsmArgs {
     const Piece *pieces;
@@ -685,63 +687,106 @@ struct AsmArgs {
     int min_dp_score, end_bonus;
 };
 
+// One wavefront per piece, one lane per task (64 tasks per step).  The row's CIGAR is the concatenation of the
+// kept tasks' runs with equal neighbours merged, so with S = runs of the kept tasks before a task and
+// M = boundaries up to and including its own where the first code equals the last code of the previous
+// non-empty kept task, run x of a task lands in slot S - M + x: a merged first run shares the slot of the run
+// it extends.  Slots are zero-initialised and the first / last run of a task are added atomically (they are the
+// only ones other tasks can touch); pass <false> needs just the first and last code of each task.
 template <bool WRITE>
-__global__ void assemble_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, const uint64_t *ops_off, uint32_t *ops,
-                                PafRec *recs, uint64_t *ord_hi, uint64_t *ord_lo) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= a.n_pieces) return;
-    if (WRITE && !valid[i]) return;
-    const Piece p = a.pieces[i];
-    const FixPt *fp = a.fps + p.fp_off;
-    const TaskOut *to = a.tout + a.task_off[i];
-    const uint32_t n_tasks = p.n_fp + 1;
-    int qs = (int)fp[0].q, ts = (int)fp[0].t, qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
-    long long score = 0;
-    uint32_t cnt = 0, last_code = 99;
-    uint64_t nmatch = 0, blen = 0;
-    uint32_t *w = WRITE ? ops + ops_off[i] : nullptr;
-    for (uint32_t t = 0; t < n_tasks; ++t) {
-        const TaskOut r = to[t];
-        const bool is_ext = t == 0 || t == n_tasks - 1;
-        if (is_ext) {
-            // an extension counts when it gains something; the end bonus counts for that decision, not for the score
-            if (r.score + ((r.pad & 0x80000000u) ? a.end_bonus : 0) <= 0 || r.n_runs == 0) continue;
-            if (t == 0) { qs -= r.bi; ts -= r.bj; } else { qe += r.bi; te += r.bj; }
-        }
-        score += r.score;
-        for (uint32_t x = 0; x < r.n_runs; ++x) {
-            const uint32_t run = a.runs[r.runs_off + x], code = run & 15u, len = run >> 4;
-            if (code == last_code) {
-                if (WRITE) w[cnt - 1] += len << 4;
-            } else {
-                if (WRITE) w[cnt] = run;
-                ++cnt;
-                last_code = code;
+__global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, const uint64_t *ops_off,
+                                                       uint32_t *ops, PafRec *recs, uint64_t *ord_hi, uint64_t *ord_lo) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t i = wave; i < a.n_pieces; i += n_waves) {
+        if (WRITE && !valid[i]) continue;
+        const Piece p = a.pieces[i];
+        const FixPt *fp = a.fps + p.fp_off;
+        const TaskOut *to = a.tout + a.task_off[i];
+        const uint32_t n_tasks = p.n_fp + 1;
+        uint32_t *w = WRITE ? ops + ops_off[i] : nullptr;
+        long long score = 0;
+        unsigned long long nmatch = 0, blen = 0;
+        uint32_t slots = 0;                       // S - M carried over the 64-task steps
+        uint32_t carry_code = 99;                 // last code of the last non-empty kept task so far
+        int ext_l_i = 0, ext_l_j = 0, ext_r_i = 0, ext_r_j = 0;
+        for (uint32_t t0 = 0; t0 < n_tasks; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            TaskOut r{0, 0, 0, 0, 0, 0};
+            bool keep = false;
+            if (t < n_tasks) {
+                r = to[t];
+                keep = true;
+                if (t == 0 || t == n_tasks - 1)   // an extension counts when it gains something (bonus: decision only)
+                    keep = !(r.score + ((r.pad & 0x80000000u) ? a.end_bonus : 0) <= 0 || r.n_runs == 0);
             }
-            blen += len;
-            if (code == OP_EQ) nmatch += len;
+            if (keep && t == 0) { ext_l_i = r.bi; ext_l_j = r.bj; }
+            if (keep && t == n_tasks - 1 && t != 0) { ext_r_i = r.bi; ext_r_j = r.bj; }
+            long long sc = keep ? r.score : 0;
+            const uint32_t nr = keep ? r.n_runs : 0;
+            uint32_t first = 0, last = 0;
+            if (nr) { first = a.runs[r.runs_off]; last = nr > 1 ? a.runs[r.runs_off + nr - 1] : first; }
+            const unsigned long long ne_mask = __ballot(nr != 0);
+            const unsigned long long below = ne_mask & ((1ull << lane) - 1ull);
+            const int prev_lane = below ? 63 - __clzll((long long)below) : 0;
+            const uint32_t prev_last = (uint32_t)__shfl((int)last, prev_lane, 64);
+            const uint32_t prev_code = below ? (prev_last & 15u) : carry_code;
+            const bool mrg = nr != 0 && (first & 15u) == prev_code;
+            uint32_t tot_runs, tot_mrg;
+            const uint32_t S = wave_excl_sum_u32(nr, lane, tot_runs);
+            const uint32_t Mx = wave_excl_sum_u32(mrg ? 1u : 0u, lane, tot_mrg);
+            if (WRITE && nr) {
+                const uint32_t base = slots + S - (Mx + (mrg ? 1u : 0u));
+                for (uint32_t x = 0; x < nr; ++x) {
+                    const uint32_t run = x == 0 ? first : (x == nr - 1 ? last : a.runs[r.runs_off + x]);
+                    const uint32_t len = run >> 4;
+                    blen += len;
+                    if ((run & 15u) == OP_EQ) nmatch += len;
+                    if (x == 0 && mrg) atomicAdd(&w[base], len << 4);
+                    else if (x == 0 || x == nr - 1) atomicAdd(&w[base + x], run);
+                    else w[base + x] = run;
+                }
+            }
+            slots += tot_runs - tot_mrg;
+            if (ne_mask) carry_code = (uint32_t)__shfl((int)last, 63 - __clzll((long long)ne_mask), 64) & 15u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+            score += sc;
+        }
+        // extension shifts live in lane 0 (left) and in the lane of the last task (right)
+        const int li = __shfl(ext_l_i, 0, 64), lj = __shfl(ext_l_j, 0, 64);
+        const int last_lane = (int)((n_tasks - 1) & 63u);
+        const int ri = __shfl(ext_r_i, last_lane, 64), rj = __shfl(ext_r_j, last_lane, 64);
+        if (!WRITE) {
+            if (lane == 0) {
+                const bool ok = slots > 0 && score >= a.min_dp_score;
+                valid[i] = ok ? 1 : 0;
+                n_ops[i] = ok ? slots : 0;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { nmatch += __shfl_xor(nmatch, o, 64); blen += __shfl_xor(blen, o, 64); }
+        if (lane == 0) {
+            const int qs = (int)fp[0].q - li, ts = (int)fp[0].t - lj;
+            const int qe = (int)fp[p.n_fp - 1].q + ri, te = (int)fp[p.n_fp - 1].t + rj;
+            const uint32_t ql = a.qlen[p.q];
+            PafRec r{};
+            r.qid = a.rank_q[p.q]; r.tid = a.rank_t[p.t];
+            r.qlen = ql; r.tlen = a.tlen[p.t];
+            r.qs = p.strand ? ql - (uint32_t)qe : (uint32_t)qs;
+            r.qe = p.strand ? ql - (uint32_t)qs : (uint32_t)qe;
+            r.ts = (uint32_t)ts; r.te = (uint32_t)te;
+            r.nmatch = (uint32_t)nmatch; r.blen = (uint32_t)blen;
+            r.flags = p.strand ? PF_REV : 0;
+            r.chunk = a.chunk_of_t[p.t];
+            r.cig_off = ops_off[i]; r.cig_n = slots; r.tie = 0;
+            recs[i] = r;
+            ord_hi[i] = (uint64_t)r.chunk << 32 | p.q;
+            ord_lo[i] = (uint64_t)p.t << 43 | (uint64_t)p.strand << 42 | (uint64_t)(p.chain & 0x3fffffu) << 20 | (p.piece & 0xfffffu);
         }
     }
-    if (!WRITE) {
-        const bool ok = cnt > 0 && score >= a.min_dp_score;
-        valid[i] = ok ? 1 : 0;
-        n_ops[i] = ok ? cnt : 0;
-        return;
-    }
-    const uint32_t ql = a.qlen[p.q];
-    PafRec r{};
-    r.qid = a.rank_q[p.q]; r.tid = a.rank_t[p.t];
-    r.qlen = ql; r.tlen = a.tlen[p.t];
-    r.qs = p.strand ? ql - (uint32_t)qe : (uint32_t)qs;
-    r.qe = p.strand ? ql - (uint32_t)qs : (uint32_t)qe;
-    r.ts = (uint32_t)ts; r.te = (uint32_t)te;
-    r.nmatch = (uint32_t)nmatch; r.blen = (uint32_t)blen;
-    r.flags = p.strand ? PF_REV : 0;
-    r.chunk = a.chunk_of_t[p.t];
-    r.cig_off = ops_off[i]; r.cig_n = cnt; r.tie = 0;
-    recs[i] = r;
-    ord_hi[i] = (uint64_t)r.chunk << 32 | p.q;
-    ord_lo[i] = (uint64_t)p.t << 43 | (uint64_t)p.strand << 42 | (uint64_t)(p.chain & 0x3fffffu) << 20 | (p.piece & 0xfffffu);
 }
 
 __global__ void compact_rows_kernel(const uint32_t *idx, size_t n, const PafRec *recs, const uint64_t *hi,
@@ -765,22 +810,23 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     const size_t NT = (size_t)download_one(toff.p + (P - 1)) + download_one(tcnt.p + (P - 1));
     DBuf<Task> tasks(NT);
     hipLaunchKernelGGL(make_tasks_kernel, grid1(P), dim3(WG), 0, stream(), ch.pieces.p, ch.fps.p, toff.p, P, d_qlen, d_tlen,
-                       tasks.p);
+                       in.Q->off.p, in.T->off.p, tasks.p);
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
-    DBuf<uint8_t> cls_keep;
     DBuf<uint32_t> counters(2);
-    // runs + one open chunk per allocating lane of every launch (classify: 16 leaders per block ...)
-    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + (size_t)256 * 16 * (32 * RUN_CHUNK_SMALL + WAVES * RUN_CHUNK);
+    DBuf<unsigned long long> astats(N_ALIGN_STATS);
+    // runs + one open chunk per allocating lane of every launch: classify and align_kernel (one per wave), the two
+    // align_narrow_kernel instances (one per 16-lane group)
+    constexpr size_t MAX_BLOCKS = 256 * 16;
+    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + MAX_BLOCKS * (2 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL);
     DBuf<uint32_t> runs;
     for (int attempt = 0;; ++attempt) {
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
         runs.alloc(cap_runs);
         counters.zero();
         AlignArgs aa{};
-        aa.tasks = tasks.p; aa.n_tasks = NT; aa.pieces = ch.pieces.p;
-        aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p; aa.qoff = in.Q->off.p; aa.toff = in.T->off.p;
-        aa.qlen = d_qlen;
+        aa.tasks = tasks.p; aa.n_tasks = NT;
+        aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p;
         aa.q_total = (long long)in.Q->total; aa.t_total = (long long)in.T->total;
         aa.end_bonus = o.end_bonus;
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
@@ -792,17 +838,25 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         // pass 1: classify every task, finish the diagonal fast path right away
         DBuf<uint8_t> cls(NT), f1(NT), f2(NT), f3(NT);
-        struct KeepCls { DBuf<uint8_t> *dst; DBuf<uint8_t> *src; ~KeepCls() { *dst = std::move(*src); } } keep{&cls_keep, &cls};
         {
             KTimer kt("align_classify");
-            const unsigned nbc = (unsigned)std::min<size_t>((NT + 15) / 16, 256 * 16);
-            hipLaunchKernelGGL(classify_kernel, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p);
+            const unsigned nbc = (unsigned)std::min<size_t>(cdiv(NT, (size_t)WG), MAX_BLOCKS);
+            astats.zero();
+            hipLaunchKernelGGL(classify_kernel, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
         }
         hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p, f3.p);
         HIP_CHECK(hipGetLastError());
         DBuf<uint32_t> list1(NT), list2(NT), list3(NT);
         const size_t n1 = select_flagged_indices(f1.p, list1.p, NT), n2 = select_flagged_indices(f2.p, list2.p, NT),
                      n3 = select_flagged_indices(f3.p, list3.p, NT);
+        for (int which = 0; which < 2; ++which) {
+            uint32_t *lst = which ? list3.p : list1.p;
+            const size_t nl = which ? n3 : n1;
+            if (nl < 8) continue;
+            DBuf<uint32_t> key(nl);
+            hipLaunchKernelGGL(task_rows_key_kernel, grid1(nl), dim3(WG), 0, stream(), tasks.p, lst, nl, key.p);
+            sort_pairs_u32_u32(key.p, lst, nl, 0, 7);
+        }
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
         if (n1) {
             KTimer kt("align_narrow");
@@ -831,24 +885,15 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         cap_runs *= 4;
     }
     stat_add("align_tasks", (double)NT);
-    {   // how many tasks took the diagonal fast path / the DP (and how many DP rows)
-        DBuf<unsigned long long> acc(3);
-        acc.zero();
-        hipLaunchKernelGGL(task_kind_kernel, dim3(1024), dim3(WG), 0, stream(), tout.p, NT, acc.p);
-        std::vector<unsigned long long> h = acc.download(3);
-        stat_add("align_tasks_fast", (double)h[0]);
-        stat_add("align_tasks_dp", (double)h[1]);
-        stat_add("align_dp_rows", (double)h[2]);
-    }
     {
-        DBuf<unsigned long long> sum(4);
-        sum.zero();
-        hipLaunchKernelGGL(task_bases_kernel, dim3(1024), dim3(WG), 0, stream(), tasks.p, cls_keep.p, NT, sum.p);
-        std::vector<unsigned long long> hs = sum.download(4);
-        stat_add("align_dp_bases", (double)hs[0]);            // Lq + Lt over all tasks
-        stat_add("align_bases_classify", (double)hs[1]);
-        stat_add("align_bases_narrow", (double)hs[2]);
-        stat_add("align_bases_wide", (double)hs[3]);
+        std::vector<unsigned long long> h = astats.download(N_ALIGN_STATS);
+        stat_add("align_tasks_fast", (double)h[ST_FAST]);
+        stat_add("align_tasks_dp", (double)h[ST_DP]);
+        stat_add("align_dp_rows", (double)h[ST_DP_ROWS]);
+        stat_add("align_dp_bases", (double)h[ST_BASES]);              // Lq + Lt over all tasks
+        stat_add("align_bases_classify", (double)h[ST_BASES_SQUARE]);
+        stat_add("align_bases_narrow", (double)h[ST_BASES_NARROW]);
+        stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
     }
     // assemble
     AsmArgs as{};
@@ -857,8 +902,12 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     as.qlen = d_qlen; as.tlen = d_tlen; as.rank_q = in.d_rank_q; as.rank_t = in.d_rank_t; as.chunk_of_t = in.d_chunk_of_t;
     DBuf<uint32_t> nops(P);
     DBuf<uint8_t> valid(P);
-    hipLaunchKernelGGL(assemble_kernel<false>, grid1(P), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
-                       nullptr, nullptr, nullptr);
+    const unsigned nba = (unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32);
+    {
+        KTimer kt("assemble_count");
+        hipLaunchKernelGGL(assemble_kernel<false>, dim3(nba), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
+                           nullptr, nullptr, nullptr);
+    }
     HIP_CHECK(hipGetLastError());
     DBuf<uint64_t> ooff(P);
     exclusive_scan_u32_to_u64(nops.p, ooff.p, P);
@@ -869,8 +918,12 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     out.ops.alloc(n_ops ? n_ops : 1);
     DBuf<PafRec> recs(P);
     DBuf<uint64_t> hi(P), lo(P);
-    hipLaunchKernelGGL(assemble_kernel<true>, grid1(P), dim3(WG), 0, stream(), as, nullptr, valid.p, ooff.p, out.ops.p,
-                       recs.p, hi.p, lo.p);
+    out.ops.zero();
+    {
+        KTimer kt("assemble_write");
+        hipLaunchKernelGGL(assemble_kernel<true>, dim3(nba), dim3(WG), 0, stream(), as, nullptr, valid.p, ooff.p, out.ops.p,
+                           recs.p, hi.p, lo.p);
+    }
     HIP_CHECK(hipGetLastError());
     out.recs.alloc(R);
     out.ord_hi.alloc(R);
