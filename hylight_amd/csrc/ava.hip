@@ -102,7 +102,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     {
         HostTimer ht("index");
         sketch_device(*in.T, o.k, o.w, o.hpc, 0, tsk);
-        build_index(tsk, in.d_chunk_of_t, in.n_chunks, o, ix);
+        build_index(tsk, in.d_chunk_of_t, in.d_rank_t, in.n_chunks, o, ix);
         tsk.mz.release();
     }
     stat_add("index_entries", (double)ix.n);

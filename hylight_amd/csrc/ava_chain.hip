@@ -77,6 +77,18 @@ __global__ void index_hist_kernel(const uint32_t *run_start, size_t n_runs, size
     atomicAdd(&hist[(size_t)c * HB + (len < (uint32_t)HB - 1 ? len : (uint32_t)HB - 1)], 1u);
 }
 
+__global__ void index_rank_kernel(const uint64_t *y, const uint32_t *occ, const uint32_t *mid_occ, const uint32_t *chunk_of_t,
+                                  const uint32_t *rank_t, size_t n, uint32_t *rk) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = (uint32_t)(y[i] >> 32);
+    rk[i] = rank_t[t] | (occ[i] > mid_occ[chunk_of_t[t]] ? 0x80000000u : 0u);
+}
+__global__ void index_bucket_kernel(const uint64_t *key, size_t n, int shift, size_t n_buckets, uint32_t *bucket) {
+    size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (b <= n_buckets) bucket[b] = b == n_buckets ? (uint32_t)n : (uint32_t)lower_bound_u64(key, n, (uint64_t)b << shift);
+}
+
 // ---------------------------------------------------------------------------------------------
 // seeds
 // ---------------------------------------------------------------------------------------------
@@ -84,7 +96,9 @@ struct SeedArgs {
     const Mz *qmz;              // first minimizer of the batch
     size_t n_mz;
     const uint64_t *ikey, *iy;
-    const uint32_t *iocc, *mid_occ, *chunk_of_t, *rank_q, *rank_t, *qlen;
+    const uint32_t *irk, *bucket, *rank_q, *qlen;
+    uint32_t *run_lo, *run_len; // occurrence run of every query minimizer: written by the counting pass, read by the fill
+    int bucket_shift;
     size_t n_idx;
     uint32_t q_lo;
     int pair_once;              // 1: only strcmp(qname,tname) < 0; 0: every pair except self
@@ -107,13 +121,23 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
     uint64_t w0 = 0;
     if (live) {
         z = a.qmz[m];
-        const uint64_t key = z.x >> 8;
-        lo = lower_bound_u64(a.ikey, a.n_idx, key);
-        hi = lo;
-        if (lo < a.n_idx && a.ikey[lo] == key) hi = lower_bound_u64(a.ikey + lo, a.n_idx - lo, key + 1) + lo;
         const uint32_t q = (uint32_t)(z.y >> 32);
         rq = a.rank_q[q];
-        if (FILL) { ql = a.qlen[q]; w0 = aoff[m]; }
+        if (FILL) {
+            lo = a.run_lo[m];
+            hi = lo + a.run_len[m];
+            ql = a.qlen[q];
+            w0 = aoff[m];
+        } else {        // the key's bucket bounds the search to a few entries
+            const uint64_t key = z.x >> 8;
+            const size_t b = (size_t)(key >> a.bucket_shift);
+            const size_t b_lo = a.bucket[b], b_hi = a.bucket[b + 1];
+            lo = b_lo + lower_bound_u64(a.ikey + b_lo, b_hi - b_lo, key);
+            hi = lo;
+            if (lo < b_hi && a.ikey[lo] == key) hi = lo + lower_bound_u64(a.ikey + lo, b_hi - lo, key + 1);
+            a.run_lo[m] = (uint32_t)lo;
+            a.run_len[m] = (uint32_t)(hi - lo);
+        }
     }
     uint32_t my_cnt = 0;
     for (int b = 0; b < 64; ++b) {
@@ -129,11 +153,9 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
             bool ok = false;
             uint64_t y = 0;
             if (e < hi_b) {
-                y = a.iy[e];
-                const uint32_t t = (uint32_t)(y >> 32);
-                const uint32_t rt = a.rank_t[t];
-                ok = !(a.iocc[e] > a.mid_occ[a.chunk_of_t[t]])      // not too frequent inside that chunk
-                     && (a.pair_once ? rq_b < rt : rq_b != rt);      // pair once / never self
+                if (FILL) y = a.iy[e];
+                const uint32_t rt = a.irk[e];                        // bit 31: too frequent inside its chunk
+                ok = a.pair_once ? rq_b < rt && !(rt >> 31) : rq_b != (rt & 0x7fffffffu) && !(rt >> 31);   // pair once / never self
             }
             const unsigned long long mask = __ballot(ok);
             if (FILL && ok) {
@@ -432,8 +454,8 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_chunks, const hlmi_ava_opts &o,
-                 DevIndex &ix) {
+void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint32_t *d_rank_t, uint32_t n_chunks,
+                 const hlmi_ava_opts &o, DevIndex &ix) {
     const size_t n = tsk.n;
     ix.n = n;
     ix.pair_once = o.pair_once;
@@ -472,16 +494,28 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_
         }
     }
     ix.mid_occ.upload(mid);
+    ix.rk.alloc(n ? n : 1);
+    // buckets: about one per 16 entries, never more than the key has bits
+    ix.bucket_bits = std::min(2 * o.k, std::max(1, bits_for(n >> 4)));
+    ix.bucket_shift = 2 * o.k - ix.bucket_bits;
+    const size_t nb = (size_t)1 << ix.bucket_bits;
+    ix.bucket.alloc(nb + 1);
+    if (n) hipLaunchKernelGGL(index_rank_kernel, grid1(n), dim3(WG), 0, stream(), ix.y.p, ix.occ.p, ix.mid_occ.p, d_chunk_of_t,
+                              d_rank_t, n, ix.rk.p);
+    hipLaunchKernelGGL(index_bucket_kernel, grid1(nb + 1), dim3(WG), 0, stream(), ix.key.p, n, ix.bucket_shift, nb, ix.bucket.p);
+    HIP_CHECK(hipGetLastError());
     sync();
 }
 
-static SeedArgs make_seed_args(const AvaInput &in, const DevIndex &ix, const uint32_t *d_qlen, size_t q_lo, size_t q_hi) {
+static SeedArgs make_seed_args(const AvaInput &in, const DevIndex &ix, const SeedPlan &plan, const uint32_t *d_qlen,
+                               size_t q_lo, size_t q_hi) {
     SeedArgs sa{};
     sa.pair_once = ix.pair_once;
     sa.qmz = in.d_qmz + in.qmz_off[q_lo];
     sa.n_mz = in.qmz_off[q_hi] - in.qmz_off[q_lo];
-    sa.ikey = ix.key.p; sa.iy = ix.y.p; sa.iocc = ix.occ.p; sa.mid_occ = ix.mid_occ.p;
-    sa.chunk_of_t = in.d_chunk_of_t; sa.rank_q = in.d_rank_q; sa.rank_t = in.d_rank_t; sa.qlen = d_qlen;
+    sa.ikey = ix.key.p; sa.iy = ix.y.p; sa.irk = ix.rk.p; sa.bucket = ix.bucket.p; sa.bucket_shift = ix.bucket_shift;
+    sa.run_lo = plan.lo.p + in.qmz_off[q_lo]; sa.run_len = plan.len.p + in.qmz_off[q_lo];
+    sa.rank_q = in.d_rank_q; sa.qlen = d_qlen;
     sa.n_idx = ix.n;
     sa.q_lo = (uint32_t)q_lo;
     return sa;
@@ -490,8 +524,11 @@ static SeedArgs make_seed_args(const AvaInput &in, const DevIndex &ix, const uin
 void plan_seeds(const AvaInput &in, const DevIndex &ix, SeedPlan &plan) {
     const size_t nQ = in.Q->n;
     plan.per_query.assign(nQ, 0);
-    SeedArgs sa = make_seed_args(in, ix, nullptr, 0, nQ);
-    plan.cnt.alloc(sa.n_mz ? sa.n_mz : 1);
+    const size_t n_all = in.qmz_off[nQ];
+    plan.cnt.alloc(n_all ? n_all : 1);
+    plan.lo.alloc(n_all ? n_all : 1);
+    plan.len.alloc(n_all ? n_all : 1);
+    SeedArgs sa = make_seed_args(in, ix, plan, nullptr, 0, nQ);
     if (!sa.n_mz || !ix.n) { plan.cnt.zero(); return; }
     {
         KTimer kt("seed_count");
@@ -524,7 +561,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     for (size_t t = 0; t < in.T->n; ++t) max_tlen = std::max<uint64_t>(max_tlen, in.T->h_off[t + 1] - in.T->h_off[t]);
     if (max_tlen >= (1ull << TPOS_BITS_MAX)) fail(HLMI_EINVAL, "target longer than 2^24 bases");
     const int pb = bits_for(max_tlen), tb = bits_for(in.T->n > 1 ? in.T->n - 1 : 1);
-    SeedArgs sa = make_seed_args(in, ix, d_qlen, q_lo, q_hi);
+    SeedArgs sa = make_seed_args(in, ix, plan, d_qlen, q_lo, q_hi);
     sa.pb = pb; sa.tb = tb;
     if (!sa.n_mz || !ix.n) return;
     const uint32_t *cnt = plan.cnt.p + in.qmz_off[q_lo];

@@ -11,10 +11,14 @@ struct DevIndex {
     DBuf<uint64_t> y;        // target << 32 | pos << 1 | strand
     DBuf<uint32_t> occ;      // occurrences of this key inside the entry's chunk
     DBuf<uint32_t> mid_occ;  // per chunk: occurrence cut-off
+    DBuf<uint32_t> rk;       // name rank of the entry's target | (too frequent in its chunk) << 31: all a seed needs to
+                             // accept or reject the occurrence, read in step with y
+    DBuf<uint32_t> bucket;   // first entry of every value of the top bucket_bits key bits (2^bits + 1 offsets)
+    int bucket_shift = 0, bucket_bits = 0;
     int pair_once = 1;       // seeding rule carried with the index (hlmi_ava_opts::pair_once)
 };
-void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, uint32_t n_chunks, const hlmi_ava_opts &o,
-                 DevIndex &ix);
+void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint32_t *d_rank_t, uint32_t n_chunks,
+                 const hlmi_ava_opts &o, DevIndex &ix);
 
 // ---- S3/S4 output: alignment pieces = lists of fixed points -----------------------------------
 struct Piece {               // 32 B
@@ -36,6 +40,7 @@ struct SeedStats { uint64_t anchors = 0, groups = 0; };
 // one counting pass over ALL query minimizers: anchors per minimizer (device) and per query (host)
 struct SeedPlan {
     DBuf<uint32_t> cnt;                 // per query minimizer
+    DBuf<uint32_t> lo, len;             // its occurrence run in the index (found once, by the counting pass)
     std::vector<uint64_t> per_query;    // per query read
 };
 void plan_seeds(const AvaInput &in, const DevIndex &ix, SeedPlan &plan);
