@@ -4,7 +4,8 @@
 //             occurrence cut-off from the count histogram (Li 2016 section 2.3: drop the top fraction)
 //   seeds   : one thread per query minimizer: binary search of the hash, walk of its occurrence run,
 //             pair-once rule strcmp(qname,tname) < 0 (ava "no dual / no diagonal"), anchors packed as
-//             key = qlocal | target:tb | strand:1 | tpos:pb (widths per batch) ,  val = qpos:32 | qspan:8
+//             key = qlocal | target:tb | strand:1 | tpos:pb | qpos:qpb | qspan:8 in ONE 64-bit word when the
+//             widths of the batch fit (they do for read sets); else key = ... | tpos and val = qpos:32 | qspan:8
 //   order   : one stable 64-bit radix sort per query batch (generation order breaks ties)
 //   chains  : one wavefront per (query,target,strand) group.  The DP keeps the current and the previous
 //             block of 64 anchors in registers (lane = index mod 64), every lane scores one predecessor and
@@ -103,6 +104,7 @@ struct SeedArgs {
     uint32_t q_lo;
     int pair_once;              // 1: only strcmp(qname,tname) < 0; 0: every pair except self
     int pb, tb;                 // key layout: tpos bits, target bits
+    int vb;                     // payload bits below tpos: 8 + qpos bits when the anchor is one word, 0 with a value array
 };
 
 // Wave-cooperative: a wave owns 64 consecutive query minimizers.  Every lane binary-searches the
@@ -164,9 +166,10 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
                 const uint32_t tpos = (uint32_t)y >> 1, strand = qz ^ ((uint32_t)y & 1);
                 const uint32_t qp = strand ? ql_b - (qpos + 1 - qspan) - 1 : qpos;
                 const unsigned long long at = w + __popcll(mask & ((1ull << lane) - 1));
-                okey[at] = (uint64_t)(q - a.q_lo) << (a.tb + 1 + a.pb) | (uint64_t)t << (1 + a.pb) |
-                           (uint64_t)strand << a.pb | tpos;
-                oval[at] = (uint64_t)qp << 32 | (uint64_t)qspan << 24;
+                const uint64_t kk = (uint64_t)(q - a.q_lo) << (a.tb + 1 + a.pb) | (uint64_t)t << (1 + a.pb) |
+                                    (uint64_t)strand << a.pb | tpos;
+                if (a.vb) okey[at] = kk << a.vb | (uint64_t)qp << 8 | qspan;
+                else { okey[at] = kk; oval[at] = (uint64_t)qp << 32 | (uint64_t)qspan << 24; }
             }
             const uint32_t n = (uint32_t)__popcll(mask);
             w += n;
@@ -213,8 +216,9 @@ struct ChainArgs {
     unsigned long long *bck;          // best child: f << 32 | ~index
     int *mem;                         // member lists of the chains (phase C scratch, one slot per anchor)
     int k, max_gap, bw, min_score, min_cnt;
-    int pb, tb;                       // key layout
+    int pb, tb, vb;                   // key layout (SeedArgs)
     uint64_t pmask;                   // (1 << pb) - 1
+    uint32_t qmask;                   // (1 << qpos bits) - 1
     uint32_t q_lo;
     Piece *pieces;
     FixPt *fps;
@@ -227,6 +231,16 @@ struct ChainArgs {
 // chains only move forward through the group (children have larger indices, a best child is at most
 // CHAIN_PRED ahead), so a walk touches every anchor once, window loads are coalesced and the walk itself runs
 // on v_readlane instead of dependent global loads.  All lanes execute it uniformly.
+// target position, query position, span of anchor idx
+__device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, int &t, int &q, int &sp) {
+    const uint64_t key = a.key[idx];
+    if (a.vb) {
+        sp = (int)(key & 0xff); q = (int)((uint32_t)(key >> 8) & a.qmask); t = (int)((key >> a.vb) & a.pmask);
+    } else {
+        const uint64_t val = a.val[idx];
+        t = (int)(key & a.pmask); q = (int)(val >> 32); sp = (int)((val >> 24) & 0xff);
+    }
+}
 __device__ __forceinline__ unsigned long long rl64(unsigned long long v, int l) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
@@ -250,8 +264,8 @@ __device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *me
             te_l = qe_l = sp_l = 0;
             if (x + lane < len) {
                 const int idx = mem[x + lane];
-                const uint64_t key = a.key[b + idx], val = a.val[b + idx];
-                te_l = (int)(key & a.pmask) + 1; qe_l = (int)(val >> 32) + 1; sp_l = (int)((val >> 24) & 0xff);
+                anchor_fields(a, b + idx, te_l, qe_l, sp_l);
+                ++te_l; ++qe_l;
             }
         }
         if (!open) {                                           // a piece starts at the START of member x
@@ -334,10 +348,7 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs a) {
         for (int i0 = 0; i0 < n; i0 += 64) {
             int my_t = 0, my_q = 0, my_s = 0, my_p = -1;
             if (i0 + lane < n) {
-                const uint64_t key = a.key[b + i0 + lane], val = a.val[b + i0 + lane];
-                my_t = (int)(key & a.pmask);
-                my_q = (int)(val >> 32);
-                my_s = (int)((val >> 24) & 0xff);
+                anchor_fields(a, b + i0 + lane, my_t, my_q, my_s);
             }
             const int nb = n - i0 < 64 ? n - i0 : 64;
             int w_cur = 0, si_cur = 0;
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs a) {
         __threadfence_block();
         if (!(a.dbg_phases & 4)) continue;
         // ---- phase C: chain starts are found 64 anchors at a time; the wave walks each chain together --------------
-        const uint64_t key0 = a.key[b];
+        const uint64_t key0 = a.key[b] >> a.vb;
         const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1 + a.pb));
         const uint32_t tg = (uint32_t)(key0 >> (1 + a.pb)) & ((1u << a.tb) - 1);
         const uint32_t strand = (uint32_t)(key0 >> a.pb) & 1u;
@@ -561,8 +572,15 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     for (size_t t = 0; t < in.T->n; ++t) max_tlen = std::max<uint64_t>(max_tlen, in.T->h_off[t + 1] - in.T->h_off[t]);
     if (max_tlen >= (1ull << TPOS_BITS_MAX)) fail(HLMI_EINVAL, "target longer than 2^24 bases");
     const int pb = bits_for(max_tlen), tb = bits_for(in.T->n > 1 ? in.T->n - 1 : 1);
+    uint64_t max_qlen = 1;
+    for (size_t q = q_lo; q < q_hi; ++q) max_qlen = std::max<uint64_t>(max_qlen, in.Q->h_off[q + 1] - in.Q->h_off[q]);
+    const int qbits = bits_for((uint64_t)(q_hi - q_lo - 1 ? q_hi - q_lo - 1 : 1)), qpb = bits_for(max_qlen);
+    // one 64-bit word per anchor when everything fits: the sort moves half the bytes and needs no value array
+    // (HLMI_ANCHOR_PAIRS=1 forces the key + value form: test hook for the path wide inputs take)
+    const bool fits = qbits + tb + 1 + pb + qpb + 8 <= 64 && !getenv("HLMI_ANCHOR_PAIRS");
+    const int vb = fits ? qpb + 8 : 0;
     SeedArgs sa = make_seed_args(in, ix, plan, d_qlen, q_lo, q_hi);
-    sa.pb = pb; sa.tb = tb;
+    sa.pb = pb; sa.tb = tb; sa.vb = vb;
     if (!sa.n_mz || !ix.n) return;
     const uint32_t *cnt = plan.cnt.p + in.qmz_off[q_lo];
     DBuf<uint64_t> aoff(sa.n_mz);
@@ -572,20 +590,20 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (!A) return;
     if (A >= (1ull << 32)) fail(HLMI_EINVAL, "anchor batch too large");
     HostTimer *ht_s = new HostTimer("seed_sort_phase");
-    DBuf<uint64_t> akey(A), aval(A);
+    DBuf<uint64_t> akey(A), aval(vb ? 1 : A);
     {
         KTimer kt("seed_fill");
         hipLaunchKernelGGL(seed_kernel<true>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, nullptr, aoff.p, akey.p, aval.p);
     }
     HIP_CHECK(hipGetLastError());
     aoff.release();
-    const int qbits = bits_for((uint64_t)(q_hi - q_lo - 1 ? q_hi - q_lo - 1 : 1));
     {
         KTimer kt("anchor_sort");
-        sort_pairs_u64_u64(akey.p, aval.p, A, 0, tb + 1 + pb + qbits);
+        if (vb) sort_keys_u64(akey.p, A, vb, vb + tb + 1 + pb + qbits);
+        else sort_pairs_u64_u64(akey.p, aval.p, A, 0, tb + 1 + pb + qbits);
     }
     DBuf<uint8_t> head(A);
-    hipLaunchKernelGGL(group_head_kernel, grid1(A), dim3(WG), 0, stream(), akey.p, A, pb, head.p);
+    hipLaunchKernelGGL(group_head_kernel, grid1(A), dim3(WG), 0, stream(), akey.p, A, vb + pb, head.p);
     DBuf<uint32_t> gstart(A);
     const size_t G = select_flagged_indices(head.p, gstart.p, A);
     head.release();
@@ -604,7 +622,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     ca.f = f.p; ca.p = p.p; ca.bck = bck.p; ca.mem = mem.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
-    ca.pb = pb; ca.tb = tb; ca.pmask = (1ull << pb) - 1;
+    ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
     ca.dbg_phases = getenv("HLMI_CHAIN_PHASES") ? atoi(getenv("HLMI_CHAIN_PHASES")) : 7;
     ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);
     ca.cap_fps = (uint32_t)std::min<size_t>(2 * A + 1024, 0xfffffff0u);

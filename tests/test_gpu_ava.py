@@ -63,6 +63,17 @@ def test_ava_matches_oracle(tmp_path, seed, n, kw):
     assert got == want
 
 
+def test_ava_key_value_anchor_form(tmp_path, monkeypatch):
+    """Anchors normally travel as one packed 64-bit word; inputs whose id / position widths do not fit take a
+    key + value form (same order, same chains).  HLMI_ANCHOR_PAIRS forces it."""
+    reads = _sim(32, 60, n_strains=3, genome_len=15000, err_sub=0.01, err_ins=0.004, err_del=0.004)
+    fa = _write(tmp_path, "r.fa", reads)
+    api.ava(fa, fa, tmp_path / "packed.paf")
+    monkeypatch.setenv("HLMI_ANCHOR_PAIRS", "1")
+    api.ava(fa, fa, tmp_path / "pairs.paf")
+    assert open(tmp_path / "pairs.paf").read() == open(tmp_path / "packed.paf").read()
+
+
 def test_ava_target_subset_and_ambiguous_bases(tmp_path):
     reads = _sim(41, 36)
     reads[2].seq[1000:1004] = ord("N")
