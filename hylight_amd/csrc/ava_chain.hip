@@ -315,25 +315,22 @@ __device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *me
 
 constexpr int PEN_TAB = 2048;         // gap-cost table entries (bandwidth + 2 must fit; else the VALU form runs)
 
-// Phase A keeps two 64-anchor blocks in registers, lane = anchor index mod 64: the 64 predecessors of anchor
-// i0+bb are the lanes below bb of the current block and the lanes from bb up of the previous one, so nothing is
-// shifted per anchor and f / p leave as coalesced 256-byte stores.  The gap cost is an LDS table look-up
-// (dd*k/100 would be two quarter-rate multiplies per lane).
-// One wave per workgroup, CHAIN_GROUPS consecutive groups per workgroup: group sizes span three orders of
-// magnitude, so the balancing is left to the hardware dispatcher (a fixed grid-stride split of the groups
-// left the SIMDs at 3 of 8 resident waves on average).
+// The gap cost is an LDS table look-up (dd*k/100 would be two quarter-rate multiplies per lane).
+// CHAIN_GROUPS consecutive groups per wave, CHAIN_WAVES independent waves per workgroup: group sizes span three
+// orders of magnitude, so the balancing is left to the hardware dispatcher (a fixed grid-stride split of the
+// groups left the SIMDs at 3 of 8 resident waves on average).
 constexpr int CHAIN_GROUPS = 4;
+constexpr int CHAIN_WAVES = 1;      // (4 waves sharing one gap-cost table measured 5 % slower)
 template <bool TAB>
-__global__ __launch_bounds__(64) void chain_kernel(ChainArgs a) {
+__global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     __shared__ uint16_t pen_tab[TAB ? PEN_TAB : 1];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     if (TAB) {
-        for (int d = lane; d < a.bw + 2; d += 64)
+        for (int d = threadIdx.x; d < a.bw + 2; d += 64 * CHAIN_WAVES)
             pen_tab[d] = (uint16_t)(d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0);
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
-    const size_t g_lo = (size_t)blockIdx.x * CHAIN_GROUPS;
+    const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
     const size_t g_hi = g_lo + CHAIN_GROUPS < a.n_groups ? g_lo + CHAIN_GROUPS : a.n_groups;
     for (size_t g = g_lo; g < g_hi; ++g) {
         const size_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g]);
@@ -341,53 +338,66 @@ __global__ __launch_bounds__(64) void chain_kernel(ChainArgs a) {
         const int n = (int)(e - b);
         if (n < a.min_cnt) continue;
         // ---- phase A: DP;  phase B: best child of every anchor (64-bit atomicMax of f << 32 | ~index) ----------
-        // R_t / R_q / R_f: lane l = the latest anchor with index = l mod 64, i.e. the 64 predecessors of the anchor
-        // about to be scored.  Everything that does not depend on f (gap geometry, gap cost look-up) is computed
-        // one anchor ahead, so it fills the wait states of the reduction of the anchor before it.
-        int R_t = 0, R_q = 0x3fffffff, R_f = 0;               // "no predecessor": dq < 0 fails the gap test
+        // "Push" form of the recurrence: lane l holds the anchor with index = l mod 64 among the 64 that FOLLOW the
+        // anchor j being finished (M_*: position, span, best score so far + 1 / best predecessor).  Step j reads the
+        // finished f(j) from lane j % 64, hands that lane to anchor j + 64 (N_*: the next 64 anchors, loaded a block
+        // ahead) and lets every lane try j as its predecessor: no cross-lane reduction, and the part that does not
+        // depend on f (gap geometry, gap cost look-up) is computed one step ahead.  Predecessors arrive in ascending
+        // order, so "candidate >= best" gives ties to the closest one; M_best starts at span + 1 so that the first
+        // predecessor needs candidate > span.
+        constexpr int DEAD_Q = -(1 << 30);                    // lanes past the end of the group: dq < 0 fails the gap test
+        auto load_block = [&](int i0, int &t, int &q, int &sp) {
+            t = 0; q = DEAD_Q; sp = 0;
+            if (i0 + lane < n) anchor_fields(a, b + i0 + lane, t, q, sp);
+        };
+        int M_t, M_q, M_s, N_t, N_q, N_s, P_t, P_q, P_s;
+        load_block(0, M_t, M_q, M_s);
+        load_block(64, N_t, N_q, N_s);
+        int M_best = M_s + 1, M_bp = -1;
+        auto prepare = [&](int jl, int &w) {
+            const int tj = __builtin_amdgcn_readlane(M_t, jl), qj = __builtin_amdgcn_readlane(M_q, jl);
+            const bool me = lane == jl;                       // this lane now receives for anchor j + 64
+            M_t = me ? N_t : M_t; M_q = me ? N_q : M_q; M_s = me ? N_s : M_s;
+            const int dr = M_t - tj, dq = M_q - qj;           // dr >= 0: the group is sorted by target position
+            const int dg = dr < dq ? dr : dq, mx = dr < dq ? dq : dr, dd = mx - dg;
+            const bool ok = (dg >= 1) & (mx <= a.max_gap) & (dd <= a.bw);
+            int pen;
+            if (TAB) {
+                const uint32_t di = (uint32_t)dd < (uint32_t)(a.bw + 1) ? (uint32_t)dd : (uint32_t)(a.bw + 1);
+                pen = pen_tab[di];
+            } else {
+                pen = dd ? (dd * a.k) / 100 + (ilog2_u32((uint32_t)dd) >> 1) : 0;
+            }
+            w = ok ? (dg < M_s ? dg : M_s) - pen : -(1 << 30);
+        };
         for (int i0 = 0; i0 < n; i0 += 64) {
-            int my_t = 0, my_q = 0, my_s = 0, my_p = -1;
-            if (i0 + lane < n) {
-                anchor_fields(a, b + i0 + lane, my_t, my_q, my_s);
-            }
+            if (i0) { N_t = P_t; N_q = P_q; N_s = P_s; }
+            load_block(i0 + 128, P_t, P_q, P_s);              // in flight during this block
+            const int N_b = N_s + 1;
             const int nb = n - i0 < 64 ? n - i0 : 64;
-            int w_cur = 0, si_cur = 0;
-            auto prepare = [&](int bb, int &w, int &si) {
-                const int ti = __builtin_amdgcn_readlane(my_t, bb), qi = __builtin_amdgcn_readlane(my_q, bb);
-                si = __builtin_amdgcn_readlane(my_s, bb);
-                const int dr = ti - R_t, dq = qi - R_q;       // dr >= 0: the group is sorted by target position
-                const int dg = dr < dq ? dr : dq, mx = dr < dq ? dq : dr, dd = mx - dg;
-                const bool ok = (dg >= 1) & (mx <= a.max_gap) & (dd <= a.bw);
-                int pen;
-                if (TAB) {
-                    const uint32_t di = (uint32_t)dd < (uint32_t)(a.bw + 1) ? (uint32_t)dd : (uint32_t)(a.bw + 1);
-                    pen = pen_tab[di];
-                } else {
-                    pen = dd ? (dd * a.k) / 100 + (ilog2_u32((uint32_t)dd) >> 1) : 0;
-                }
-                // ties go to the closest predecessor: code = 64 - distance
-                const int v = ((dg < si ? dg : si) - pen + 1024) << 6 | (int)((uint32_t)(lane - bb) & 63u);
-                w = ok ? v : -(1 << 30);
-                R_t = writelane_i32(R_t, ti, bb);
-                R_q = writelane_i32(R_q, qi, bb);
-            };
-            prepare(0, w_cur, si_cur);
-            for (int bb = 0; bb < nb; ++bb) {
-                int w_nxt, si_nxt;
-                prepare(bb + 1 < nb ? bb + 1 : bb, w_nxt, si_nxt);
-                const int best = wave_max_i32_dpp((R_f << 6) + w_cur);     // (f + sc - pen + 1024) << 6 | code
-                const int c = (best >> 6) - 1024;
-                const int bf = c > si_cur ? c : si_cur;
-                const int bp = c > si_cur ? i0 + bb - 64 + (best & 63) : -1;
-                R_f = writelane_i32(R_f, bf, bb);
-                my_p = writelane_i32(my_p, bp, bb);
-                w_cur = w_nxt; si_cur = si_nxt;
+            int O_f = 0, O_p = -1;
+            int w_cur;
+            prepare(0, w_cur);
+            for (int jl = 0; jl < nb; ++jl) {
+                const int sb = __builtin_amdgcn_readlane(M_best, jl), sp = __builtin_amdgcn_readlane(M_bp, jl);
+                const int fj = sp < 0 ? sb - 1 : sb;
+                O_f = writelane_i32(O_f, fj, jl);
+                O_p = writelane_i32(O_p, sp, jl);
+                M_best = lane == jl ? N_b : M_best;
+                M_bp = writelane_i32(M_bp, -1, jl);
+                const int cand = fj + w_cur;
+                const bool take = cand >= M_best;
+                M_best = take ? cand : M_best;
+                M_bp = take ? i0 + jl : M_bp;
+                int w_nxt;
+                prepare(jl + 1 < nb ? jl + 1 : jl, w_nxt);    // (the repeat at the block end is idempotent, its w unused)
+                w_cur = w_nxt;
             }
             if (i0 + lane < n) {
-                a.f[b + i0 + lane] = R_f;
-                a.p[b + i0 + lane] = my_p;
-                if ((a.dbg_phases & 2) && my_p >= 0)
-                    atomicMax(&a.bck[b + my_p], (unsigned long long)(uint32_t)R_f << 32 | (0xffffffffu - (uint32_t)(i0 + lane)));
+                a.f[b + i0 + lane] = O_f;
+                a.p[b + i0 + lane] = O_p;
+                if ((a.dbg_phases & 2) && O_p >= 0)
+                    atomicMax(&a.bck[b + O_p], (unsigned long long)(uint32_t)O_f << 32 | (0xffffffffu - (uint32_t)(i0 + lane)));
             }
         }
         __threadfence_block();
@@ -629,13 +639,13 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     out.pieces.alloc(ca.cap_pieces);
     out.fps.alloc(ca.cap_fps);
     ca.pieces = out.pieces.p; ca.fps = out.fps.p; ca.counters = counters.p;
-    const unsigned n_blocks = (unsigned)cdiv(G, (size_t)CHAIN_GROUPS);
+    const unsigned n_blocks = (unsigned)cdiv(G, (size_t)CHAIN_GROUPS * CHAIN_WAVES);
     {
         KTimer kt("chain");
         if (o.bandwidth + 2 <= PEN_TAB)
-            hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks ? n_blocks : 1), dim3(64), 0, stream(), ca);
+            hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks ? n_blocks : 1), dim3(64 * CHAIN_WAVES), 0, stream(), ca);
         else
-            hipLaunchKernelGGL(chain_kernel<false>, dim3(n_blocks ? n_blocks : 1), dim3(64), 0, stream(), ca);
+            hipLaunchKernelGGL(chain_kernel<false>, dim3(n_blocks ? n_blocks : 1), dim3(64 * CHAIN_WAVES), 0, stream(), ca);
     }
     HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> hc = counters.download(4);
