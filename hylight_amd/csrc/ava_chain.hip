@@ -215,6 +215,8 @@ struct ChainArgs {
     int32_t *f, *p;
     unsigned long long *bck;          // best child: f << 32 | ~index
     int *mem;                         // member lists of the chains (phase C scratch, one slot per anchor)
+    int *root;                        // chain id of every anchor (index of the chain's start inside the group)
+    unsigned long long *peak;         // per chain, at its root: best f << 32 | ~(first index reaching it)
     int k, max_gap, bw, min_score, min_cnt;
     int pb, tb, vb;                   // key layout (SeedArgs)
     uint64_t pmask;                   // (1 << pb) - 1
@@ -402,59 +404,81 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         }
         __threadfence_block();
         if (!(a.dbg_phases & 4)) continue;
-        // ---- phase C: chain starts are found 64 anchors at a time; the wave walks each chain together --------------
+        // ---- phase C: chains without walking them ------------------------------------------------------------------
+        // An anchor belongs to the chain of its parent when it is that parent's best child, else it starts a chain;
+        // parents are at most 64 back, so the chain id ("root" = index of the start) of a 64-anchor window follows
+        // from the window before it by pointer jumping inside the window (<= 6 rounds of one ds_bpermute).  C1 stores
+        // the roots and the peak of every chain (max f, first index: 64-bit atomicMax keyed by the root; the chain
+        // owning the window's best f - the long one - sends one atomic for all its lanes).  C2 then turns each chain
+        // that scores enough into its member list up to the peak, a ballot per window.
         const uint64_t key0 = a.key[b] >> a.vb;
         const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1 + a.pb));
         const uint32_t tg = (uint32_t)(key0 >> (1 + a.pb)) & ((1u << a.tb) - 1);
         const uint32_t strand = (uint32_t)(key0 >> a.pb) & 1u;
+        int prev_root = 0;                                 // roots of the window before (lane = index mod 64)
+        for (int w0 = 0; w0 < n; w0 += 64) {
+            const int i = w0 + lane;
+            const bool live = i < n;
+            int val = 0, fi = 0, pi = -1;                  // val >= 0: root; val < 0: ~lane of the parent (same window)
+            bool child = false;
+            if (live) {
+                pi = a.p[b + i];
+                fi = a.f[b + i];
+                child = pi >= 0 && (0xffffffffu - (uint32_t)(a.bck[b + pi] & 0xffffffffull)) == (uint32_t)i;
+                val = !child ? i : ~(pi - w0);
+            }
+            const int from_prev = __shfl(prev_root, (pi - w0 + 64) & 63, 64);    // every lane takes part (bpermute reads 0 from idle lanes)
+            if (child && pi < w0) val = from_prev;
+            while (__ballot(val < 0)) {
+                const int up = __shfl(val, val < 0 ? ~val : lane, 64);
+                if (val < 0) val = up;                     // parent resolved: its root; else jump to the parent's parent
+            }
+            if (live) a.root[b + i] = val;
+            prev_root = val;
+            // peaks: f << 32 | ~index, max = highest f, first index among equals
+            const uint32_t k32 = live ? (uint32_t)fi << 6 | (uint32_t)(63 - lane) : 0u;
+            const uint32_t kmax = wave_max_u32_dpp(k32);
+            const int lmax = 63 - (int)(kmax & 63u);
+            const int rmax = __builtin_amdgcn_readlane(val, lmax);
+            if (live && (val != rmax || lane == lmax))
+                atomicMax(&a.peak[b + val], (unsigned long long)(uint32_t)fi << 32 | (0xffffffffu - (uint32_t)i));
+        }
+        __threadfence_block();
         int moff = 0;                                      // member lists of the group's chains are disjoint
         for (int s0 = 0; s0 < n; s0 += 64) {
-            int ps = -1, fs = 0, fps_ = 0;
+            int ps = -1, fps_ = 0, pk_f = 0, pk_i = 0;
             bool cand = false;
             if (s0 + lane < n) {
                 const int s = s0 + lane;
-                ps = a.p[b + s];
-                fs = a.f[b + s];
-                bool start = true;
-                if (ps >= 0) {
-                    start = (0xffffffffu - (uint32_t)(a.bck[b + ps] & 0xffffffffull)) != (uint32_t)s;
-                    fps_ = a.f[b + ps];
+                if (a.root[b + s] == s) {
+                    ps = a.p[b + s];
+                    if (ps >= 0) fps_ = a.f[b + ps];
+                    const unsigned long long pk = a.peak[b + s];
+                    pk_f = (int)(pk >> 32);
+                    pk_i = (int)(0xffffffffu - (uint32_t)(pk & 0xffffffffull));
+                    // a childless start is a one-anchor chain: it can only survive when min_cnt <= 1
+                    cand = pk_f - fps_ >= a.min_score && (a.min_cnt <= 1 || a.bck[b + s] != 0);
                 }
-                // a childless start is a one-anchor chain: it can only survive when min_cnt <= 1
-                cand = start && (a.min_cnt <= 1 || a.bck[b + s] != 0);
             }
             unsigned long long cm = __ballot(cand);
+            if (a.dbg_phases & 8) cm = 0;
             while (cm) {
                 const int l = __ffsll((long long)cm) - 1;
                 cm &= cm - 1;
                 const int s = s0 + l;
-                const int ps_s = __builtin_amdgcn_readlane(ps, l), f_s = __builtin_amdgcn_readlane(fs, l),
-                          f_ps = __builtin_amdgcn_readlane(fps_, l);
-                // walk 1: member list (into mem[moff..]) and the peak
-                int len = 1, best_len = 1, cur = s, best_f = f_s;
+                const int peak_i = __builtin_amdgcn_readlane(pk_i, l);
+                // member list up to the peak: one ballot per window between the start and the peak
                 int *mem = a.mem + b + moff;
-                int wbase = -(1 << 30), pend = 0;                  // pend: members gathered in `mreg`, not stored yet
-                unsigned long long wbck = 0;
-                int mreg = 0;
-                while (true) {
-                    if (lane == (pend & 63)) mreg = cur;            // member #pend of this 64-batch
-                    ++pend;
-                    if ((pend & 63) == 0) mem[pend - 64 + lane] = mreg;
-                    if (cur < wbase || cur >= wbase + 64) {
-                        wbase = cur;
-                        wbck = cur + lane < n ? a.bck[b + cur + lane] : 0ull;
-                    }
-                    const unsigned long long bc = rl64(wbck, cur - wbase);
-                    if (!bc) break;
-                    cur = (int)(0xffffffffu - (uint32_t)(bc & 0xffffffffull));
-                    ++len;
-                    const int fc = (int)(bc >> 32);            // = f[cur]
-                    if (fc > best_f) { best_f = fc; best_len = len; }
+                int best_len = 0;
+                for (int w0 = s0; w0 <= peak_i; w0 += 64) {
+                    const int i = w0 + lane;
+                    const bool in = i <= peak_i && a.root[b + i] == s;          // peak_i < n
+                    const unsigned long long mm = __ballot(in);
+                    if (in) mem[best_len + __popcll(mm & ((1ull << lane) - 1ull))] = i;
+                    best_len += __popcll(mm);
                 }
-                if ((pend & 63) && lane < (pend & 63)) mem[(pend & ~63) + lane] = mreg;
-                moff += len;
-                const int sc = best_f - (ps_s >= 0 ? f_ps : 0);
-                if (sc < a.min_score || best_len < a.min_cnt) continue;
+                moff += best_len;
+                if (best_len < a.min_cnt || (a.dbg_phases & 16)) continue;
                 __threadfence_block();
                 uint32_t np = 0, nf = 0;
                 emit_chain<false>(a, b, lane, mem, s, best_len, qg, tg, strand, np, nf, 0, 0);
@@ -628,8 +652,10 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     counters.zero();
     ChainArgs ca{};
     ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.n_groups = G; ca.n_anchors = A;
-    DBuf<int> mem(A);
-    ca.f = f.p; ca.p = p.p; ca.bck = bck.p; ca.mem = mem.p;
+    DBuf<int> mem(A), root(A);
+    DBuf<unsigned long long> peak(A);
+    peak.zero();
+    ca.f = f.p; ca.p = p.p; ca.bck = bck.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
