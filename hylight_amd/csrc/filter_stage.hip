@@ -270,53 +270,82 @@ __global__ void pair_order_select_kernel(const PafRec *recs, uint32_t *grows /* 
 // ---------------------------------------------------------------------------------------
 // a5: events
 // ---------------------------------------------------------------------------------------
-__global__ void snp_count_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows, const uint8_t *sel,
-                                 size_t n, int long_mode, uint32_t *n_ev, uint32_t *n_iv) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t ne = 0, ni = 0;
-    if (sel[i]) {
-        const PafRec &r = recs[grows[i]];
-        const uint32_t *o = ops + r.cig_off;
-        for (uint32_t k = 0; k < r.cig_n; ++k) ne += ((o[k] & 15u) == OP_X) ? 1u : 0u;
-        if (long_mode) ne *= 2;
-        ni = (r.ts < r.te ? 1u : 0u) + ((long_mode && r.qs < r.qe) ? 1u : 0u);
+// One wavefront per row: the CIGAR is read 64 ops at a time (coalesced), the positions before each op come from
+// wave prefix sums, every 'X' lane writes its own events.
+__device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, o, 64);
+        if (lane >= o) v += u;
     }
-    n_ev[i] = ne;
-    n_iv[i] = ni;
+    return v;
 }
 
-__global__ void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows, const uint8_t *sel,
-                                size_t n, int long_mode, const uint32_t *ev_off, const uint32_t *iv_off,
-                                uint32_t *ev_chunk, uint64_t *ev_key, uint32_t *ev_partner, uint32_t *iv_chunk,
-                                uint64_t *iv_skey, uint64_t *iv_ekey) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n || !sel[i]) return;
-    const PafRec &r = recs[grows[i]];
-    uint32_t w = iv_off[i];
-    if (r.ts < r.te) {
-        iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.tid << 32 | r.ts; iv_ekey[w] = (uint64_t)r.tid << 32 | r.te; ++w;
+__global__ __launch_bounds__(WG) void snp_count_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
+                                                        const uint8_t *sel, size_t n, int long_mode, uint32_t *n_ev,
+                                                        uint32_t *n_iv) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t i = wave; i < n; i += n_waves) {
+        uint32_t ne = 0, ni = 0;
+        if (sel[i]) {
+            const PafRec &r = recs[grows[i]];
+            const uint32_t *o = ops + r.cig_off;
+            for (uint32_t k0 = 0; k0 < r.cig_n; k0 += 64)
+                ne += (uint32_t)__popcll(__ballot(k0 + lane < r.cig_n && (o[k0 + lane] & 15u) == OP_X));
+            if (long_mode) ne *= 2;
+            ni = (r.ts < r.te ? 1u : 0u) + ((long_mode && r.qs < r.qe) ? 1u : 0u);
+        }
+        if (lane == 0) { n_ev[i] = ne; n_iv[i] = ni; }
     }
-    if (long_mode && r.qs < r.qe) {
-        iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.qid << 32 | r.qs; iv_ekey[w] = (uint64_t)r.qid << 32 | r.qe;
-    }
-    const bool rev = r.flags & PF_REV;
-    uint32_t p1 = rev ? r.qlen - r.qe : r.qs;   // slr2:334
-    uint32_t p2 = r.ts;                         // slr2:336
-    uint32_t e = ev_off[i];
-    const uint32_t *o = ops + r.cig_off;
-    for (uint32_t k = 0; k < r.cig_n; ++k) {
-        uint32_t len = o[k] >> 4, code = o[k] & 15u;
-        if (code == OP_EQ) { p1 += len; p2 += len; }
-        else if (code == OP_I) p1 += len;
-        else if (code == OP_D) p2 += len;
-        else if (code == OP_X) {
-            p1 += len; p2 += len;
-            if (long_mode) {
-                uint32_t qp = rev ? r.qlen - p1 + 1 : p1;   // slr2:357
-                ev_chunk[e] = r.chunk; ev_key[e] = (uint64_t)r.qid << 32 | qp; ev_partner[e] = r.tid; ++e;
+}
+
+__global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
+                                                       const uint8_t *sel, size_t n, int long_mode, const uint32_t *ev_off,
+                                                       const uint32_t *iv_off, uint32_t *ev_chunk, uint64_t *ev_key,
+                                                       uint32_t *ev_partner, uint32_t *iv_chunk, uint64_t *iv_skey,
+                                                       uint64_t *iv_ekey) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t i = wave; i < n; i += n_waves) {
+        if (!sel[i]) continue;
+        const PafRec r = recs[grows[i]];
+        if (lane == 0) {
+            uint32_t w = iv_off[i];
+            if (r.ts < r.te) {
+                iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.tid << 32 | r.ts; iv_ekey[w] = (uint64_t)r.tid << 32 | r.te; ++w;
             }
-            ev_chunk[e] = r.chunk; ev_key[e] = (uint64_t)r.tid << 32 | p2; ev_partner[e] = r.qid; ++e;
+            if (long_mode && r.qs < r.qe) {
+                iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.qid << 32 | r.qs; iv_ekey[w] = (uint64_t)r.qid << 32 | r.qe;
+            }
+        }
+        const bool rev = r.flags & PF_REV;
+        uint32_t p1 = rev ? r.qlen - r.qe : r.qs;   // slr2:334   (positions after the ops handled so far)
+        uint32_t p2 = r.ts;                         // slr2:336
+        uint32_t e = ev_off[i];
+        const uint32_t *o = ops + r.cig_off;
+        for (uint32_t k0 = 0; k0 < r.cig_n; k0 += 64) {
+            uint32_t len = 0, code = 0;
+            if (k0 + lane < r.cig_n) { const uint32_t op = o[k0 + lane]; len = op >> 4; code = op & 15u; }
+            const bool isx = code == OP_X;
+            const uint32_t d1 = (code == OP_EQ || code == OP_I || isx) ? len : 0u;
+            const uint32_t d2 = (code == OP_EQ || code == OP_D || isx) ? len : 0u;
+            const uint32_t s1 = wave_incl_sum_u32(d1, lane), s2 = wave_incl_sum_u32(d2, lane);
+            const unsigned long long xm = __ballot(isx);
+            if (isx) {
+                const uint32_t q1 = p1 + s1, q2 = p2 + s2;              // positions after this op
+                uint32_t at = e + (uint32_t)__popcll(xm & ((1ull << lane) - 1ull)) * (long_mode ? 2u : 1u);
+                if (long_mode) {
+                    const uint32_t qp = rev ? r.qlen - q1 + 1 : q1;    // slr2:357
+                    ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.qid << 32 | qp; ev_partner[at] = r.tid; ++at;
+                }
+                ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.tid << 32 | q2; ev_partner[at] = r.qid;
+            }
+            p1 += (uint32_t)__shfl((int)s1, 63, 64);
+            p2 += (uint32_t)__shfl((int)s2, 63, 64);
+            e += (uint32_t)__popcll(xm) * (long_mode ? 2u : 1u);
         }
     }
 }
@@ -407,9 +436,20 @@ std::vector<uint64_t> make_windows(const std::vector<uint64_t> &chunk_row_start,
 }  // namespace
 
 namespace {
+// rows come chunk by chunk: a wave whose rows share one chunk adds its sum with one atomic
 __global__ void chunk_ops_kernel(const PafRec *recs, size_t n, unsigned long long *ops_of_chunk) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n && recs[i].cig_n) atomicAdd(&ops_of_chunk[recs[i].chunk], (unsigned long long)recs[i].cig_n);
+    const bool live = i < n;
+    const uint32_t c = live ? recs[i].chunk : 0xffffffffu;
+    unsigned long long v = live ? recs[i].cig_n : 0;
+    const uint32_t c0 = (uint32_t)__shfl((int)c, 0, 64);
+    if (__all(!live || c == c0)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&ops_of_chunk[c0], v);
+    } else if (live && v) {
+        atomicAdd(&ops_of_chunk[c], v);
+    }
 }
 }  // namespace
 
@@ -509,7 +549,8 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
 
     // ---- a5: events + intervals -------------------------------------------------------------------
     DBuf<uint32_t> n_ev(m), n_iv(m), ev_off(m), iv_off(m);
-    hipLaunchKernelGGL(snp_count_kernel, grid1(m), dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm, n_ev.p,
+    const dim3 rows_grid((unsigned)std::min<size_t>(cdiv(m ? m : 1, WG / 64), 65536));    // one wave per row, grid-stride
+    hipLaunchKernelGGL(snp_count_kernel, rows_grid, dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm, n_ev.p,
                        n_iv.p);
     exclusive_scan_u32(n_ev.p, ev_off.p, m);
     exclusive_scan_u32(n_iv.p, iv_off.p, m);
@@ -521,7 +562,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     if (E) {
         DBuf<uint32_t> ev_chunk(E), ev_partner(E), iv_chunk(I ? I : 1);
         DBuf<uint64_t> ev_key(E), iv_skey(I ? I : 1), iv_ekey(I ? I : 1);
-        hipLaunchKernelGGL(snp_fill_kernel, grid1(m), dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm,
+        hipLaunchKernelGGL(snp_fill_kernel, rows_grid, dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm,
                            ev_off.p, iv_off.p, ev_chunk.p, ev_key.p, ev_partner.p, iv_chunk.p, iv_skey.p, iv_ekey.p);
         SortedCK sev, sis, sie;
         sort_chunk_key(ev_chunk.p, ev_key.p, E, n_chunks, sev);
