@@ -76,6 +76,26 @@ def pmc_traffic(timer, workload):
     return k["hbm_bytes_per_launch"] if k else None
 
 
+def pmc_valu(timer, workload):
+    """What the kernel behind `timer` is really bound by (chain and banded DP are VALU work): the share
+    of the SIMDs' vector-issue cycles it uses, from the committed SQ counter pass (profiles/*_sq_counters.json,
+    tools/summarize_sq.py; SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)).  C2 only."""
+    if workload != "C2":
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    name = KERNEL_OF_TIMER.get(timer, "")
+    k = next((v for n, v in d.items() if n.startswith(name)), None)
+    if not k or not k.get("GRBM_GUI_ACTIVE"):
+        return None
+    busy = k["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0)
+    return dict(valu_issue_frac=round(busy, 4), valu_insts_per_launch=k.get("SQ_INSTS_VALU", 0.0) / max(k.get("launches", 1), 1),
+                source=os.path.basename(files[-1]))
+
+
 def cpu_baseline(fa, nsplit, budget_s=25.0):
     """Oracle (CPU port) timed on a bounded sample of the same workload: as many --nsplit target chunks
     (each vs ALL query reads, exactly like one reference worker) as fit the budget, one process per
@@ -191,15 +211,19 @@ def main():
     dom = max(kms, key=kms.get)
     # algorithmic bytes per kernel for the whole step (DESIGN.md "Algorithmic bytes")
     A, P = stats.get("anchors", 0.0), stats.get("pieces", 0.0)
+    AB = stats.get("anchor_bytes", 16 * A)             # 8 B per anchor when a batch packs them into one word, else 16
+    M = stats.get("sketch_minimizers", 0.0)
     algo = {
-        "chain": 16 * A + 8 * A + 8 * A + 4 * A,       # read anchors (16 B); write f,p (8 B), best child (8 B), member list (4 B)
+        # every anchor read once, the alignment pieces (32 B) and their fixed points (8 B) written once; the DP's
+        # own arrays (f, p, best child, chain id, peak, member list: 36 B per anchor) are scratch, not counted
+        "chain": AB + 32 * P + 8 * stats.get("fixed_points", 0.0),
         "align_narrow": stats.get("align_bases_narrow", 0.0) + 4 * stats.get("cigar_ops", 0.0) + 32 * stats.get("align_tasks_narrow", 0.0),
         "align_wide": stats.get("align_bases_wide", 0.0) + 32 * stats.get("align_tasks_wide", 0.0),
         "align_classify": stats.get("align_bases_classify", 0.0) + (32 + 24 + 1) * stats.get("align_tasks", 0.0),
-        "anchor_sort": 32 * A,                         # one read + one write of 16 B per anchor
-        "seed_fill": 16 * stats.get("sketch_minimizers", 0.0) / 2 + 8 * A + 16 * A,
-        "seed_count": 16 * stats.get("sketch_minimizers", 0.0) / 2 + 8 * A,
-        "sketch_kmer_window": stats.get("sketch_bases", 0.0) * 1 + 16 * stats.get("sketch_minimizers", 0.0),
+        "anchor_sort": 2 * AB,                         # one read + one write per anchor
+        "seed_fill": 16 * M / 2 + 8 * A + AB,          # query minimizers, index occurrences (y), anchors out
+        "seed_count": 16 * M / 2 + 4 * A,              # query minimizers, rank/frequency word of every occurrence
+        "sketch_kmer_window": stats.get("sketch_bases", 0.0) * 1 + 16 * M,
     }
     launches = max(kn.get(dom, 1.0), 1.0)
     avg_ms = kms[dom] / launches
@@ -207,7 +231,7 @@ def main():
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                 traffic=pmc_traffic(dom, args.workload), algorithmic_bytes_per_launch=bytes_per_launch,
-                avg_launch_ms=avg_ms, launches_per_step=launches,
+                avg_launch_ms=avg_ms, launches_per_step=launches, valu=pmc_valu(dom, args.workload),
                 kernel_ms_per_step={k: round(v, 3) for k, v in sorted(kms.items(), key=lambda kv: -kv[1])})
 
     line = dict(metric="long-read all-vs-all overlaps/sec", value=value, unit="overlaps/s", n_gpus=world,

@@ -126,6 +126,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
             seed_and_chain(in, ix, o, plan, qlen.p, tlen.p, q, hi, ch, st);
         }
         stat_add("pieces", (double)ch.n_pieces);
+        stat_add("fixed_points", (double)ch.n_fp);
         if (ch.n_pieces) {
             AlignOut ao;
             HostTimer ht("align_pieces");

@@ -23,9 +23,7 @@ namespace hlmi {
 namespace {
 constexpr int WG = 256;
 constexpr int WAVES = WG / 64;
-constexpr int TB_ROWS = 257;
 constexpr int SEQ_T_MAX = EXT_MAX + BAND_W;     // 320
-constexpr int UNIT_MAX = EXT_MAX + SEQ_T_MAX + 16;
 constexpr int NR_SHORT = 128;                   // rows of an align_narrow_kernel<NR_SHORT> task; longer near-diagonal
                                                 // blocks (3-4 % of them) run in the <BLOCK_MAX> instance with twice the LDS
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
@@ -171,160 +169,6 @@ __device__ __forceinline__ uint32_t load_window4(const uint8_t *codes, long long
     uint32_t v = down ? __builtin_bswap32(load_codes4(codes, a0 - x - 3, total)) : load_codes4(codes, a0 + x, total);
     if (comp) v = comp_codes4(v);
     return v;
-}
-
-__global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
-    __shared__ unsigned long long s_tb[WAVES][TB_ROWS][4];
-    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][EXT_MAX];
-    __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][SEQ_T_MAX];
-    __shared__ uint8_t s_u[WAVES][UNIT_MAX];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
-    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    unsigned long long(*tb)[4] = s_tb[wv];
-    uint8_t *sq = s_q[wv], *st = s_t[wv], *su = s_u[wv];
-    uint32_t chunk_off = 0, chunk_left = 0;
-    for (size_t li = wave; li < a.n_list; li += n_waves) {
-        const size_t ti = a.list[li];
-        const Task tk = a.tasks[ti];
-        TaskOut res{0, 0, 0, 0, 0, 0};
-        const int n = tk.n;
-        // rows i > n - dlo have no cell inside the band (j = i + dlo + lane > n): an extension whose query
-        // side is longer than the target side + half band never looks at them
-        const int m = tk.m < n - tk.dlo ? tk.m : n - tk.dlo;
-        if (m <= 0 || n <= 0) {
-            if (lane == 0) a.out[ti] = res;
-            continue;
-        }
-        // ---- stage the two windows in LDS (DP order), 4 bases per lane and step ----------------------------------
-        {
-            const bool rev = (tk.kind & TASK_REV) != 0, left = (tk.kind & 3) == 1;
-            uint32_t vq = 0, vt[2] = {0, 0};
-            if (4 * lane < m) vq = load_window4(a.qcodes, a.q_total, (long long)tk.qa, left != rev, rev, 4 * lane);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                if (4 * (lane + 64 * r) < n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)tk.ta, left, false, 4 * (lane + 64 * r));
-            if (4 * lane < m) *(uint32_t *)(sq + 4 * lane) = vq;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                if (4 * (lane + 64 * r) < n) *(uint32_t *)(st + 4 * (lane + 64 * r)) = vt[r];
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        // ---- DP ------------------------------------------------------------------------------------------------
-        const int dlo = tk.dlo, go = a.go, ge = a.ge;
-        const int kind = tk.kind & 3;
-        const int end_row = kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
-        int Hp = NEG_INF, Fp = NEG_INF;
-        unsigned long long best = 0;
-        for (int i = 0; i <= m; ++i) {
-            const int j = i + dlo + lane;
-            const bool valid = j >= 0 && j <= n;
-            const int Hup = wave_shl1(Hp, NEG_INF), Fup = wave_shl1(Fp, NEG_INF);   // lane d+1 of the previous row
-            int mm = NEG_INF, f = NEG_INF;
-            bool flagF = false;
-            if (valid && i > 0) {
-                if (j > 0) {
-                    const int qa = sq[i - 1], tb2 = st[j - 1];
-                    const int s = (qa > 3 || tb2 > 3) ? -a.ambi : (qa == tb2 ? a.match : -a.mismatch);
-                    mm = Hp + s;
-                }
-                if (lane < 63) {
-                    const int fo = Hup - go - ge, fe = Fup - ge;
-                    if (fo >= fe) f = fo; else { f = fe; flagF = true; }
-                }
-            }
-            int ht = mm > f ? mm : f;
-            if (i == 0 && j == 0) ht = 0;
-            if (!valid) ht = NEG_INF;
-            const int pm = wave_shr1(wave_prefix_max_incl_dpp(ht + ge * lane), NEG_INF * 2);
-            int e = NEG_INF;
-            if (valid && j > 0 && lane > 0) e = pm - go - ge * lane;
-            int h, src;
-            if (i == 0 && j == 0) { h = 0; src = 0; }
-            else if (mm >= e && mm >= f) { h = mm; src = 0; }
-            else if (e >= f) { h = e; src = 1; }
-            else { h = f; src = 2; }
-            if (!valid) { h = NEG_INF; f = NEG_INF; e = NEG_INF; }
-            const int Hl = wave_shr1(h, NEG_INF), El = wave_shr1(e, NEG_INF);
-            const bool flagE = lane > 0 && !(Hl - go - ge >= El - ge);
-            const unsigned long long b0 = __ballot(src & 1), b1 = __ballot(src & 2), b2 = __ballot(flagE), b3 = __ballot(flagF);
-            if (lane == 0) { tb[i][0] = b0; tb[i][1] = b1; tb[i][2] = b2; tb[i][3] = b3; }
-            if (kind != 0 && valid && h > NEG_INF / 2) {
-                // cells in the row that reaches the query end are ranked with the end bonus (ksw2 --end-bonus)
-                const int hb = h + (i == end_row ? a.end_bonus : 0);
-                const unsigned long long key = (unsigned long long)(uint32_t)(hb + (1 << 20)) << 32 |
-                                               (unsigned long long)(0xffffu - (uint32_t)(i + j)) << 16 |
-                                               (unsigned long long)(0xffffu - (uint32_t)i);
-                best = key > best ? key : best;
-            }
-            Hp = h;
-            Fp = f;
-        }
-        int ei, ej, score;
-        if (kind == 0) {
-            ei = m; ej = n;
-            score = __shfl(Hp, n - m - dlo, 64);
-        } else {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                unsigned long long u = __shfl_xor(best, o, 64);
-                best = u > best ? u : best;
-            }
-            ei = (int)(0xffffu - (uint32_t)(best & 0xffff));
-            ej = (int)(0xffffu - (uint32_t)((best >> 16) & 0xffff)) - ei;
-            score = (int)(uint32_t)(best >> 32) - (1 << 20) - (ei == end_row ? a.end_bonus : 0);   // the bonus only ranks
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        // ---- traceback + run-length encoding by lane 0 --------------------------------------------------------
-        if (lane == 0) {
-            int i = ei, j = ej, state = 0, nr = 0;
-            while (i > 0 || j > 0) {
-                const int d = j - i - dlo;
-                const unsigned long long bit = 1ull << d;
-                if (state == 0) {
-                    const int src = ((tb[i][0] & bit) ? 1 : 0) | ((tb[i][1] & bit) ? 2 : 0);
-                    if (src == 0) {
-                        su[nr++] = sq[i - 1] == st[j - 1] ? (uint8_t)OP_EQ : (uint8_t)OP_X;
-                        --i; --j;
-                    } else state = src;
-                } else if (state == 1) {
-                    su[nr++] = (uint8_t)OP_D;
-                    if (!(tb[i][2] & bit)) state = 0;
-                    --j;
-                } else {
-                    su[nr++] = (uint8_t)OP_I;
-                    if (!(tb[i][3] & bit)) state = 0;
-                    --i;
-                }
-            }
-            // forward order: blocks and right extensions reverse the emission order, left extensions keep it
-            const bool fwd = kind == 1;
-            uint32_t n_runs = 0;
-            for (int x = 0; x < nr; ++x) {
-                const int y = fwd ? x : nr - 1 - x, yp = fwd ? x - 1 : nr - x;
-                if (x == 0 || su[y] != su[yp]) ++n_runs;
-            }
-            uint32_t off = 0;
-            bool ok = true;
-            if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
-            if (ok && n_runs) {
-                uint32_t w = off, len = 0;
-                uint8_t code = 0;
-                for (int x = 0; x < nr; ++x) {
-                    const uint8_t c = su[fwd ? x : nr - 1 - x];
-                    if (x && c != code) { a.runs[w++] = len << 4 | code; len = 0; }
-                    code = c;
-                    ++len;
-                }
-                a.runs[w++] = len << 4 | code;
-            }
-            res.score = score; res.bi = ei; res.bj = ej; res.runs_off = off; res.n_runs = ok ? n_runs : 0; res.pad = 2u | ((uint32_t)m & 0xfffffu) << 2 | (kind != 0 && ei == end_row ? 0x80000000u : 0u);
-            a.out[ti] = res;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
 }
 
 // ---- pass 1: classification + diagonal fast path, one lane per task --------------------------------
@@ -512,7 +356,9 @@ struct NarrowWalk {
     const uint32_t *pl;                     // planes of this wave: word (plane, chunk, lane) at (plane * chunks + chunk) * 64 + lane
     int chunks;
     int lb;                                 // first lane of the group
-    int m, n, dlo;
+    int m, n, dlo;                          // the walk starts at cell (m, n)
+    int wmask;                              // band width - 1
+    bool keep_order;                        // left extensions: the reversed sequences make end -> start the forward order
     __device__ __forceinline__ uint32_t word(int plane, int c, int lane) const { return pl[(plane * chunks + c) * 64 + lane]; }
 };
 // Traceback of one task by one lane.  Emits the runs in reverse (end -> start); with `out` they are written to
@@ -523,12 +369,12 @@ __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t tot
     uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
     auto emit = [&](uint32_t op, uint32_t len) {
         if (op == cur_op) { cur_len += len; return; }
-        if (cur_len) { if (out) out[total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
+        if (cur_len) { if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
         cur_op = op; cur_len = len;
     };
-    for (int it = 0; (i > 0 || j > 0) && it < 4 * (BLOCK_MAX + NARROW_W); ++it) {
+    for (int it = 0; (i > 0 || j > 0) && it < 4 * (EXT_MAX + SEQ_T_MAX); ++it) {
         if (i == 0) { emit(OP_D, (uint32_t)j); j = 0; break; }       // row 0: H(0,j) is a gap from the corner
-        const int d = w.lb + ((j - i - w.dlo) & (NARROW_W - 1));
+        const int d = w.lb + ((j - i - w.dlo) & w.wmask);
         const int c = (i - 1) >> 5, sh = 31 - ((i - 1) & 31);          // row i = bit sh of word c; row i-1 = bit sh+1
         if (state == 0) {
             const uint32_t inv = ~(w.word(PL_DIAG, c, d) >> sh);         // bit 0 = row i, bit 1 = row i-1, ... zeros above
@@ -559,7 +405,7 @@ __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t tot
             --i;
         }
     }
-    if (cur_len) { if (out) out[total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
+    if (cur_len) { if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
     return n_runs;
 }
 
@@ -663,13 +509,160 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         if (live && l == 0) {
-            const NarrowWalk w{&pl[0][0][0], NR_CHUNKS, g * 16, m, n, dlo};
+            const NarrowWalk w{&pl[0][0][0], NR_CHUNKS, g * 16, m, n, dlo, NARROW_W - 1, false};
             const uint32_t n_runs = narrow_walk(w, nullptr, 0);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
             if (ok && n_runs) narrow_walk(w, a.runs + off, n_runs);
             a.out[ti] = TaskOut{score, m, n, off, ok ? n_runs : 0, 2u | (uint32_t)m << 2};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- pass 2b: the 64-diagonal band (wide blocks, end extensions), one task per wave ------------------------------
+// Same scheme as align_narrow_kernel with the whole wave as one band: bit planes per lane, no validity masks in
+// the recurrences.  Extensions additionally rank their cells (best score, then fewest bases, ksw2 end bonus on the
+// row that reaches the query end): along one diagonal "fewest bases" is "first row", so every lane keeps its first
+// best row and the 64 lanes are compared once at the end; only there the cells outside 0 <= j <= n are masked.
+constexpr int WT_PAD = 64;                                  // st index of target offset 0 (dlo >= -51)
+constexpr int WT_LEN = WT_PAD + SEQ_T_MAX + 64;
+constexpr int W_CHUNKS = EXT_MAX / 32;
+
+template <bool AMBI, bool EXT>
+__device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int dlo, int lane, int end_row,
+                                          const uint8_t *sq, const uint8_t *st, uint32_t (*pl)[W_CHUNKS][64], int &Hend,
+                                          int &best_h, int &best_i) {
+    const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * lane, goel = go + ge * lane;
+    const int j0 = dlo + lane;
+    int H = j0 == 0 ? 0 : (j0 > 0 ? -(go + ge * j0) : NEG_INF);       // row 0
+    int G = H - goe;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    const uint8_t *tp = st + WT_PAD + dlo + lane - 1;                 // target base of row i: tp[i]
+    // cell (i, j) is inside the rectangle for imin <= i <= imax (j = i + dlo + lane)
+    const int imin = -j0, span = n - j0 - imin;                       // span < 0: never
+    best_h = NEG_INF; best_i = 0;
+    if (EXT && j0 >= 0 && j0 <= n) best_h = H;                        // row 0 (only (0,0) can win, the rest is a gap from it)
+    int qa = sq[0], t2 = tp[1];
+    for (int i = 1; i <= m; ++i) {
+        const int qa_next = sq[i], t2_next = tp[i + 1];
+        const bool ne = qa != t2;
+        int s = ne ? -a.mismatch : a.match;
+        if (AMBI) s = (qa | t2) > 3 ? -a.ambi : s;
+        const int mm = H + s;
+        const int f = wave_shl1(G, NEG_INF);
+        const int ht = mm > f ? mm : f;
+        const int e = wave_shr1(wave_prefix_max_incl_dpp(ht + gel), NEG_INF * 2) - goel;
+        const int h = ht > e ? ht : e;
+        const int fo = h - goe, fe = f - ge;
+        a0 = shift_in(a0, mm == h);
+        a1 = shift_in(a1, e >= f);
+        a2 = shift_in(a2, e + go > h);
+        a3 = shift_in(a3, fe > fo);
+        a4 = shift_in(a4, ne);
+        G = fo > fe ? fo : fe;
+        H = h;
+        qa = qa_next; t2 = t2_next;
+        if (EXT) {
+            const int hb = h + (i == end_row ? a.end_bonus : 0);
+            if ((uint32_t)(i - imin) <= (uint32_t)span && span >= 0 && hb > best_h) { best_h = hb; best_i = i; }
+        }
+        if ((i & 31) == 0) {
+            const int c = (i >> 5) - 1;
+            pl[PL_DIAG][c][lane] = a0; pl[PL_EGEF][c][lane] = a1; pl[PL_EEXT][c][lane] = a2; pl[PL_FEXT][c][lane] = a3;
+            pl[PL_NE][c][lane] = a4;
+        }
+    }
+    Hend = H;
+    if (m & 31) {
+        const int c = m >> 5, up = 32 - (m & 31);
+        pl[PL_DIAG][c][lane] = a0 << up; pl[PL_EGEF][c][lane] = a1 << up; pl[PL_EEXT][c][lane] = a2 << up;
+        pl[PL_FEXT][c][lane] = a3 << up; pl[PL_NE][c][lane] = a4 << up;
+    }
+}
+
+__global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
+    __shared__ uint32_t s_pl[WAVES][N_PLANES][W_CHUNKS][64];
+    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][EXT_MAX + 4];
+    __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][WT_LEN];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t (*pl)[W_CHUNKS][64] = s_pl[wv];
+    uint8_t *sq = s_q[wv], *st = s_t[wv];
+    uint32_t chunk_off = 0, chunk_left = 0;
+    for (size_t li = wave; li < a.n_list; li += n_waves) {
+        const size_t ti = a.list[li];
+        const Task tk = a.tasks[ti];
+        const int n = tk.n, dlo = tk.dlo;
+        // rows i > n - dlo have no cell inside the band (j = i + dlo + lane > n): an extension whose query
+        // side is longer than the target side + half band never looks at them
+        const int m = tk.m < n - dlo ? tk.m : n - dlo;
+        if (m <= 0 || n <= 0) {
+            if (lane == 0) a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
+            continue;
+        }
+        const int kind = tk.kind & 3;
+        bool ambig = false;
+        {   // stage the two windows (DP order), 4 bases per lane and step
+            const bool rev = (tk.kind & TASK_REV) != 0, left = kind == 1;
+            uint32_t vq = 0, vt[2] = {0, 0};
+            if (4 * lane < m) vq = load_window4(a.qcodes, a.q_total, (long long)tk.qa, left != rev, rev, 4 * lane);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (4 * (lane + 64 * r) < n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)tk.ta, left, false, 4 * (lane + 64 * r));
+            if (4 * lane < m) { *(uint32_t *)(sq + 4 * lane) = vq; ambig |= (vq & 0x04040404u) != 0; }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (4 * (lane + 64 * r) < n) {
+                    *(uint32_t *)(st + WT_PAD + 4 * (lane + 64 * r)) = vt[r];
+                    ambig |= (vt[r] & 0x04040404u) != 0;
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int end_row = kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
+        int Hend = NEG_INF, best_h = NEG_INF, best_i = 0;
+        const bool amb = __any(ambig);
+        if (kind == 0) {
+            if (amb) wide_rows<true, false>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            else wide_rows<false, false>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+        } else {
+            if (amb) wide_rows<true, true>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            else wide_rows<false, true>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+        }
+        int ei, ej, score;
+        if (kind == 0) {
+            ei = m; ej = n;
+            score = __shfl(Hend, n - m - dlo, 64);
+        } else {
+            // best cell: score (with the bonus), then fewest bases i + j, then fewest rows
+            unsigned long long best = 0;
+            if (best_h > NEG_INF / 2)
+                best = (unsigned long long)(uint32_t)(best_h + (1 << 20)) << 32 |
+                       (unsigned long long)(0xffffu - (uint32_t)(2 * best_i + dlo + lane)) << 16 |
+                       (unsigned long long)(0xffffu - (uint32_t)best_i);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long u = __shfl_xor(best, o, 64);
+                best = u > best ? u : best;
+            }
+            ei = (int)(0xffffu - (uint32_t)(best & 0xffff));
+            ej = (int)(0xffffu - (uint32_t)((best >> 16) & 0xffff)) - ei;
+            score = (int)(uint32_t)(best >> 32) - (1 << 20) - (ei == end_row ? a.end_bonus : 0);   // the bonus only ranks
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const NarrowWalk w{&pl[0][0][0], W_CHUNKS, 0, ei, ej, dlo, BAND_W - 1, kind == 1};
+            const uint32_t n_runs = narrow_walk(w, nullptr, 0);
+            uint32_t off = 0;
+            bool ok = true;
+            if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
+            if (ok && n_runs) narrow_walk(w, a.runs + off, n_runs);
+            a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0,
+                                2u | ((uint32_t)m & 0xfffffu) << 2 | (kind != 0 && ei == end_row ? 0x80000000u : 0u)};
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -621,6 +621,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     exclusive_scan_u32_to_u64(cnt, aoff.p, sa.n_mz);
     const size_t A = (size_t)(download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt + (sa.n_mz - 1)));
     st.anchors += A;
+    stat_add("anchor_bytes", (double)A * (vb ? 8.0 : 16.0));
     if (!A) return;
     if (A >= (1ull << 32)) fail(HLMI_EINVAL, "anchor batch too large");
     HostTimer *ht_s = new HostTimer("seed_sort_phase");
