@@ -225,7 +225,7 @@ struct ChainArgs {
     Piece *pieces;
     FixPt *fps;
     uint32_t cap_pieces, cap_fps;
-    uint32_t *counters;               // [0] pieces, [1] fixed points, [2] overflow flag
+    uint32_t *counters;               // [0] pieces, [1] fixed-point slots reserved, [2] overflow flag, [3] fixed points written
     int dbg_phases;                   // timing ablation only (HLMI_CHAIN_PHASES): 1 = A, 3 = A+B, 7 = all
 };
 
@@ -252,13 +252,22 @@ __device__ __forceinline__ unsigned long long rl64(unsigned long long v, int l) 
 // Fixed-point selection over the member list mem[0..len) of one chain (oracle/ava_oracle.c:align_chain).
 // 64 members at a time sit in registers; the next fixed point = first later member that is >= BLOCK_MIN away
 // in both sequences (or the last member) comes from one ballot instead of a scan over ~16 anchors.
-template <bool WRITE>
+// One pass: the fixed points go into a range reserved for the worst case (a chain of len members has at most
+// 2 * len of them: one per member plus one more per piece), every piece takes its slot when it closes.
 __device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *mem, int s, int len, uint32_t q, uint32_t t,
-                           uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t piece_base, uint32_t fp_base) {
+                           uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t fp_base) {
     bool open = false;
     int cq = 0, ct = 0;
     uint32_t np = 0, nf = 0, piece_fp0 = 0;
-    const bool wr = WRITE && lane == 0;
+    const bool wr = lane == 0;
+    auto close_piece = [&]() {
+        if (wr) {
+            const uint32_t slot = atomicAdd(&a.counters[0], 1u);
+            if (slot < a.cap_pieces) a.pieces[slot] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
+            else a.counters[2] = 1;
+        }
+        ++np;
+    };
     int base = -(1 << 30), te_l = 0, qe_l = 0, sp_l = 0;
     for (int x = 0; x < len;) {
         if (x < base || x >= base + 64) {                      // load the window of members x .. x+63
@@ -301,16 +310,12 @@ __device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *me
             cq = qe; ct = te;
             x = base + l + 1;
         } else {                                               // split: close here, reopen at this member
-            if (wr) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
-            ++np;
+            close_piece();
             open = false;
             x = base + l;
         }
     }
-    if (open) {
-        if (wr) a.pieces[piece_base + np] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
-        ++np;
-    }
+    if (open) close_piece();
     n_pieces = np;
     n_fps = nf;
 }
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     }
     const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
     const size_t g_hi = g_lo + CHAIN_GROUPS < a.n_groups ? g_lo + CHAIN_GROUPS : a.n_groups;
+    uint32_t wave_fps = 0;                                 // fixed points actually written by this wave (statistics)
     for (size_t g = g_lo; g < g_hi; ++g) {
         const size_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g]);
         const size_t e = g + 1 < a.n_groups ? (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g + 1]) : a.n_anchors;
@@ -480,18 +486,16 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                 moff += best_len;
                 if (best_len < a.min_cnt || (a.dbg_phases & 16)) continue;
                 __threadfence_block();
-                uint32_t np = 0, nf = 0;
-                emit_chain<false>(a, b, lane, mem, s, best_len, qg, tg, strand, np, nf, 0, 0);
-                if (!np) continue;
-                uint32_t pb = 0, fb = 0;
-                if (lane == 0) { pb = atomicAdd(&a.counters[0], np); fb = atomicAdd(&a.counters[1], nf); }
-                pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pb);
+                uint32_t np = 0, nf = 0, fb = 0;
+                if (lane == 0) fb = atomicAdd(&a.counters[1], 2u * (uint32_t)best_len);
                 fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb);
-                if (pb + np > a.cap_pieces || fb + nf > a.cap_fps) { if (lane == 0) a.counters[2] = 1; continue; }
-                emit_chain<true>(a, b, lane, mem, s, best_len, qg, tg, strand, np, nf, pb, fb);
+                if ((unsigned long long)fb + 2ull * (unsigned long long)best_len > a.cap_fps) { if (lane == 0) a.counters[2] = 1; continue; }
+                emit_chain(a, b, lane, mem, s, best_len, qg, tg, strand, np, nf, fb);
+                wave_fps += nf;
             }
         }
     }
+    if (lane == 0 && wave_fps) atomicAdd(&a.counters[3], wave_fps);
 }
 
 }  // namespace
@@ -679,7 +683,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (hc[2]) fail(HLMI_ENOMEM, "chain output buffers overflowed (pieces %u/%u, fixed points %u/%u)", hc[0],
                     ca.cap_pieces, hc[1], ca.cap_fps);
     out.n_pieces = hc[0];
-    out.n_fp = hc[1];
+    out.n_fp = hc[3];
 }
 
 }  // namespace hlmi
