@@ -330,11 +330,11 @@ constexpr int CHAIN_GROUPS = 4;
 constexpr int CHAIN_WAVES = 1;      // (4 waves sharing one gap-cost table measured 5 % slower)
 template <bool TAB>
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
-    __shared__ uint16_t pen_tab[TAB ? PEN_TAB : 1];
+    __shared__ uint8_t pen_tab[TAB ? PEN_TAB : 1];          // byte entries: the index is the LDS address
     const int lane = threadIdx.x & 63;
     if (TAB) {
         for (int d = threadIdx.x; d < a.bw + 2; d += 64 * CHAIN_WAVES)
-            pen_tab[d] = (uint16_t)(d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0);
+            pen_tab[d] = (uint8_t)(d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0);
         __syncthreads();
     }
     const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         int M_best = M_s + 1, M_bp = -1;
         auto prepare = [&](int jl, int &w) {
             const int tj = __builtin_amdgcn_readlane(M_t, jl), qj = __builtin_amdgcn_readlane(M_q, jl);
-            const bool me = lane == jl;                       // this lane now receives for anchor j + 64
-            M_t = me ? N_t : M_t; M_q = me ? N_q : M_q; M_s = me ? N_s : M_s;
+            const unsigned long long me = 1ull << jl;         // this lane now receives for anchor j + 64
+            M_t = select_by_mask(me, N_t, M_t); M_q = select_by_mask(me, N_q, M_q); M_s = select_by_mask(me, N_s, M_s);
             const int dr = M_t - tj, dq = M_q - qj;           // dr >= 0: the group is sorted by target position
             const int dg = dr < dq ? dr : dq, mx = dr < dq ? dq : dr, dd = mx - dg;
             const bool ok = (dg >= 1) & (mx <= a.max_gap) & (dd <= a.bw);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             if (i0) { N_t = P_t; N_q = P_q; N_s = P_s; }
             load_block(i0 + 128, P_t, P_q, P_s);              // in flight during this block
             const int N_b = N_s + 1;
-            const int nb = n - i0 < 64 ? n - i0 : 64;
+            const int nb = __builtin_amdgcn_readfirstlane(n - i0 < 64 ? n - i0 : 64);
             int O_f = 0, O_p = -1;
             int w_cur;
             prepare(0, w_cur);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                 const int fj = sp < 0 ? sb - 1 : sb;
                 O_f = writelane_i32(O_f, fj, jl);
                 O_p = writelane_i32(O_p, sp, jl);
-                M_best = lane == jl ? N_b : M_best;
+                M_best = select_by_mask(1ull << jl, N_b, M_best);
                 M_bp = writelane_i32(M_bp, -1, jl);
                 const int cand = fj + w_cur;
                 const bool take = cand >= M_best;
@@ -673,7 +673,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     const unsigned n_blocks = (unsigned)cdiv(G, (size_t)CHAIN_GROUPS * CHAIN_WAVES);
     {
         KTimer kt("chain");
-        if (o.bandwidth + 2 <= PEN_TAB)
+        if (o.bandwidth + 2 <= PEN_TAB && (o.bandwidth * o.k) / 100 + 16 <= 255)      // table index range, byte entries
             hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks ? n_blocks : 1), dim3(64 * CHAIN_WAVES), 0, stream(), ca);
         else
             hipLaunchKernelGGL(chain_kernel<false>, dim3(n_blocks ? n_blocks : 1), dim3(64 * CHAIN_WAVES), 0, stream(), ca);

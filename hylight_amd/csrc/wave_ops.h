@@ -81,6 +81,16 @@ __device__ __forceinline__ int row_prefix_max_incl_dpp(int x) {
 extern "C" __device__ int hlmi_llvm_writelane(int v, int sel, int old) __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ int writelane_i32(int old, int v, int sel) { return hlmi_llvm_writelane(v, sel, old); }
 
+// per-lane select by a wave-uniform 64-bit lane mask held in SGPRs: bit l set -> lane l takes `yes`.  (A C++
+// expression of this needs a per-lane compare first; the mask of "lane == j" is just 1 << j on the scalar unit.)
+__device__ __forceinline__ int select_by_mask(unsigned long long mask, int yes, int no) {
+    int r = no;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(mask));
+#endif
+    return r;
+}
+
 // lane i <- lane i-1 (lane 0 keeps `lane0`)
 __device__ __forceinline__ int wave_shr1(int x, int lane0) { return dpp_i32<0x138>(lane0, x); }
 // lane i <- lane i+1 (lane 63 keeps `lane63`)
