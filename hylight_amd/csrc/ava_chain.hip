@@ -14,6 +14,7 @@
 //             one chain: cut at the peak, split into alignment pieces of fixed points.
 // Integer / index work throughout: HBM- and latency-bound, no MFMA.
 #include <algorithm>
+#include <type_traits>
 
 #include "ava_internal.h"
 #include "dev_prims.h"
@@ -328,13 +329,15 @@ constexpr int PEN_TAB = 2048;         // gap-cost table entries (bandwidth + 2 m
 // groups left the SIMDs at 3 of 8 resident waves on average).
 constexpr int CHAIN_GROUPS = 4;
 constexpr int CHAIN_WAVES = 1;      // (4 waves sharing one gap-cost table measured 5 % slower)
-template <bool TAB>
+// TAB: 0 = gap cost computed, 1 = byte table (the index is the LDS address), 2 = 16-bit table
+template <int TAB>
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
-    __shared__ uint8_t pen_tab[TAB ? PEN_TAB : 1];          // byte entries: the index is the LDS address
+    typedef typename std::conditional<TAB == 1, uint8_t, uint16_t>::type pen_t;
+    __shared__ pen_t pen_tab[TAB ? PEN_TAB : 1];
     const int lane = threadIdx.x & 63;
     if (TAB) {
         for (int d = threadIdx.x; d < a.bw + 2; d += 64 * CHAIN_WAVES)
-            pen_tab[d] = (uint8_t)(d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0);
+            pen_tab[d] = (pen_t)(d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0);
         __syncthreads();
     }
     const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
@@ -673,10 +676,10 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     const unsigned n_blocks = (unsigned)cdiv(G, (size_t)CHAIN_GROUPS * CHAIN_WAVES);
     {
         KTimer kt("chain");
-        if (o.bandwidth + 2 <= PEN_TAB && (o.bandwidth * o.k) / 100 + 16 <= 255)      // table index range, byte entries
-            hipLaunchKernelGGL(chain_kernel<true>, dim3(n_blocks ? n_blocks : 1), dim3(64 * CHAIN_WAVES), 0, stream(), ca);
-        else
-            hipLaunchKernelGGL(chain_kernel<false>, dim3(n_blocks ? n_blocks : 1), dim3(64 * CHAIN_WAVES), 0, stream(), ca);
+        const dim3 grid(n_blocks ? n_blocks : 1), block(64 * CHAIN_WAVES);
+        if (o.bandwidth + 2 > PEN_TAB) hipLaunchKernelGGL(chain_kernel<0>, grid, block, 0, stream(), ca);
+        else if ((o.bandwidth * o.k) / 100 + 16 <= 255) hipLaunchKernelGGL(chain_kernel<1>, grid, block, 0, stream(), ca);
+        else hipLaunchKernelGGL(chain_kernel<2>, grid, block, 0, stream(), ca);
     }
     HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> hc = counters.download(4);
