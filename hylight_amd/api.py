@@ -179,11 +179,15 @@ class Job:
             raise HlmiError(-1, load().hlmi_last_error().decode(errors="replace"))
 
     def close(self):
-        if self._h:
-            load().hlmi_job_close(self._h)
-            self._h = None
+        if self._h and _lib is not None:
+            _lib.hlmi_job_close(self._h)
+        self._h = None
 
-    __del__ = close
+    def __del__(self):          # at interpreter shutdown module globals may already be gone
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def num_queries(self):
