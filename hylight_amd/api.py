@@ -40,6 +40,9 @@ SYMBOLS = {
     "hlmi_paf_window_filter": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
     "hlmi_filter_ovlp_inline": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_double]),
     "hlmi_minimap22sfo": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_double]),
+    "hlmi_filter_non_atcg": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
+    "hlmi_gfa2fa": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "hlmi_pick_up": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
     "hlmi_ava_opts_long": (None, [C.POINTER(AvaOpts)]),
     "hlmi_ava_opts_short": (None, [C.POINTER(AvaOpts)]),
     "hlmi_ava": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(AvaOpts), C.c_char_p]),
@@ -131,6 +134,22 @@ def filter_ovlp_inline(in_paf, out_paf, min_ovlp_len, min_identity, o=1000, r=0.
 
 def minimap22sfo(in_paf, out_sfo, min_overlap_len=0, min_pident=0.0):
     _check(load().hlmi_minimap22sfo(_b(in_paf), _b(out_sfo), min_overlap_len, min_pident))
+
+
+def filter_non_atcg(fastx, out_fa, model):
+    """utils.filter_non_atcg with an explicit output path; model = "fastq" | "fasta" (script/utils.py:81)."""
+    _check(load().hlmi_filter_non_atcg(_b(fastx), _b(out_fa), int(model == "fastq")))
+    return out_fa
+
+
+def gfa2fa(gfa, fa):
+    _check(load().hlmi_gfa2fa(_b(gfa), _b(fa)))
+
+
+def pick_up(ovlap_paf, fastx, out_fastx, mode):
+    """HyLight.pick_up with an explicit output path; mode = "fastq" | "fasta" (script/HyLight.py:347)."""
+    _check(load().hlmi_pick_up(_b(ovlap_paf), _b(fastx), _b(out_fastx), int(mode == "fastq")))
+    return out_fastx
 
 
 def split_reads2(reads_fa, ref_fa, nsplit, out_dir, out_paf, threads=30, len_over=3000, mc=2, iden=0.95,

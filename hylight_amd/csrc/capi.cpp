@@ -8,6 +8,7 @@
 #include "graph.h"
 #include "paf_io.h"
 #include "stage.h"
+#include "textpass.h"
 
 namespace hlmi {
 void init_device(int device, int threads);
@@ -156,6 +157,27 @@ int hlmi_filter_ovlp_inline(const char *in_paf, const char *out_paf, int min_ovl
             for (auto &pr : order) lines.emplace_back(pt.line(pr.second));
         }
         write_lines(out_paf, lines);
+    });
+}
+
+int hlmi_filter_non_atcg(const char *fastx, const char *out_fa, int is_fastq) {
+    return guarded([&] {
+        if (!fastx || !out_fa) fail(HLMI_EINVAL, "hlmi_filter_non_atcg: NULL path");
+        filter_non_atcg_run(fastx, out_fa, is_fastq != 0);
+    });
+}
+
+int hlmi_gfa2fa(const char *gfa, const char *out_fa) {
+    return guarded([&] {
+        if (!gfa || !out_fa) fail(HLMI_EINVAL, "hlmi_gfa2fa: NULL path");
+        gfa2fa_run(gfa, out_fa);
+    });
+}
+
+int hlmi_pick_up(const char *ovlap_paf, const char *fastx, const char *out_fastx, int is_fastq) {
+    return guarded([&] {
+        if (!ovlap_paf || !fastx || !out_fastx) fail(HLMI_EINVAL, "hlmi_pick_up: NULL path");
+        pick_up_run(ovlap_paf, fastx, out_fastx, is_fastq != 0);
     });
 }
 

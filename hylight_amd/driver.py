@@ -37,56 +37,23 @@ def fq_or_fa(path):
 
 def filter_non_atcg(fq, out_dir, model):
     """utils.filter_non_atcg (script/utils.py:81-114): upper-case, [^ATGCN] -> N, header cut at the first
-    space; 4-line FASTQ / 2-line FASTA records."""
+    space; 4-line FASTQ / 2-line FASTA records.  The pass itself is hlmi_filter_non_atcg."""
     new_dir = os.path.join(out_dir, "1.split_fastx")
     os.makedirs(new_dir, exist_ok=True)
-    out = os.path.join(new_dir, "s1.fa")
-    bad = re.compile(r"[^ATGCN\n]")
-    with open(out, "w") as o, open(fq) as f:
-        for num, line in enumerate(f):
-            if model == "fastq":
-                if num % 4 == 1:
-                    o.write(bad.sub("N", line.upper()))
-                elif num % 4 == 0 and line.startswith("@"):
-                    o.write(">" + line.strip().split(" ")[0][1:] + "\n")
-            else:
-                if num % 2 == 1:
-                    o.write(bad.sub("N", line.upper()))
-                else:
-                    o.write(line.strip().split(" ")[0] + "\n")
-    return out
+    return api.filter_non_atcg(fq, os.path.join(new_dir, "s1.fa"), model)
 
 
 def gfa2fa(gfa, fa):
-    """HyLight.gfa2fa (script/HyLight.py:328-337): S lines only."""
-    with open(gfa) as g, open(fa, "w") as o:
-        for line in g:
-            f = line.split()
-            if f and f[0] == "S":
-                o.write(f">{f[1]}\n{f[2]}\n")
+    """HyLight.gfa2fa (script/HyLight.py:328-337): S lines only (hlmi_gfa2fa)."""
+    api.gfa2fa(gfa, fa)
 
 
 def pick_up(ovlap, outdir, fq):
     """HyLight.pick_up (script/HyLight.py:347-378): reads whose name (up to the first '/') appears in
-    neither column 1 nor column 6 of the PAF."""
-    seen = set()
-    with open(ovlap) as f:
-        for line in f:
-            k = line.split()
-            seen.add(k[0].split("/")[0])
-            seen.add(k[5].split("/")[0])
+    neither column 1 nor column 6 of the PAF (hlmi_pick_up); the output name follows the reference.  When every
+    read overlaps, the reference leaves no file behind - callers get the path either way."""
     out = os.path.join(outdir, "sub" + str(time.time())[-3:] + "_remain.fq")
-    if os.path.exists(out):
-        os.remove(out)
-    nu = 4 if fq_or_fa(fq) == "fastq" else 2
-    keep = False
-    with open(fq) as f, open(out, "a") as o:
-        for num, line in enumerate(f):
-            if num % nu == 0:
-                keep = line.strip().split("/")[0][1:] not in seen
-            if keep:
-                o.write(line)
-    return out
+    return api.pick_up(ovlap, fq, out, fq_or_fa(fq))
 
 
 def _tool(name):

@@ -78,6 +78,22 @@ int hlmi_filter_ovlp_inline(const char *in_paf, const char *out_paf, int min_ovl
  * the ids in string order.  Pure text conversion (host). */
 int hlmi_minimap22sfo(const char *in_paf, const char *out_sfo, int min_overlap_len, double min_pident);
 
+/* ---- the line-oriented text passes either side of the path (host I/O, no GPU work) ----
+ * Same text conventions as the Python originals (universal newlines, str.strip()/split() white space).
+ *
+ * utils.filter_non_atcg(fq, out_dir, model) (script/utils.py:81-114): sequences upper-cased with every character
+ * outside ATGCN replaced by N, headers cut at the first space; `is_fastq` = (model == "fastq").  The reference
+ * derives the output path (<out_dir>/1.split_fastx/s1.fa); here the caller passes it. */
+int hlmi_filter_non_atcg(const char *fastx, const char *out_fa, int is_fastq);
+/* HyLight.gfa2fa(gfa, fa) (script/HyLight.py:328-337): S lines -> FASTA records.  An empty line is an error
+ * (the reference raises IndexError on it). */
+int hlmi_gfa2fa(const char *gfa, const char *out_fa);
+/* HyLight.pick_up(ovlap, outdir, fq) (script/HyLight.py:347-378): the records of `fastx` whose name (text before
+ * the first '/', without the leading '@' or '>') appears in neither column 1 nor column 6 of the PAF.  The
+ * reference names the output <outdir>/sub<clock digits>_remain.fq; here the caller passes the path.  As in the
+ * reference an existing file is removed first and no file is created when nothing is kept. */
+int hlmi_pick_up(const char *ovlap_paf, const char *fastx, const char *out_fastx, int is_fastq);
+
 /* ---- a3: the overlapper (replaces the external minimap2 call, slr2:51 / slr2:55) -------- */
 typedef struct {
     int k;                 /* 19 (long, -Hk19) */
