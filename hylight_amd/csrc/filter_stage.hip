@@ -191,12 +191,46 @@ struct SortedCK {
     DBuf<uint32_t> perm, chunk;
     DBuf<uint64_t> key;
 };
+// (chunk, key) -> one word chunk | key.hi | key.lo with the bit widths the data needs, so that ONE radix sort of
+// cb + hb + lb bits (38 on C2 instead of 64 + 7 in two sorts) orders the rows; `bits` = OR of all keys.
+__global__ void or_reduce_u64_kernel(const uint64_t *key, size_t n, unsigned long long *acc) {
+    unsigned long long v = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v |= key[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicOr(acc, v);
+}
+__global__ void compact_ck_kernel(const uint32_t *chunk, const uint64_t *key, size_t n, int hb, int lb, uint64_t *out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ((uint64_t)chunk[i] << hb | key[i] >> 32) << lb | (key[i] & 0xffffffffull);
+}
+__global__ void expand_ck_kernel(const uint64_t *ck, size_t n, int hb, int lb, uint32_t *chunk, uint64_t *key) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = ck[i];
+    chunk[i] = (uint32_t)(v >> (hb + lb));
+    key[i] = ((v >> lb) & ((1ull << hb) - 1ull)) << 32 | (v & ((1ull << lb) - 1ull));
+}
+
 void sort_chunk_key(const uint32_t *d_chunk, const uint64_t *d_key, size_t n, uint32_t n_chunks, SortedCK &o) {
     o.perm.alloc(n);
     o.chunk.alloc(n);
     o.key.alloc(n);
     if (!n) return;
     hipLaunchKernelGGL(iota_kernel, grid1(n), dim3(WG), 0, stream(), o.perm.p, n);
+    DBuf<unsigned long long> acc(1);
+    acc.zero();
+    hipLaunchKernelGGL(or_reduce_u64_kernel, dim3((unsigned)std::min<size_t>(cdiv(n, WG), 2048)), dim3(WG), 0, stream(), d_key,
+                       n, acc.p);
+    const uint64_t bits = acc.download(1)[0];
+    const int hb = bits_for(bits >> 32), lb = bits_for(bits & 0xffffffffull), cb = bits_for(n_chunks > 1 ? n_chunks - 1 : 1);
+    if (cb + hb + lb <= 64) {
+        DBuf<uint64_t> ck(n);
+        hipLaunchKernelGGL(compact_ck_kernel, grid1(n), dim3(WG), 0, stream(), d_chunk, d_key, n, hb, lb, ck.p);
+        sort_pairs_u64_u32(ck.p, o.perm.p, n, 0, cb + hb + lb);
+        hipLaunchKernelGGL(expand_ck_kernel, grid1(n), dim3(WG), 0, stream(), ck.p, n, hb, lb, o.chunk.p, o.key.p);
+        return;
+    }
     HIP_CHECK(hipMemcpyAsync(o.key.p, d_key, n * 8, hipMemcpyDeviceToDevice, stream()));
     sort_pairs_u64_u32(o.key.p, o.perm.p, n);
     if (n_chunks > 1) {
@@ -303,9 +337,9 @@ __global__ __launch_bounds__(WG) void snp_count_kernel(const PafRec *recs, const
 
 __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
                                                        const uint8_t *sel, size_t n, int long_mode, const uint32_t *ev_off,
-                                                       const uint32_t *iv_off, uint32_t *ev_chunk, uint64_t *ev_key,
-                                                       uint32_t *ev_partner, uint32_t *iv_chunk, uint64_t *iv_skey,
-                                                       uint64_t *iv_ekey) {
+                                                       const uint32_t *iv_off, const uint32_t *pseg_start, size_t n_pseg,
+                                                       uint32_t *ev_chunk, uint64_t *ev_key, uint32_t *ev_pair,
+                                                       uint32_t *iv_chunk, uint64_t *iv_skey, uint64_t *iv_ekey) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -320,6 +354,14 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
             if (long_mode && r.qs < r.qe) {
                 iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.qid << 32 | r.qs; iv_ekey[w] = (uint64_t)r.qid << 32 | r.qe;
             }
+        }
+        // the pair group of this row = the pair every event of the row counts for (read and partner are the row's
+        // two names): last group start <= i
+        uint32_t pg;
+        {
+            size_t lo = 0, hi = n_pseg;
+            while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (pseg_start[mid] <= i) lo = mid + 1; else hi = mid; }
+            pg = (uint32_t)(lo - 1);
         }
         const bool rev = r.flags & PF_REV;
         uint32_t p1 = rev ? r.qlen - r.qe : r.qs;   // slr2:334   (positions after the ops handled so far)
@@ -339,9 +381,9 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
                 uint32_t at = e + (uint32_t)__popcll(xm & ((1ull << lane) - 1ull)) * (long_mode ? 2u : 1u);
                 if (long_mode) {
                     const uint32_t qp = rev ? r.qlen - q1 + 1 : q1;    // slr2:357
-                    ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.qid << 32 | qp; ev_partner[at] = r.tid; ++at;
+                    ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.qid << 32 | qp; ev_pair[at] = pg; ++at;
                 }
-                ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.tid << 32 | q2; ev_partner[at] = r.qid;
+                ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.tid << 32 | q2; ev_pair[at] = pg;
             }
             p1 += (uint32_t)__shfl((int)s1, 63, 64);
             p2 += (uint32_t)__shfl((int)s2, 63, 64);
@@ -355,7 +397,7 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
 // ---------------------------------------------------------------------------------------
 // Two balanced kernels: (1) one thread per distinct SNP key decides "supported" (v >= mc supporters and >= mc
 // further spanning reads) and writes the verdict over the key's event range; (2) one thread per EVENT of a
-// supported key looks its pair group up and bumps the pair's counter.  (A key on a deeply covered read has
+// supported key bumps the counter of its row's pair group (recorded with the event).  (A key on a deeply covered read has
 // hundreds of events; a single thread walking them all was the long pole of the filter stage.)
 __global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_key, const uint32_t *kseg_start,
                                    size_t n_kseg, size_t n_ev, const uint32_t *ivs_chunk, const uint64_t *ivs_key,
@@ -379,16 +421,10 @@ __global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_
     for (size_t i = b; i < e; ++i) ev_supported[i] = 1;      // contiguous bytes; v is at most the read depth
 }
 
-__global__ void snp_pair_count_kernel(const uint32_t *ev_chunk, const uint64_t *ev_key, const uint32_t *ev_partner,
-                                      const uint32_t *ev_perm, const uint8_t *ev_supported, size_t n_ev,
-                                      const uint32_t *pseg_chunk, const uint64_t *pseg_key, size_t n_pseg,
-                                      uint32_t *pair_mut) {
+__global__ void snp_pair_count_kernel(const uint32_t *ev_pair, const uint32_t *ev_perm, const uint8_t *ev_supported,
+                                      size_t n_ev, uint32_t *pair_mut) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n_ev || !ev_supported[i]) return;
-    const uint32_t c = ev_chunk[i], read = (uint32_t)(ev_key[i] >> 32), other = ev_partner[ev_perm[i]];
-    const uint64_t pk = pair_key(read, other);
-    size_t p = lower_bound_ck(pseg_chunk, pseg_key, n_pseg, c, pk);
-    if (p < n_pseg && pseg_chunk[p] == c && pseg_key[p] == pk) atomicAdd(&pair_mut[p], 1u);
+    if (i < n_ev && ev_supported[i]) atomicAdd(&pair_mut[ev_pair[ev_perm[i]]], 1u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -539,10 +575,6 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     DBuf<uint32_t> pseg_start(m);
     const size_t n_pseg = select_flagged_indices(head.p, pseg_start.p, m);
     out.n_pairs = n_pseg;
-    DBuf<uint32_t> pseg_chunk(n_pseg);
-    DBuf<uint64_t> pseg_key(n_pseg);
-    hipLaunchKernelGGL(gather_u32_kernel, grid1(n_pseg), dim3(WG), 0, stream(), g.chunk.p, pseg_start.p, pseg_chunk.p, n_pseg);
-    hipLaunchKernelGGL(gather_u64_kernel, grid1(n_pseg), dim3(WG), 0, stream(), g.key.p, pseg_start.p, pseg_key.p, n_pseg);
     DBuf<uint8_t> sel(m);
     hipLaunchKernelGGL(pair_order_select_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, grows.p, pseg_start.p,
                        n_pseg, m, lm, sel.p);
@@ -560,10 +592,11 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     DBuf<uint32_t> pair_mut(n_pseg);
     pair_mut.zero();
     if (E) {
-        DBuf<uint32_t> ev_chunk(E), ev_partner(E), iv_chunk(I ? I : 1);
+        DBuf<uint32_t> ev_chunk(E), ev_pair(E), iv_chunk(I ? I : 1);
         DBuf<uint64_t> ev_key(E), iv_skey(I ? I : 1), iv_ekey(I ? I : 1);
         hipLaunchKernelGGL(snp_fill_kernel, rows_grid, dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm,
-                           ev_off.p, iv_off.p, ev_chunk.p, ev_key.p, ev_partner.p, iv_chunk.p, iv_skey.p, iv_ekey.p);
+                           ev_off.p, iv_off.p, pseg_start.p, n_pseg, ev_chunk.p, ev_key.p, ev_pair.p, iv_chunk.p, iv_skey.p,
+                           iv_ekey.p);
         SortedCK sev, sis, sie;
         sort_chunk_key(ev_chunk.p, ev_key.p, E, n_chunks, sev);
         sort_chunk_key(iv_chunk.p, iv_skey.p, I, n_chunks, sis);
@@ -577,8 +610,8 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
         ev_sup.zero();
         hipLaunchKernelGGL(snp_support_kernel, grid1(n_kseg), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p, kseg_start.p,
                            n_kseg, E, sis.chunk.p, sis.key.p, sie.chunk.p, sie.key.p, I, cfg.mc, ev_sup.p);
-        hipLaunchKernelGGL(snp_pair_count_kernel, grid1(E), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p, ev_partner.p,
-                           sev.perm.p, ev_sup.p, E, pseg_chunk.p, pseg_key.p, n_pseg, pair_mut.p);
+        hipLaunchKernelGGL(snp_pair_count_kernel, grid1(E), dim3(WG), 0, stream(), ev_pair.p, sev.perm.p, ev_sup.p, E,
+                           pair_mut.p);
         HIP_CHECK(hipGetLastError());
         sync();
     }
