@@ -2,15 +2,17 @@
 //
 // Every piece is a list of fixed points; consecutive fixed points bound an independent global
 // alignment block (<= 256 x 256, |diagonal shift| <= 39) and the two piece ends get a local
-// extension (<= 256 rows).  One wavefront per task:
-//   * the 64 lanes are the 64 diagonals of the band, rows are processed one by one;
-//   * affine gaps (Gotoh): the vertical gap F comes from lane d+1 of the previous row, the
-//     horizontal gap E from a max-plus prefix scan across the lanes of the current row
-//     (E(d) = max_{d'<d} Ht(d') - open - ext*(d-d'));
-//   * the 4 traceback bits per cell are written as 4 wave ballots (32 B per row) into LDS;
-//   * lane 0 walks the traceback and run-length encodes the =/X/I/D ops.
+// extension (<= 256 rows).  Passes:
+//   make_tasks   one self-contained 32-byte record per block / extension
+//   classify     lane per task: square blocks with <= kmax substitutions are finished on the spot (proof at the
+//                kernel), the rest is split into near-diagonal (16-diagonal band) and wide (64 diagonals) lists
+//   align_narrow four tasks per wave (one per DPP row), align (wide) one task per wave.  Lanes = diagonals, rows one
+//                by one; affine gaps (Gotoh): F from lane d+1 of the previous row, E from a max-plus prefix scan
+//                across the lanes (E(d) = max_{d'<d} Ht(d') - open - ext*(d-d')); the five traceback bits of a cell
+//                stay with its lane as bit planes; the traceback jumps along diagonals with count-trailing-ones
+//   assemble     wave per piece: merged CIGAR + PafRec
 // The recurrences, tie rules and the best-cell rule of the extensions are those of
-// oracle/ava_oracle.c:band_dp.  LDS/VALU bound by nature: reads ~1 B per
+// oracle/ava_oracle.c:band_dp.  VALU bound by nature: reads ~1 B per
 // DP row per sequence from HBM.
 #include <algorithm>
 
@@ -105,17 +107,6 @@ struct AlignArgs {
     uint32_t cap_runs;
     uint32_t *counters;     // [0] runs cursor, [1] overflow
 };
-
-__device__ __forceinline__ int wave_prefix_max_excl(int v, int lane) {
-    // inclusive scan with max, then shift by one lane
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int u = __shfl_up(v, o, 64);
-        if (lane >= o) v = u > v ? u : v;
-    }
-    int r = __shfl_up(v, 1, 64);
-    return lane == 0 ? NEG_INF * 2 : r;
-}
 
 // exclusive prefix sum over the wave; total = sum of all lanes
 __device__ __forceinline__ uint32_t wave_excl_sum_u32(uint32_t v, int lane, uint32_t &total) {

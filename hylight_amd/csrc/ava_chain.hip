@@ -7,11 +7,12 @@
 //             key = qlocal | target:tb | strand:1 | tpos:pb | qpos:qpb | qspan:8 in ONE 64-bit word when the
 //             widths of the batch fit (they do for read sets); else key = ... | tpos and val = qpos:32 | qspan:8
 //   order   : one stable 64-bit radix sort per query batch (generation order breaks ties)
-//   chains  : one wavefront per (query,target,strand) group.  The DP keeps the current and the previous
-//             block of 64 anchors in registers (lane = index mod 64), every lane scores one predecessor and
-//             a wave max-reduction picks the best (Li 2018 eq. 1-2, integer gap cost); chain extraction
-//             hands each anchor's trunk to its best child (64-bit atomicMax) and lets every lane walk
-//             one chain: cut at the peak, split into alignment pieces of fixed points.
+//   chains  : one wavefront per (query,target,strand) group.  DP in push form: lane l keeps the anchor with
+//             index = l mod 64 among the 64 that follow the anchor being finished and tries that anchor as its
+//             predecessor (Li 2018 eq. 1-2, integer gap cost from an LDS table) - no cross-lane reduction; every
+//             anchor hands its trunk to its best child (64-bit atomicMax); chain ids by pointer jumping inside
+//             64-anchor windows, peaks by atomicMax keyed on the chain start, member lists and fixed points by
+//             ballots: cut at the peak, split into alignment pieces of fixed points.
 // Integer / index work throughout: HBM- and latency-bound, no MFMA.
 #include <algorithm>
 #include <type_traits>
@@ -244,12 +245,6 @@ __device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, in
         t = (int)(key & a.pmask); q = (int)(val >> 32); sp = (int)((val >> 24) & 0xff);
     }
 }
-__device__ __forceinline__ unsigned long long rl64(unsigned long long v, int l) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-    return (unsigned long long)hi << 32 | lo;
-}
-
 // Fixed-point selection over the member list mem[0..len) of one chain (oracle/ava_oracle.c:align_chain).
 // 64 members at a time sit in registers; the next fixed point = first later member that is >= BLOCK_MIN away
 // in both sequences (or the last member) comes from one ballot instead of a scan over ~16 anchors.

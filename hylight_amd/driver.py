@@ -5,14 +5,14 @@ Keeps script/HyLight.py's CLI flags and defaults (HyLight.py:25-52), stage order
 ...), and calls libhylight_mi.so at the two boundaries the path owns: B1 = split_reads2 and
 B3 = miniasm.  External tools the reference shells out to (bfc, ropebwt2, fmlrc2, racon) are still
 external; unlike the reference (whose `execute()` swallows most failures) a missing or
-failing tool stops the run with a message.  The short-read branch (HyLight.py:198 onwards) needs the
-short-read overlapper mode, which is SURVEY.md §8f rank 1 and not built: the driver stops there.
+failing tool stops the run with a message.  The two short-read overlap calls of the path (HyLight.py:200,207)
+run in the library's short mode; short-read clustering, POLYTE and stage b are out of scope: the driver stops
+after them.  The text passes (filter_non_atcg, gfa2fa, pick_up) are the library's native ones.
 """
 from __future__ import annotations
 
 import argparse
 import os
-import re
 import shutil
 import subprocess
 import sys
@@ -150,7 +150,7 @@ def main(argv=None):
     ti = 0
     while ti < 2 and not args.low_quality:                      # HyLight.py:158-190
         remain = pick_up(ov_long_ref, tmp, infile)
-        if os.path.getsize(remain) == 0:
+        if not os.path.exists(remain) or os.path.getsize(remain) == 0:    # every read overlapped: nothing left to assemble
             break
         ov_remain = stage(remain, remain, nsplit, tmp + "ov_long_remain.paf", len_over, 2, iden)
         remain_gfa = tmp + "remain.gfa"
@@ -181,7 +181,7 @@ def main(argv=None):
     long_con3 = os.path.join(outdir, "long_con_polished.fa")
     _run(f"{racon} --no-trimming -u -t 30 {short_reads} {ov_short} {long_con2} > {long_con3}", cwd=outdir)
     remain_short = pick_up(ov_short, tmp, short_reads)
-    if os.path.getsize(remain_short):
+    if os.path.exists(remain_short) and os.path.getsize(remain_short):
         stage(short_reads, remain_short, nsplit, tmp + "shortr2.paf", 70, 3, iden, long=False)
     raise SystemExit("overlap path finished (tmp/shortr1.paf, tmp/shortr2.paf, long_con_polished.fa).  Short-read "
                      "clustering, POLYTE and stage b (HyLight.py:211-280) are outside this implementation's scope "
