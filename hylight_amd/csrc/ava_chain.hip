@@ -636,7 +636,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     aoff.release();
     {
         KTimer kt("anchor_sort");
-        if (vb) sort_keys_u64(akey.p, A, vb, vb + tb + 1 + pb + qbits);
+        if (vb) sort_keys_u64(akey, A, vb, vb + tb + 1 + pb + qbits);
         else sort_pairs_u64_u64(akey.p, aval.p, A, 0, tb + 1 + pb + qbits);
     }
     DBuf<uint8_t> head(A);

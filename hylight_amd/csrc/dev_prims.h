@@ -12,11 +12,15 @@ void sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, size_t n, int begin_bit 
 void sort_pairs_u64_u64(uint64_t *keys, uint64_t *vals, size_t n, int begin_bit = 0, int end_bit = 64);
 void sort_pairs_u32_u32(uint32_t *keys, uint32_t *vals, size_t n, int begin_bit = 0, int end_bit = 32);
 void sort_keys_u64(uint64_t *keys, size_t n, int begin_bit = 0, int end_bit = 64);
+// same, without the copy back when the last pass lands in the temporary: `keys` then takes that buffer over
+template <typename T> struct DBuf;
+void sort_keys_u64(DBuf<uint64_t> &keys, size_t n, int begin_bit = 0, int end_bit = 64);
 
 // out[i] = sum_{j<i} in[j]; returns nothing, total = out[n-1] + in[n-1] (use scan_total)
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n);
 void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n);
-// writes the indices i with flags[i] != 0 (ascending) to out_idx; returns their count (syncs)
+// writes the indices i with flags[i] != 0 (ascending) to out_idx; returns their count (the only call here that waits
+// for the device: the count goes back to the host)
 size_t select_flagged_indices(const uint8_t *flags, uint32_t *out_idx, size_t n);
 // number of significant bits of the maximum key value helper
 inline int bits_for(uint64_t max_value) {

@@ -3,15 +3,20 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_select.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
+
+#include <utility>
 
 #include "common.h"
 
 namespace hlmi {
 
+// Temporaries are pooled device buffers (common.h): releasing one while kernels of this stream still use it is
+// safe, the next user is ordered behind them on the same stream - no host synchronisation in here unless a
+// value goes back to the host.
 namespace {
+constexpr int WG = 256;
+
 template <typename K, typename V>
 void sort_pairs_impl(K *keys, V *vals, size_t n, int b0, int b1) {
     if (n < 2) return;
@@ -27,7 +32,19 @@ void sort_pairs_impl(K *keys, V *vals, size_t n, int b0, int b1) {
         HIP_CHECK(hipMemcpyAsync(keys, dk.current(), n * sizeof(K), hipMemcpyDeviceToDevice, stream()));
     if (dv.current() != vals)
         HIP_CHECK(hipMemcpyAsync(vals, dv.current(), n * sizeof(V), hipMemcpyDeviceToDevice, stream()));
-    sync();  // temporaries die here
+}
+
+// per 64 flags: how many are set
+__global__ __launch_bounds__(WG) void flag_count_kernel(const uint8_t *flags, size_t n, uint32_t *cnt) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && flags[i] != 0);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) cnt[i >> 6] = (uint32_t)__popcll(m);
+}
+__global__ __launch_bounds__(WG) void flag_scatter_kernel(const uint8_t *flags, size_t n, const uint32_t *off, uint32_t *out_idx) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const bool f = i < n && flags[i] != 0;
+    const unsigned long long m = __ballot(f);
+    if (f) out_idx[off[i >> 6] + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)i;
 }
 }  // namespace
 
@@ -45,7 +62,17 @@ void sort_keys_u64(uint64_t *keys, size_t n, int b0, int b1) {
     HIP_CHECK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, n, b0, b1, stream()));
     if (dk.current() != keys)
         HIP_CHECK(hipMemcpyAsync(keys, dk.current(), n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()));
-    sync();
+}
+
+void sort_keys_u64(DBuf<uint64_t> &keys, size_t n, int b0, int b1) {
+    if (n < 2) return;
+    DBuf<uint64_t> k2(keys.n);
+    rocprim::double_buffer<uint64_t> dk(keys.p, k2.p);
+    size_t tmp_bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, n, b0, b1, stream()));
+    DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+    HIP_CHECK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, n, b0, b1, stream()));
+    if (dk.current() != keys.p) std::swap(keys, k2);      // the result sits in the other buffer: keep that one
 }
 
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n) {
@@ -54,7 +81,6 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n) {
     HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), stream()));
     DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
     HIP_CHECK(rocprim::exclusive_scan(tmp.p, tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), stream()));
-    sync();
 }
 
 void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n) {
@@ -64,18 +90,22 @@ void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n) {
     HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in64, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream()));
     DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
     HIP_CHECK(rocprim::exclusive_scan(tmp.p, tmp_bytes, in64, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), stream()));
-    sync();
 }
 
+// Three small launches instead of rocprim::select: set bits per 64 flags (ballot), their exclusive scan, scatter by
+// ballot rank.  The flags are read twice (1 B each); on the 5e7-element head arrays of the anchor batches this is
+// several times quicker than the look-back partition, and most calls of a step are such selections.
 size_t select_flagged_indices(const uint8_t *flags, uint32_t *out_idx, size_t n) {
     if (!n) return 0;
-    DBuf<size_t> cnt(1);
-    size_t tmp_bytes = 0;
-    rocprim::counting_iterator<uint32_t> iota(0);
-    HIP_CHECK(rocprim::select(nullptr, tmp_bytes, iota, flags, out_idx, cnt.p, n, stream()));
-    DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
-    HIP_CHECK(rocprim::select(tmp.p, tmp_bytes, iota, flags, out_idx, cnt.p, n, stream()));
-    return download_one(cnt.p);
+    if (n >= (1ull << 32)) fail(HLMI_EINVAL, "select_flagged_indices: more than 2^32 elements");
+    const size_t nw = (n + 63) / 64;
+    DBuf<uint32_t> cnt(nw), off(nw);
+    const dim3 grid(cdiv(n, WG));
+    hipLaunchKernelGGL(flag_count_kernel, grid, dim3(WG), 0, stream(), flags, n, cnt.p);
+    exclusive_scan_u32(cnt.p, off.p, nw);
+    hipLaunchKernelGGL(flag_scatter_kernel, grid, dim3(WG), 0, stream(), flags, n, off.p, out_idx);
+    HIP_CHECK(hipGetLastError());
+    return (size_t)download_one(off.p + (nw - 1)) + download_one(cnt.p + (nw - 1));
 }
 
 }  // namespace hlmi
