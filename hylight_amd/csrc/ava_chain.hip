@@ -6,7 +6,9 @@
 //             pair-once rule strcmp(qname,tname) < 0 (ava "no dual / no diagonal"), anchors packed as
 //             key = qlocal | target:tb | strand:1 | tpos:pb | qpos:qpb | qspan:8 in ONE 64-bit word when the
 //             widths of the batch fit (they do for read sets); else key = ... | tpos and val = qpos:32 | qspan:8
-//   order   : one stable 64-bit radix sort per query batch (generation order breaks ties)
+//   order   : one stable radix sort per query batch on the (query, target, strand) bits only; inside a group the
+//             anchors stay in generation order = ascending query position (the chain kernel reads a reverse-strand
+//             group back to front)
 //   chains  : one wavefront per (query,target,strand) group.  DP in push form: lane l keeps the anchor with
 //             index = l mod 64 among the 64 that follow the anchor being finished and tries that anchor as its
 //             predecessor (Li 2018 eq. 1-2, integer gap cost from an LDS table) - no cross-lane reduction; every
@@ -250,8 +252,8 @@ __device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, in
 // in both sequences (or the last member) comes from one ballot instead of a scan over ~16 anchors.
 // One pass: the fixed points go into a range reserved for the worst case (a chain of len members has at most
 // 2 * len of them: one per member plus one more per piece), every piece takes its slot when it closes.
-__device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *mem, int s, int len, uint32_t q, uint32_t t,
-                           uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t fp_base) {
+__device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step, int lane, const int *mem, int s, int len,
+                           uint32_t q, uint32_t t, uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t fp_base) {
     bool open = false;
     int cq = 0, ct = 0;
     uint32_t np = 0, nf = 0, piece_fp0 = 0;
@@ -271,7 +273,7 @@ __device__ void emit_chain(const ChainArgs &a, size_t b, int lane, const int *me
             te_l = qe_l = sp_l = 0;
             if (x + lane < len) {
                 const int idx = mem[x + lane];
-                anchor_fields(a, b + idx, te_l, qe_l, sp_l);
+                anchor_fields(a, (size_t)((long long)g_first + g_step * idx), te_l, qe_l, sp_l);
                 ++te_l; ++qe_l;
             }
         }
@@ -351,10 +353,18 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         // depend on f (gap geometry, gap cost look-up) is computed one step ahead.  Predecessors arrive in ascending
         // order, so "candidate >= best" gives ties to the closest one; M_best starts at span + 1 so that the first
         // predecessor needs candidate > span.
+        const uint64_t key0 = a.key[b] >> (a.vb + a.pb);
+        const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1));
+        const uint32_t tg = (uint32_t)(key0 >> 1) & ((1u << a.tb) - 1);
+        const uint32_t strand = (uint32_t)key0 & 1u;
+        // anchor i of the group in chaining order (ascending aligned query position) sits at b + i, or at
+        // b + n - 1 - i on the reverse strand
+        const size_t g_first = strand ? b + (size_t)n - 1 : b;
+        const long long g_step = strand ? -1 : 1;
         constexpr int DEAD_Q = -(1 << 30);                    // lanes past the end of the group: dq < 0 fails the gap test
         auto load_block = [&](int i0, int &t, int &q, int &sp) {
             t = 0; q = DEAD_Q; sp = 0;
-            if (i0 + lane < n) anchor_fields(a, b + i0 + lane, t, q, sp);
+            if (i0 + lane < n) anchor_fields(a, (size_t)((long long)g_first + g_step * (i0 + lane)), t, q, sp);
         };
         int M_t, M_q, M_s, N_t, N_q, N_s, P_t, P_q, P_s;
         load_block(0, M_t, M_q, M_s);
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             const int tj = __builtin_amdgcn_readlane(M_t, jl), qj = __builtin_amdgcn_readlane(M_q, jl);
             const unsigned long long me = 1ull << jl;         // this lane now receives for anchor j + 64
             M_t = select_by_mask(me, N_t, M_t); M_q = select_by_mask(me, N_q, M_q); M_s = select_by_mask(me, N_s, M_s);
-            const int dr = M_t - tj, dq = M_q - qj;           // dr >= 0: the group is sorted by target position
+            const int dr = M_t - tj, dq = M_q - qj;           // dq >= 0: the group is in query order
             const int dg = dr < dq ? dr : dq, mx = dr < dq ? dq : dr, dd = mx - dg;
             const bool ok = (dg >= 1) & (mx <= a.max_gap) & (dd <= a.bw);
             int pen;
@@ -415,10 +425,6 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         // the roots and the peak of every chain (max f, first index: 64-bit atomicMax keyed by the root; the chain
         // owning the window's best f - the long one - sends one atomic for all its lanes).  C2 then turns each chain
         // that scores enough into its member list up to the peak, a ballot per window.
-        const uint64_t key0 = a.key[b] >> a.vb;
-        const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1 + a.pb));
-        const uint32_t tg = (uint32_t)(key0 >> (1 + a.pb)) & ((1u << a.tb) - 1);
-        const uint32_t strand = (uint32_t)(key0 >> a.pb) & 1u;
         int prev_root = 0;                                 // roots of the window before (lane = index mod 64)
         for (int w0 = 0; w0 < n; w0 += 64) {
             const int i = w0 + lane;
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                 if (lane == 0) fb = atomicAdd(&a.counters[1], 2u * (uint32_t)best_len);
                 fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb);
                 if ((unsigned long long)fb + 2ull * (unsigned long long)best_len > a.cap_fps) { if (lane == 0) a.counters[2] = 1; continue; }
-                emit_chain(a, b, lane, mem, s, best_len, qg, tg, strand, np, nf, fb);
+                emit_chain(a, g_first, g_step, lane, mem, s, best_len, qg, tg, strand, np, nf, fb);
                 wave_fps += nf;
             }
         }
@@ -636,8 +642,10 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     aoff.release();
     {
         KTimer kt("anchor_sort");
-        if (vb) sort_keys_u64(akey, A, vb, vb + tb + 1 + pb + qbits);
-        else sort_pairs_u64_u64(akey.p, aval.p, A, 0, tb + 1 + pb + qbits);
+        // grouping only: the target-position bits are not sorted - inside a (query, target, strand) group the stable
+        // sort keeps the generation order = ascending query position (descending on the reverse strand)
+        if (vb) sort_keys_u64(akey, A, vb + pb, vb + pb + 1 + tb + qbits);
+        else sort_pairs_u64_u64(akey.p, aval.p, A, pb, pb + 1 + tb + qbits);
     }
     DBuf<uint8_t> head(A);
     hipLaunchKernelGGL(group_head_kernel, grid1(A), dim3(WG), 0, stream(), akey.p, A, vb + pb, head.p);

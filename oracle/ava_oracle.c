@@ -268,12 +268,15 @@ static int64_t index_find(const index_t *ix, uint64_t key, int64_t *cnt) {
 /* ---- S3: anchors ------------------------------------------------------------------------------ */
 typedef struct { uint32_t t, strand, tpos, qpos, qspan, gen; } anchor_t;   /* gen = generation order */
 
+/* Order of the anchors of one query: by target, strand, then by position on the QUERY in aligned orientation.
+ * Anchors are generated query minimizer by query minimizer (ascending forward position; the occurrences of one
+ * minimizer ascending by target position), so this is the generation order on the forward strand and its reverse
+ * on the reverse strand - a grouping, not a sort by coordinate. */
 static int cmp_anchor(const void *a, const void *b) {
     const anchor_t *x = (const anchor_t *)a, *y = (const anchor_t *)b;
     if (x->t != y->t) return x->t < y->t ? -1 : 1;
     if (x->strand != y->strand) return x->strand < y->strand ? -1 : 1;
-    if (x->tpos != y->tpos) return x->tpos < y->tpos ? -1 : 1;
-    if (x->gen != y->gen) return x->gen < y->gen ? -1 : 1;   /* stable: (query minimizer, occurrence) order */
+    if (x->gen != y->gen) return (x->gen < y->gen) != (x->strand != 0) ? -1 : 1;
     return 0;
 }
 
@@ -514,8 +517,8 @@ static void chain_group(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
         int32_t best = (int32_t)a[i].qspan, bp = -1;
         for (int j = i - 1; j >= 0 && j >= i - CHAIN_PRED; --j) {
             int32_t dr = (int32_t)a[i].tpos - (int32_t)a[j].tpos, dq = (int32_t)a[i].qpos - (int32_t)a[j].qpos;
-            if (dr > o->max_gap) break;
-            if (dq <= 0 || dq > o->max_gap || dr == 0) continue;
+            if (dq > o->max_gap) break;                       /* query positions only grow going back */
+            if (dr <= 0 || dr > o->max_gap || dq == 0) continue;
             int32_t dd = dr > dq ? dr - dq : dq - dr;
             if (dd > o->bandwidth) continue;
             int32_t dg = dr < dq ? dr : dq;
