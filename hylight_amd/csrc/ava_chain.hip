@@ -6,9 +6,9 @@
 //             pair-once rule strcmp(qname,tname) < 0 (ava "no dual / no diagonal"), anchors packed as
 //             key = qlocal | target:tb | strand:1 | tpos:pb | qpos:qpb | qspan:8 in ONE 64-bit word when the
 //             widths of the batch fit (they do for read sets); else key = ... | tpos and val = qpos:32 | qspan:8
-//   order   : one stable radix sort per query batch on the (query, target, strand) bits only; inside a group the
-//             anchors stay in generation order = ascending query position (the chain kernel reads a reverse-strand
-//             group back to front)
+//   order   : one stable radix sort per query batch on the (target, strand) bits only: generation is query by query,
+//             so the (target, strand, query) groups come out contiguous with their anchors in generation order =
+//             ascending query position (the chain kernel reads a reverse-strand group back to front)
 //   chains  : one wavefront per (query,target,strand) group.  DP in push form: lane l keeps the anchor with
 //             index = l mod 64 among the 64 that follow the anchor being finished and tries that anchor as its
 //             predecessor (Li 2018 eq. 1-2, integer gap cost from an LDS table) - no cross-lane reduction; every
@@ -642,10 +642,11 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     aoff.release();
     {
         KTimer kt("anchor_sort");
-        // grouping only: the target-position bits are not sorted - inside a (query, target, strand) group the stable
-        // sort keeps the generation order = ascending query position (descending on the reverse strand)
-        if (vb) sort_keys_u64(akey, A, vb + pb, vb + pb + 1 + tb + qbits);
-        else sort_pairs_u64_u64(akey.p, aval.p, A, pb, pb + 1 + tb + qbits);
+        // grouping only: anchors are generated query by query, so a stable sort on the (target, strand) bits alone
+        // leaves every (target, strand, query) group contiguous and in generation order = ascending query position
+        // (descending on the reverse strand); neither the position bits nor the query bits are sorted
+        if (vb) sort_keys_u64(akey, A, vb + pb, vb + pb + 1 + tb);
+        else sort_pairs_u64_u64(akey.p, aval.p, A, pb, pb + 1 + tb);
     }
     DBuf<uint8_t> head(A);
     hipLaunchKernelGGL(group_head_kernel, grid1(A), dim3(WG), 0, stream(), akey.p, A, vb + pb, head.p);
