@@ -216,8 +216,7 @@ struct ChainArgs {
     const uint64_t *key, *val;
     const uint32_t *gstart;
     size_t n_groups, n_anchors;
-    int32_t *f, *p;
-    unsigned long long *bck;          // best child: f << 32 | ~index
+    uint32_t *sbase;                  // per chain start: f(parent of the start) | has a child << 31
     int *mem;                         // member lists of the chains (phase C scratch, one slot per anchor)
     int *root;                        // chain id of every anchor (index of the chain's start inside the group)
     unsigned long long *peak;         // per chain, at its root: best f << 32 | ~(first index reaching it)
@@ -230,7 +229,6 @@ struct ChainArgs {
     FixPt *fps;
     uint32_t cap_pieces, cap_fps;
     uint32_t *counters;               // [0] pieces, [1] fixed-point slots reserved, [2] overflow flag, [3] fixed points written
-    int dbg_phases;                   // timing ablation only (HLMI_CHAIN_PHASES): 1 = A, 3 = A+B, 7 = all
 };
 
 // Chain walk (phase C).  A 64-anchor window of the group is held in registers (lane l = anchor base+l):
@@ -324,6 +322,7 @@ constexpr int PEN_TAB = 2048;         // gap-cost table entries (bandwidth + 2 m
 // CHAIN_GROUPS consecutive groups per wave, CHAIN_WAVES independent waves per workgroup: group sizes span three
 // orders of magnitude, so the balancing is left to the hardware dispatcher (a fixed grid-stride split of the
 // groups left the SIMDs at 3 of 8 resident waves on average).
+constexpr int BC_RING = 256;         // best-child ring: this block, the two before (still read), one spare
 constexpr int CHAIN_GROUPS = 4;
 constexpr int CHAIN_WAVES = 1;      // (4 waves sharing one gap-cost table measured 5 % slower)
 // TAB: 0 = gap cost computed, 1 = byte table (the index is the LDS address), 2 = 16-bit table
@@ -331,6 +330,8 @@ template <int TAB>
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     typedef typename std::conditional<TAB == 1, uint8_t, uint16_t>::type pen_t;
     __shared__ pen_t pen_tab[TAB ? PEN_TAB : 1];
+    __shared__ unsigned long long s_bc[CHAIN_WAVES][BC_RING];      // best child of the anchors of the last few blocks
+    unsigned long long *bc = s_bc[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     if (TAB) {
         for (int d = threadIdx.x; d < a.bw + 2; d += 64 * CHAIN_WAVES)
@@ -386,6 +387,54 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             }
             w = ok ? (dg < M_s ? dg : M_s) - pen : -(1 << 30);
         };
+        // ---- chains without walking them --------------------------------------------------------------------------
+        // An anchor belongs to the chain of its parent when it is that parent's best child, else it starts a chain.
+        // Parents are at most 64 back, so once block B has voted the best children of block B-1's parents are final
+        // and the chain id ("root" = index of the start) of every anchor of block B-1 follows from the roots of block
+        // B-2 by pointer jumping inside the block (<= 6 rounds of one ds_bpermute).  Per anchor only the root goes to
+        // memory; a start also stores f(parent) and whether it has a child; the peak of every chain (max f, first
+        // index) is a 64-bit atomicMax keyed by the root - the chain owning the block's best f, the long one, sends
+        // one atomic for all its lanes.  f, p and the best-child ring never leave the wave.
+        for (int k = lane; k < BC_RING; k += 64) bc[k] = 0;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        int P1_f = 0, P1_p = -1, P2_f = 0;                 // f / p of the block before, f of the one before that
+        int prev_root = 0;                                 // roots of the last resolved block (lane = index mod 64)
+        auto resolve = [&](int w0, int Rf, int Rp, int Bf) {
+            const int i = w0 + lane;
+            const bool live = i < n;
+            const int pi = live ? Rp : -1;
+            bool child = false, has_child = false;
+            int val = 0;                                   // val >= 0: root; val < 0: ~lane of the parent (same block)
+            if (live) {
+                child = pi >= 0 && (0xffffffffu - (uint32_t)(bc[pi & (BC_RING - 1)] & 0xffffffffull)) == (uint32_t)i;
+                has_child = bc[i & (BC_RING - 1)] != 0;
+                val = !child ? i : ~(pi - w0);
+            }
+            // every lane takes part in the shuffles (ds_bpermute reads 0 from idle lanes)
+            const int from_prev = __shfl(prev_root, (pi - w0 + 64) & 63, 64);
+            const int f_same = __shfl(Rf, pi & 63, 64), f_before = __shfl(Bf, pi & 63, 64);
+            if (child && pi < w0) val = from_prev;
+            while (__ballot(val < 0)) {
+                const int up = __shfl(val, val < 0 ? ~val : lane, 64);
+                if (val < 0) val = up;                     // parent resolved: its root; else jump to the parent's parent
+            }
+            if (live) {
+                a.root[b + i] = val;
+                if (val == i) a.sbase[b + i] = (uint32_t)(pi < 0 ? 0 : (pi >= w0 ? f_same : f_before)) | (has_child ? 0x80000000u : 0u);
+            }
+            prev_root = val;
+            // peaks: f << 32 | ~index, max = highest f, first index among equals
+            const uint32_t k32 = live ? (uint32_t)Rf << 6 | (uint32_t)(63 - lane) : 0u;
+            const uint32_t kmax = wave_max_u32_dpp(k32);
+            const int lmax = 63 - (int)(kmax & 63u);
+            const int rmax = __builtin_amdgcn_readlane(val, lmax);
+            if (live && (val != rmax || lane == lmax))
+                atomicMax(&a.peak[b + val], (unsigned long long)(uint32_t)Rf << 32 | (0xffffffffu - (uint32_t)i));
+            // the votes for the block before this one have served their purpose: its ring slots are free for the block
+            // three ahead (this block's own are still read when the next one is resolved)
+            bc[(i - 64) & (BC_RING - 1)] = 0;
+        };
         for (int i0 = 0; i0 < n; i0 += 64) {
             if (i0) { N_t = P_t; N_q = P_q; N_s = P_s; }
             load_block(i0 + 128, P_t, P_q, P_s);              // in flight during this block
@@ -409,69 +458,31 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                 prepare(jl + 1 < nb ? jl + 1 : jl, w_nxt);    // (the repeat at the block end is idempotent, its w unused)
                 w_cur = w_nxt;
             }
-            if (i0 + lane < n) {
-                a.f[b + i0 + lane] = O_f;
-                a.p[b + i0 + lane] = O_p;
-                if ((a.dbg_phases & 2) && O_p >= 0)
-                    atomicMax(&a.bck[b + O_p], (unsigned long long)(uint32_t)O_f << 32 | (0xffffffffu - (uint32_t)(i0 + lane)));
-            }
+            // best child of the parents (they sit in this block or the one before): 64-bit max of f << 32 | ~index in LDS
+            if (i0 + lane < n && O_p >= 0)
+                atomicMax(&bc[O_p & (BC_RING - 1)], (unsigned long long)(uint32_t)O_f << 32 | (0xffffffffu - (uint32_t)(i0 + lane)));
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            if (i0) resolve(i0 - 64, P1_f, P1_p, P2_f);       // every child of the block before has voted now
+            P2_f = P1_f; P1_f = O_f; P1_p = O_p;
         }
-        __threadfence_block();
-        if (!(a.dbg_phases & 4)) continue;
-        // ---- phase C: chains without walking them ------------------------------------------------------------------
-        // An anchor belongs to the chain of its parent when it is that parent's best child, else it starts a chain;
-        // parents are at most 64 back, so the chain id ("root" = index of the start) of a 64-anchor window follows
-        // from the window before it by pointer jumping inside the window (<= 6 rounds of one ds_bpermute).  C1 stores
-        // the roots and the peak of every chain (max f, first index: 64-bit atomicMax keyed by the root; the chain
-        // owning the window's best f - the long one - sends one atomic for all its lanes).  C2 then turns each chain
-        // that scores enough into its member list up to the peak, a ballot per window.
-        int prev_root = 0;                                 // roots of the window before (lane = index mod 64)
-        for (int w0 = 0; w0 < n; w0 += 64) {
-            const int i = w0 + lane;
-            const bool live = i < n;
-            int val = 0, fi = 0, pi = -1;                  // val >= 0: root; val < 0: ~lane of the parent (same window)
-            bool child = false;
-            if (live) {
-                pi = a.p[b + i];
-                fi = a.f[b + i];
-                child = pi >= 0 && (0xffffffffu - (uint32_t)(a.bck[b + pi] & 0xffffffffull)) == (uint32_t)i;
-                val = !child ? i : ~(pi - w0);
-            }
-            const int from_prev = __shfl(prev_root, (pi - w0 + 64) & 63, 64);    // every lane takes part (bpermute reads 0 from idle lanes)
-            if (child && pi < w0) val = from_prev;
-            while (__ballot(val < 0)) {
-                const int up = __shfl(val, val < 0 ? ~val : lane, 64);
-                if (val < 0) val = up;                     // parent resolved: its root; else jump to the parent's parent
-            }
-            if (live) a.root[b + i] = val;
-            prev_root = val;
-            // peaks: f << 32 | ~index, max = highest f, first index among equals
-            const uint32_t k32 = live ? (uint32_t)fi << 6 | (uint32_t)(63 - lane) : 0u;
-            const uint32_t kmax = wave_max_u32_dpp(k32);
-            const int lmax = 63 - (int)(kmax & 63u);
-            const int rmax = __builtin_amdgcn_readlane(val, lmax);
-            if (live && (val != rmax || lane == lmax))
-                atomicMax(&a.peak[b + val], (unsigned long long)(uint32_t)fi << 32 | (0xffffffffu - (uint32_t)i));
-        }
+        resolve((n - 1) & ~63, P1_f, P1_p, P2_f);
         __threadfence_block();
         int moff = 0;                                      // member lists of the group's chains are disjoint
         for (int s0 = 0; s0 < n; s0 += 64) {
-            int ps = -1, fps_ = 0, pk_f = 0, pk_i = 0;
+            int pk_i = 0;
             bool cand = false;
             if (s0 + lane < n) {
                 const int s = s0 + lane;
                 if (a.root[b + s] == s) {
-                    ps = a.p[b + s];
-                    if (ps >= 0) fps_ = a.f[b + ps];
+                    const uint32_t sb = a.sbase[b + s];     // f(parent of the start) | has a child << 31
                     const unsigned long long pk = a.peak[b + s];
-                    pk_f = (int)(pk >> 32);
                     pk_i = (int)(0xffffffffu - (uint32_t)(pk & 0xffffffffull));
                     // a childless start is a one-anchor chain: it can only survive when min_cnt <= 1
-                    cand = pk_f - fps_ >= a.min_score && (a.min_cnt <= 1 || a.bck[b + s] != 0);
+                    cand = (int)(pk >> 32) - (int)(sb & 0x7fffffffu) >= a.min_score && (a.min_cnt <= 1 || (sb >> 31));
                 }
             }
             unsigned long long cm = __ballot(cand);
-            if (a.dbg_phases & 8) cm = 0;
             while (cm) {
                 const int l = __ffsll((long long)cm) - 1;
                 cm &= cm - 1;
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                     best_len += __popcll(mm);
                 }
                 moff += best_len;
-                if (best_len < a.min_cnt || (a.dbg_phases & 16)) continue;
+                if (best_len < a.min_cnt) continue;
                 __threadfence_block();
                 uint32_t np = 0, nf = 0, fb = 0;
                 if (lane == 0) fb = atomicAdd(&a.counters[1], 2u * (uint32_t)best_len);
@@ -657,9 +668,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     delete ht_s;
 
     HostTimer ht_c("chain_phase");
-    DBuf<int32_t> f(A), p(A);
-    DBuf<unsigned long long> bck(A);
-    bck.zero();
+
     DBuf<uint32_t> counters(4);
     counters.zero();
     ChainArgs ca{};
@@ -667,11 +676,11 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     DBuf<int> mem(A), root(A);
     DBuf<unsigned long long> peak(A);
     peak.zero();
-    ca.f = f.p; ca.p = p.p; ca.bck = bck.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
+    DBuf<uint32_t> sbase(A);
+    ca.sbase = sbase.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
-    ca.dbg_phases = getenv("HLMI_CHAIN_PHASES") ? atoi(getenv("HLMI_CHAIN_PHASES")) : 7;
     ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);
     ca.cap_fps = (uint32_t)std::min<size_t>(2 * A + 1024, 0xfffffff0u);
     out.pieces.alloc(ca.cap_pieces);
