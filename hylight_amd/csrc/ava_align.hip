@@ -329,6 +329,7 @@ __global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, ui
 //   * a diagonal of the traceback is then a run of ones in ONE word: count-trailing-ones finds its length, the
 //     NE word its mismatches; the walk is per event, not per base, and is done twice (count, then write) so the
 //     runs go straight into the pool in forward order.
+constexpr int DP_BIAS = 1 << 24;             // added to every DP score: 0 then acts as -inf (block scores stay within +-4096)
 constexpr int NT_PAD = 16;                   // st index of target offset 0
 constexpr int NT_EXTRA = NT_PAD + NARROW_DELTA + NARROW_W + 7;     // st length = rows + NT_EXTRA
 enum { PL_DIAG = 0, PL_EGEF, PL_EEXT, PL_FEXT, PL_NE, N_PLANES };
@@ -405,20 +406,24 @@ __device__ __forceinline__ void narrow_rows(const AlignArgs &a, int rows, int m,
                                             const uint8_t *st, uint32_t (*pl)[NR_CHUNKS][64], int lane, int &Hend) {
     const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * l, goel = go + ge * l;
     const int j0 = dlo + l;
-    int H = j0 == 0 ? 0 : (j0 > 0 ? -(go + ge * j0) : NEG_INF);       // row 0
+    // scores carry DP_BIAS and "-inf" is 0 (plus or minus a few hundred): lanes a DPP shift has no source for
+    // are then simply zero-filled (bound_ctrl), no identity register to rebuild every row
+    int H = j0 == 0 ? DP_BIAS : (j0 > 0 ? DP_BIAS - (go + ge * j0) : 0);      // row 0
     int G = H - goe;                                                 // max(H - open - ext, F - ext) with F = -inf
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
     const uint8_t *tp = st + NT_PAD + dlo + l - 1;                    // target base of row i: tp[i]
+    int v_match = a.match, v_mis = -a.mismatch;
+    asm volatile("" : "+v"(v_match), "+v"(v_mis));                    // keep the two select operands in registers
     int qa = sq[0], t2 = tp[1];
     for (int i = 1; i <= rows; ++i) {
         const int qa_next = sq[i], t2_next = tp[i + 1];               // the next row's bases are in flight during this row
         const bool ne = qa != t2;
-        int s = ne ? -a.mismatch : a.match;
+        int s = ne ? v_mis : v_match;
         if (AMBI) s = (qa | t2) > 3 ? -a.ambi : s;
         const int mm = H + s;
-        const int f = row_shl1(G, NEG_INF);                           // from lane d+1 of the row above
+        const int f = row_shl1(G, 0);                                 // from lane d+1 of the row above
         const int ht = mm > f ? mm : f;
-        const int e = row_shr1(row_prefix_max_incl_dpp(ht + gel), NEG_INF * 2) - goel;
+        const int e = row_shr1(row_prefix_max_incl_dpp(ht + gel), 0) - goel;
         const int h = ht > e ? ht : e;
         const int fo = h - goe, fe = f - ge;
         a0 = shift_in(a0, mm == h);
@@ -493,10 +498,10 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const int rows = (int)wave_max_u32_dpp(live ? (uint32_t)m : 0u);
-        int Hend = NEG_INF;
+        int Hend = 0;
         if (__any(ambig)) narrow_rows<true, NR_CHUNKS>(a, rows, m, dlo, l, sq, st, pl, lane, Hend);
         else narrow_rows<false, NR_CHUNKS>(a, rows, m, dlo, l, sq, st, pl, lane, Hend);
-        const int score = __shfl(Hend, g * 16 + ((n - m - dlo) & (NARROW_W - 1)), 64);
+        const int score = __shfl(Hend, g * 16 + ((n - m - dlo) & (NARROW_W - 1)), 64) - DP_BIAS;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         if (live && l == 0) {
@@ -527,24 +532,26 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
                                           int &best_h, int &best_i) {
     const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * lane, goel = go + ge * lane;
     const int j0 = dlo + lane;
-    int H = j0 == 0 ? 0 : (j0 > 0 ? -(go + ge * j0) : NEG_INF);       // row 0
+    int H = j0 == 0 ? DP_BIAS : (j0 > 0 ? DP_BIAS - (go + ge * j0) : 0);      // row 0 (biased scores, see narrow_rows)
     int G = H - goe;
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    int v_match = a.match, v_mis = -a.mismatch;
+    asm volatile("" : "+v"(v_match), "+v"(v_mis));
     const uint8_t *tp = st + WT_PAD + dlo + lane - 1;                 // target base of row i: tp[i]
     // cell (i, j) is inside the rectangle for imin <= i <= imax (j = i + dlo + lane)
     const int imin = -j0, span = n - j0 - imin;                       // span < 0: never
-    best_h = NEG_INF; best_i = 0;
+    best_h = 0; best_i = 0;                                           // biased like H: 0 = no cell yet
     if (EXT && j0 >= 0 && j0 <= n) best_h = H;                        // row 0 (only (0,0) can win, the rest is a gap from it)
     int qa = sq[0], t2 = tp[1];
     for (int i = 1; i <= m; ++i) {
         const int qa_next = sq[i], t2_next = tp[i + 1];
         const bool ne = qa != t2;
-        int s = ne ? -a.mismatch : a.match;
+        int s = ne ? v_mis : v_match;
         if (AMBI) s = (qa | t2) > 3 ? -a.ambi : s;
         const int mm = H + s;
-        const int f = wave_shl1(G, NEG_INF);
+        const int f = wave_shl1(G, 0);
         const int ht = mm > f ? mm : f;
-        const int e = wave_shr1(wave_prefix_max_incl_dpp(ht + gel), NEG_INF * 2) - goel;
+        const int e = wave_shr1(wave_prefix_max_incl_dpp(ht + gel), 0) - goel;
         const int h = ht > e ? ht : e;
         const int fo = h - goe, fe = f - ge;
         a0 = shift_in(a0, mm == h);
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const int end_row = kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
-        int Hend = NEG_INF, best_h = NEG_INF, best_i = 0;
+        int Hend = 0, best_h = 0, best_i = 0;
         const bool amb = __any(ambig);
         if (kind == 0) {
             if (amb) wide_rows<true, false>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
@@ -626,12 +633,12 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         int ei, ej, score;
         if (kind == 0) {
             ei = m; ej = n;
-            score = __shfl(Hend, n - m - dlo, 64);
+            score = __shfl(Hend, n - m - dlo, 64) - DP_BIAS;
         } else {
             // best cell: score (with the bonus), then fewest bases i + j, then fewest rows
             unsigned long long best = 0;
-            if (best_h > NEG_INF / 2)
-                best = (unsigned long long)(uint32_t)(best_h + (1 << 20)) << 32 |
+            if (best_h > DP_BIAS / 2)
+                best = (unsigned long long)(uint32_t)(best_h - DP_BIAS + (1 << 20)) << 32 |
                        (unsigned long long)(0xffffu - (uint32_t)(2 * best_i + dlo + lane)) << 16 |
                        (unsigned long long)(0xffffu - (uint32_t)best_i);
 #pragma unroll
