@@ -11,7 +11,7 @@ Workload at N=1 = BASELINE.json configs[1] (C2): 10 000 synthetic ONT reads, mea
 400 kb, --nsplit 100; the stage constants are those of the reference's main all-vs-all call
 (script/HyLight.py:130: len_over=6000, mc=2, iden=0.95).  With N>1 the --nsplit target chunks are
 sharded over the ranks (chunk i -> rank i % N), every rank sketches 1/N of the reads and the sketches
-are all-gathered over RCCL; the read set is fixed, so scaling is "strong".
+are all-gathered over RCCL; the read set is fixed whatever N is, so scaling is "strong".
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
@@ -236,10 +236,10 @@ def main():
 
     line = dict(metric="long-read all-vs-all overlaps/sec", value=value, unit="overlaps/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
-                scaling="strong" if world > 1 else "weak", vs_baseline=None, dtype="u8/int32", data="synthetic",
+                scaling="strong", vs_baseline=None, dtype="u8/int32", data="synthetic",
                 config=dict(workload=f"{args.workload}: {wl['n_reads']} synthetic ONT reads, mean {wl['mean_len']} bp, "
                                      f"{wl['n_strains']} strains x {wl['genome_len']} bp, ava, --nsplit {wl['nsplit']}",
-                            nsplit=wl["nsplit"], parallelism=f"chunks%{world}", **STAGE,
+                            nsplit=wl["nsplit"], parallelism=f"chunks%{world}", **wl.get("stage", STAGE),
                             overlaps_out=rows, candidate_rows=stats.get("ava_rows"), anchors=A),
                 roofline=roof,
                 stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})

@@ -414,14 +414,12 @@ __device__ __forceinline__ void narrow_rows(const AlignArgs &a, int rows, int m,
     const uint8_t *tp = st + NT_PAD + dlo + l - 1;                    // target base of row i: tp[i]
     int v_match = a.match, v_mis = -a.mismatch;
     asm volatile("" : "+v"(v_match), "+v"(v_mis));                    // keep the two select operands in registers
-    int qa = sq[0], t2 = tp[1];
-    for (int i = 1; i <= rows; ++i) {
-        const int qa_next = sq[i], t2_next = tp[i + 1];               // the next row's bases are in flight during this row
+    auto row = [&](int i, int qa, int t2) {
         const bool ne = qa != t2;
         int s = ne ? v_mis : v_match;
         if (AMBI) s = (qa | t2) > 3 ? -a.ambi : s;
         const int mm = H + s;
-        const int f = row_shl1(G, 0);                                 // from lane d+1 of the row above
+        const int f = row_shl1_z(G);                                  // from lane d+1 of the row above
         const int ht = mm > f ? mm : f;
         const int e = row_shr1(row_prefix_max_incl_dpp(ht + gel), 0) - goel;
         const int h = ht > e ? ht : e;
@@ -433,14 +431,24 @@ __device__ __forceinline__ void narrow_rows(const AlignArgs &a, int rows, int m,
         a4 = shift_in(a4, ne);
         G = fo > fe ? fo : fe;
         H = h;
-        qa = qa_next; t2 = t2_next;
         if (i == m) Hend = h;
-        if ((i & 31) == 0) {
-            const int c = (i >> 5) - 1;
+    };
+    // two rows per trip (the bases of the next two rows are in flight meanwhile); a word of the planes fills up on
+    // an even row
+    int qa = sq[0], t2 = tp[1];
+    int i = 1;
+    for (; i < rows; i += 2) {
+        const int qb = sq[i], tb = tp[i + 1], qc = sq[i + 1], tc = tp[i + 2];
+        row(i, qa, t2);
+        row(i + 1, qb, tb);
+        qa = qc; t2 = tc;
+        if (((i + 1) & 31) == 0) {
+            const int c = ((i + 1) >> 5) - 1;
             pl[PL_DIAG][c][lane] = a0; pl[PL_EGEF][c][lane] = a1; pl[PL_EEXT][c][lane] = a2; pl[PL_FEXT][c][lane] = a3;
             pl[PL_NE][c][lane] = a4;
         }
     }
+    if (i == rows) row(i, qa, t2);                                    // odd row count (rows is odd: no word boundary here)
     if (rows & 31) {        // partial word: move its first row up to bit 31
         const int c = rows >> 5, up = 32 - (rows & 31);
         pl[PL_DIAG][c][lane] = a0 << up; pl[PL_EGEF][c][lane] = a1 << up; pl[PL_EEXT][c][lane] = a2 << up;
@@ -549,7 +557,7 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
         int s = ne ? v_mis : v_match;
         if (AMBI) s = (qa | t2) > 3 ? -a.ambi : s;
         const int mm = H + s;
-        const int f = wave_shl1(G, 0);
+        const int f = wave_shl1_z(G);
         const int ht = mm > f ? mm : f;
         const int e = wave_shr1(wave_prefix_max_incl_dpp(ht + gel), 0) - goel;
         const int h = ht > e ? ht : e;

@@ -91,6 +91,10 @@ __device__ __forceinline__ int select_by_mask(unsigned long long mask, int yes, 
     return r;
 }
 
+// zero-filling one-lane shifts: a single v_mov_b32_dpp ... bound_ctrl:1 (no `old` register to prepare)
+__device__ __forceinline__ int row_shl1_z(int x) { return __builtin_amdgcn_mov_dpp(x, 0x101, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_shl1_z(int x) { return __builtin_amdgcn_mov_dpp(x, 0x130, 0xf, 0xf, true); }
+
 // lane i <- lane i-1 (lane 0 keeps `lane0`)
 __device__ __forceinline__ int wave_shr1(int x, int lane0) { return dpp_i32<0x138>(lane0, x); }
 // lane i <- lane i+1 (lane 63 keeps `lane63`)
