@@ -806,7 +806,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     DBuf<uint32_t> tcnt(P), toff(P);
     hipLaunchKernelGGL(piece_task_count_kernel, grid1(P), dim3(WG), 0, stream(), ch.pieces.p, P, tcnt.p);
     exclusive_scan_u32(tcnt.p, toff.p, P);
-    const size_t NT = (size_t)download_one(toff.p + (P - 1)) + download_one(tcnt.p + (P - 1));
+    const size_t NT = ch.n_fp + P;              // a piece of n fixed points has n - 1 blocks and two extensions
     DBuf<Task> tasks(NT);
     hipLaunchKernelGGL(make_tasks_kernel, grid1(P), dim3(WG), 0, stream(), ch.pieces.p, ch.fps.p, toff.p, P, d_qlen, d_tlen,
                        in.Q->off.p, in.T->off.p, tasks.p);
@@ -846,8 +846,12 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p, f3.p);
         HIP_CHECK(hipGetLastError());
         DBuf<uint32_t> list1(NT), list2(NT), list3(NT);
-        const size_t n1 = select_flagged_indices(f1.p, list1.p, NT), n2 = select_flagged_indices(f2.p, list2.p, NT),
-                     n3 = select_flagged_indices(f3.p, list3.p, NT);
+        DBuf<uint32_t> list_n(3);
+        select_flagged_indices_async(f1.p, list1.p, NT, list_n.p);
+        select_flagged_indices_async(f2.p, list2.p, NT, list_n.p + 1);
+        select_flagged_indices_async(f3.p, list3.p, NT, list_n.p + 2);
+        const std::vector<uint32_t> hn = list_n.download(3);
+        const size_t n1 = hn[0], n2 = hn[1], n3 = hn[2];
         for (int which = 0; which < 2; ++which) {
             uint32_t *lst = which ? list3.p : list1.p;
             const size_t nl = which ? n3 : n1;

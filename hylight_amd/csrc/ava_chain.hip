@@ -638,7 +638,8 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     const uint32_t *cnt = plan.cnt.p + in.qmz_off[q_lo];
     DBuf<uint64_t> aoff(sa.n_mz);
     exclusive_scan_u32_to_u64(cnt, aoff.p, sa.n_mz);
-    const size_t A = (size_t)(download_one(aoff.p + (sa.n_mz - 1)) + download_one(cnt + (sa.n_mz - 1)));
+    size_t A = 0;                               // the plan knows the anchors of every query: no round trip to the device
+    for (size_t q = q_lo; q < q_hi; ++q) A += plan.per_query[q];
     st.anchors += A;
     stat_add("anchor_bytes", (double)A * (vb ? 8.0 : 16.0));
     if (!A) return;

@@ -22,6 +22,8 @@ void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n);
 // writes the indices i with flags[i] != 0 (ascending) to out_idx; returns their count (the only call here that waits
 // for the device: the count goes back to the host)
 size_t select_flagged_indices(const uint8_t *flags, uint32_t *out_idx, size_t n);
+// same, the count goes to *d_count (device): several selections can then share one trip to the host
+void select_flagged_indices_async(const uint8_t *flags, uint32_t *out_idx, size_t n, uint32_t *d_count);
 // number of significant bits of the maximum key value helper
 inline int bits_for(uint64_t max_value) {
     int b = 1;

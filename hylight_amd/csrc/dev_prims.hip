@@ -40,11 +40,13 @@ __global__ __launch_bounds__(WG) void flag_count_kernel(const uint8_t *flags, si
     const unsigned long long m = __ballot(i < n && flags[i] != 0);
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) cnt[i >> 6] = (uint32_t)__popcll(m);
 }
-__global__ __launch_bounds__(WG) void flag_scatter_kernel(const uint8_t *flags, size_t n, const uint32_t *off, uint32_t *out_idx) {
+__global__ __launch_bounds__(WG) void flag_scatter_kernel(const uint8_t *flags, size_t n, const uint32_t *off, uint32_t *out_idx,
+                                                           uint32_t *total) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const bool f = i < n && flags[i] != 0;
     const unsigned long long m = __ballot(f);
     if (f) out_idx[off[i >> 6] + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)i;
+    if (i == n - 1) *total = off[i >> 6] + (uint32_t)__popcll(m);      // the wave that holds the last element
 }
 }  // namespace
 
@@ -95,17 +97,23 @@ void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n) {
 // Three small launches instead of rocprim::select: set bits per 64 flags (ballot), their exclusive scan, scatter by
 // ballot rank.  The flags are read twice (1 B each); on the 5e7-element head arrays of the anchor batches this is
 // several times quicker than the look-back partition, and most calls of a step are such selections.
-size_t select_flagged_indices(const uint8_t *flags, uint32_t *out_idx, size_t n) {
-    if (!n) return 0;
+void select_flagged_indices_async(const uint8_t *flags, uint32_t *out_idx, size_t n, uint32_t *d_count) {
+    if (!n) { HIP_CHECK(hipMemsetAsync(d_count, 0, 4, stream())); return; }
     if (n >= (1ull << 32)) fail(HLMI_EINVAL, "select_flagged_indices: more than 2^32 elements");
     const size_t nw = (n + 63) / 64;
     DBuf<uint32_t> cnt(nw), off(nw);
     const dim3 grid(cdiv(n, WG));
     hipLaunchKernelGGL(flag_count_kernel, grid, dim3(WG), 0, stream(), flags, n, cnt.p);
     exclusive_scan_u32(cnt.p, off.p, nw);
-    hipLaunchKernelGGL(flag_scatter_kernel, grid, dim3(WG), 0, stream(), flags, n, off.p, out_idx);
+    hipLaunchKernelGGL(flag_scatter_kernel, grid, dim3(WG), 0, stream(), flags, n, off.p, out_idx, d_count);
     HIP_CHECK(hipGetLastError());
-    return (size_t)download_one(off.p + (nw - 1)) + download_one(cnt.p + (nw - 1));
+}
+
+size_t select_flagged_indices(const uint8_t *flags, uint32_t *out_idx, size_t n) {
+    if (!n) return 0;
+    DBuf<uint32_t> total(1);
+    select_flagged_indices_async(flags, out_idx, n, total.p);
+    return (size_t)download_one(total.p);
 }
 
 }  // namespace hlmi

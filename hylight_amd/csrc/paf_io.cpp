@@ -242,12 +242,6 @@ int cmp_mag(const NumKey &a, const NumKey &b) {
     c = a.fp.compare(b.fp);   // digit strings without trailing zeros: lexicographic == numeric
     return c < 0 ? -1 : c > 0 ? 1 : 0;
 }
-int gnu_numcmp(std::string_view a, std::string_view b) {
-    NumKey x = gnu_num(a), y = gnu_num(b);
-    if (x.neg != y.neg) return x.neg ? -1 : 1;
-    int c = cmp_mag(x, y);
-    return x.neg ? -c : c;
-}
 std::string_view field_tail(std::string_view L, int k) {
     size_t p = 0;
     for (int i = 1; i < k; ++i) {
@@ -263,10 +257,13 @@ void sort_scored_lines(std::vector<std::string> &lines) {
     size_t n = lines.size();
     std::vector<uint32_t> idx(n);
     std::iota(idx.begin(), idx.end(), 0u);
-    std::vector<std::string_view> key(n);
-    for (size_t i = 0; i < n; ++i) key[i] = field_tail(lines[i], 12);
+    std::vector<NumKey> key(n);             // the numeric prefix of column 12.., parsed once per line
+    for (size_t i = 0; i < n; ++i) key[i] = gnu_num(field_tail(lines[i], 12));
     std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-        int c = gnu_numcmp(key[a], key[b]);
+        const NumKey &x = key[a], &y = key[b];
+        int c;
+        if (x.neg != y.neg) c = x.neg ? -1 : 1;
+        else { c = cmp_mag(x, y); if (x.neg) c = -c; }
         if (c) return c > 0;               // -r: descending
         return lines[a] > lines[b];        // last resort, reversed as well
     });
