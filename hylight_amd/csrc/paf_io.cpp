@@ -259,14 +259,15 @@ void sort_scored_lines(std::vector<std::string> &lines) {
     std::iota(idx.begin(), idx.end(), 0u);
     std::vector<NumKey> key(n);             // the numeric prefix of column 12.., parsed once per line
     for (size_t i = 0; i < n; ++i) key[i] = gnu_num(field_tail(lines[i], 12));
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+    auto less = [&](uint32_t a, uint32_t b) {
         const NumKey &x = key[a], &y = key[b];
         int c;
         if (x.neg != y.neg) c = x.neg ? -1 : 1;
         else { c = cmp_mag(x, y); if (x.neg) c = -c; }
         if (c) return c > 0;               // -r: descending
         return lines[a] > lines[b];        // last resort, reversed as well
-    });
+    };
+    std::sort(idx.begin(), idx.end(), less);
     std::vector<std::string> out;
     out.reserve(n);
     for (uint32_t i : idx) out.push_back(std::move(lines[i]));
