@@ -72,7 +72,8 @@ def pmc_traffic(timer, workload):
     if not files:
         return None
     d = json.load(open(files[-1]))
-    k = d.get(KERNEL_OF_TIMER.get(timer, ""))
+    name = KERNEL_OF_TIMER.get(timer, "")
+    k = next((v for n, v in d.items() if name and n.startswith(name)), None)      # template arguments follow the name
     return k["hbm_bytes_per_launch"] if k else None
 
 
