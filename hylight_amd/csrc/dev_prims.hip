@@ -66,6 +66,20 @@ void sort_keys_u64(uint64_t *keys, size_t n, int b0, int b1) {
         HIP_CHECK(hipMemcpyAsync(keys, dk.current(), n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()));
 }
 
+void sort_pairs_u64_u32(DBuf<uint64_t> &keys, DBuf<uint32_t> &vals, size_t n, int b0, int b1) {
+    if (n < 2) return;
+    DBuf<uint64_t> k2(keys.n);
+    DBuf<uint32_t> v2(vals.n);
+    rocprim::double_buffer<uint64_t> dk(keys.p, k2.p);
+    rocprim::double_buffer<uint32_t> dv(vals.p, v2.p);
+    size_t tmp_bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+    HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    if (dk.current() != keys.p) std::swap(keys, k2);
+    if (dv.current() != vals.p) std::swap(vals, v2);
+}
+
 void sort_keys_u64(DBuf<uint64_t> &keys, size_t n, int b0, int b1) {
     if (n < 2) return;
     DBuf<uint64_t> k2(keys.n);

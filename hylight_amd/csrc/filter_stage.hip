@@ -227,7 +227,7 @@ void sort_chunk_key(const uint32_t *d_chunk, const uint64_t *d_key, size_t n, ui
     if (cb + hb + lb <= 64) {
         DBuf<uint64_t> ck(n);
         hipLaunchKernelGGL(compact_ck_kernel, grid1(n), dim3(WG), 0, stream(), d_chunk, d_key, n, hb, lb, ck.p);
-        sort_pairs_u64_u32(ck.p, o.perm.p, n, 0, cb + hb + lb);
+        sort_pairs_u64_u32(ck, o.perm, n, 0, cb + hb + lb);
         hipLaunchKernelGGL(expand_ck_kernel, grid1(n), dim3(WG), 0, stream(), ck.p, n, hb, lb, o.chunk.p, o.key.p);
         return;
     }

@@ -3,6 +3,7 @@
 #include "paf_io.h"
 
 #include <algorithm>
+#include <thread>
 #include <cerrno>
 #include <cstdlib>
 #include <numeric>
@@ -254,20 +255,75 @@ std::string_view field_tail(std::string_view L, int k) {
 }  // namespace
 
 void sort_scored_lines(std::vector<std::string> &lines) {
-    size_t n = lines.size();
+    const size_t n = lines.size();
     std::vector<uint32_t> idx(n);
-    std::iota(idx.begin(), idx.end(), 0u);
-    std::vector<NumKey> key(n);             // the numeric prefix of column 12.., parsed once per line
-    for (size_t i = 0; i < n; ++i) key[i] = gnu_num(field_tail(lines[i], 12));
-    auto less = [&](uint32_t a, uint32_t b) {
-        const NumKey &x = key[a], &y = key[b];
-        int c;
-        if (x.neg != y.neg) c = x.neg ? -1 : 1;
-        else { c = cmp_mag(x, y); if (x.neg) c = -c; }
-        if (c) return c > 0;               // -r: descending
-        return lines[a] > lines[b];        // last resort, reversed as well
+    // The rows this library writes carry "%.4f" scores: non-negative, few integer digits, at most 4 decimals.  Such a
+    // key is an integer (value x 10^4): a counting sort on it, then the runs of equal scores by the text rule (the
+    // 8-byte head of a line settles nearly every tie without touching the strings; memcmp order = big-endian integer
+    // order).  Parsing and the tie runs go over the host threads.  Anything else in the column takes the general
+    // comparator.
+    struct Rec { uint32_t score, idx; uint64_t head; };
+    constexpr uint32_t SCORE_LIMIT = 1u << 22;                // 419.4304
+    std::vector<Rec> rec(n);
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), n / 4096));
+    std::vector<uint8_t> bad(nt, 0);
+    auto each_slice = [&](auto &&fn) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(fn, t);
+        fn(0);
+        for (auto &th : pool) th.join();
     };
-    std::sort(idx.begin(), idx.end(), less);
+    each_slice([&](int t) {
+        for (size_t i = n * (size_t)t / nt; i < n * (size_t)(t + 1) / nt; ++i) {
+            const NumKey k = gnu_num(field_tail(lines[i], 12));
+            uint64_t v = 0;
+            for (char c : k.ip) v = v * 10 + (uint64_t)(c - '0');
+            for (size_t d = 0; d < 4; ++d) v = v * 10 + (d < k.fp.size() ? (uint64_t)(k.fp[d] - '0') : 0u);
+            if (k.neg || k.ip.size() > 4 || k.fp.size() > 4 || v >= SCORE_LIMIT) { bad[t] = 1; return; }
+            uint64_t h = 0;
+            for (size_t d = 0; d < 8; ++d) h = h << 8 | (d < lines[i].size() ? (uint64_t)(unsigned char)lines[i][d] : 0u);
+            rec[i] = Rec{(uint32_t)v, (uint32_t)i, h};
+        }
+    });
+    bool simple = true;
+    for (uint8_t x : bad) simple = simple && !x;
+    if (simple && n) {
+        uint32_t hi = 0;
+        for (const Rec &r : rec) hi = std::max(hi, r.score);
+        std::vector<uint32_t> start(hi + 2, 0);               // descending: slot of score s = #records with a larger score
+        for (const Rec &r : rec) ++start[hi - r.score + 1];
+        for (uint32_t v = 1; v <= hi + 1; ++v) start[v] += start[v - 1];
+        std::vector<Rec> byscore(n);
+        {
+            std::vector<uint32_t> at(start.begin(), start.end() - 1);
+            for (const Rec &r : rec) byscore[at[hi - r.score]++] = r;
+        }
+        // tie runs: slices of whole score values
+        each_slice([&](int t) {
+            const uint32_t v0 = (uint32_t)((uint64_t)(hi + 1) * t / nt), v1 = (uint32_t)((uint64_t)(hi + 1) * (t + 1) / nt);
+            for (uint32_t v = v0; v < v1; ++v) {
+                const uint32_t lo = start[v], up = start[v + 1];
+                if (up - lo > 1)
+                    std::sort(byscore.begin() + lo, byscore.begin() + up, [&](const Rec &a, const Rec &b) {
+                        if (a.head != b.head) return a.head > b.head;
+                        return lines[a.idx] > lines[b.idx];
+                    });
+            }
+        });
+        for (size_t i = 0; i < n; ++i) idx[i] = byscore[i].idx;
+    } else {
+        std::iota(idx.begin(), idx.end(), 0u);
+        std::vector<NumKey> key(n);             // the numeric prefix of column 12.., parsed once per line
+        for (size_t i = 0; i < n; ++i) key[i] = gnu_num(field_tail(lines[i], 12));
+        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+            const NumKey &x = key[a], &y = key[b];
+            int c;
+            if (x.neg != y.neg) c = x.neg ? -1 : 1;
+            else { c = cmp_mag(x, y); if (x.neg) c = -c; }
+            if (c) return c > 0;               // -r: descending
+            return lines[a] > lines[b];        // last resort, reversed as well
+        });
+    }
     std::vector<std::string> out;
     out.reserve(n);
     for (uint32_t i : idx) out.push_back(std::move(lines[i]));
