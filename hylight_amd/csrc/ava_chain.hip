@@ -217,7 +217,7 @@ struct ChainArgs {
     const uint32_t *gstart;
     size_t n_groups, n_anchors;
     uint32_t *sbase;                  // per chain start: f(parent of the start) | has a child << 31
-    int *mem;                         // member lists of the chains (phase C scratch, one slot per anchor)
+    int *mem;                         // member lists of the chains that score enough (scratch, one slot per anchor)
     int *root;                        // chain id of every anchor (index of the chain's start inside the group)
     unsigned long long *peak;         // per chain, at its root: best f << 32 | ~(first index reaching it)
     int k, max_gap, bw, min_score, min_cnt;
@@ -231,10 +231,6 @@ struct ChainArgs {
     uint32_t *counters;               // [0] pieces, [1] fixed-point slots reserved, [2] overflow flag, [3] fixed points written
 };
 
-// Chain walk (phase C).  A 64-anchor window of the group is held in registers (lane l = anchor base+l):
-// chains only move forward through the group (children have larger indices, a best child is at most
-// CHAIN_PRED ahead), so a walk touches every anchor once, window loads are coalesced and the walk itself runs
-// on v_readlane instead of dependent global loads.  All lanes execute it uniformly.
 // target position, query position, span of anchor idx
 __device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, int &t, int &q, int &sp) {
     const uint64_t key = a.key[idx];
@@ -346,7 +342,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         const size_t e = g + 1 < a.n_groups ? (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g + 1]) : a.n_anchors;
         const int n = (int)(e - b);
         if (n < a.min_cnt) continue;
-        // ---- phase A: DP;  phase B: best child of every anchor (64-bit atomicMax of f << 32 | ~index) ----------
+        // ---- DP ---------------------------------------------------------------------------------------------------
         // "Push" form of the recurrence: lane l holds the anchor with index = l mod 64 among the 64 that FOLLOW the
         // anchor j being finished (M_*: position, span, best score so far + 1 / best predecessor).  Step j reads the
         // finished f(j) from lane j % 64, hands that lane to anchor j + 64 (N_*: the next 64 anchors, loaded a block
