@@ -188,6 +188,16 @@ __global__ void gather_u64_at_kernel(const uint64_t *src, const uint64_t *idx, u
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
+// sort key that puts the big groups first: the hardware hands workgroups out in order, so the long groups start
+// early and the tail of a launch is made of small ones
+__global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, size_t n_anchors, uint32_t *key, uint32_t *order) {
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const size_t e = g + 1 < n_groups ? gstart[g + 1] : n_anchors;
+    const uint32_t sz = (uint32_t)(e - gstart[g]);
+    key[g] = 0xffffu - (sz < 0xffffu ? sz : 0xffffu);
+    order[g] = (uint32_t)g;
+}
 __global__ void group_head_kernel(const uint64_t *key, size_t n, int pb, uint8_t *head) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) head[i] = (i == 0 || (key[i] >> pb) != (key[i - 1] >> pb)) ? 1 : 0;
@@ -215,6 +225,7 @@ __device__ __forceinline__ bool block_ok(int q0, int t0, int q1, int t1) {
 struct ChainArgs {
     const uint64_t *key, *val;
     const uint32_t *gstart;
+    const uint32_t *gorder;           // groups, largest first (the order the workgroups take them in)
     size_t n_groups, n_anchors;
     uint32_t *sbase;                  // per chain start: f(parent of the start) | has a child << 31
     int *mem;                         // member lists of the chains that score enough (scratch, one slot per anchor)
@@ -337,7 +348,8 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
     const size_t g_hi = g_lo + CHAIN_GROUPS < a.n_groups ? g_lo + CHAIN_GROUPS : a.n_groups;
     uint32_t wave_fps = 0;                                 // fixed points actually written by this wave (statistics)
-    for (size_t g = g_lo; g < g_hi; ++g) {
+    for (size_t gi = g_lo; gi < g_hi; ++gi) {
+        const size_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gorder[gi]);
         const size_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g]);
         const size_t e = g + 1 < a.n_groups ? (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g + 1]) : a.n_anchors;
         const int n = (int)(e - b);
@@ -669,7 +681,12 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     DBuf<uint32_t> counters(4);
     counters.zero();
     ChainArgs ca{};
-    ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.n_groups = G; ca.n_anchors = A;
+    DBuf<uint32_t> gkey(G ? G : 1), gorder(G ? G : 1);
+    if (G) {
+        hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p);
+        sort_pairs_u32_u32(gkey.p, gorder.p, G, 0, 16);
+    }
+    ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
     DBuf<int> mem(A), root(A);
     DBuf<unsigned long long> peak(A);
     peak.zero();
