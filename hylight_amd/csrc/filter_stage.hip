@@ -411,11 +411,18 @@ __global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_
     const uint32_t c = ev_chunk[b];
     const uint64_t key = ev_key[b];
     const uint64_t read0 = key & 0xffffffff00000000ull;
-    // #intervals of this read with start < pos  minus  #with end <= pos   (start < end holds for all)
-    int64_t n_start_lt = (int64_t)lower_bound_ck(ivs_chunk, ivs_key, n_iv, c, key) -
-                         (int64_t)lower_bound_ck(ivs_chunk, ivs_key, n_iv, c, read0);
-    int64_t n_end_le = (int64_t)lower_bound_ck(ive_chunk, ive_key, n_iv, c, key + 1) -
-                       (int64_t)lower_bound_ck(ive_chunk, ive_key, n_iv, c, read0);
+    // #intervals of this read with start < pos  minus  #with end <= pos   (start < end holds for all).
+    // Both arrays hold the same intervals grouped by (chunk, read), so the read's block [a, b) is the same index
+    // range in both: one full search for a, a short one for b (a read rarely has more than a few thousand
+    // intervals in a chunk), then two searches inside the block.
+    const size_t a = lower_bound_ck(ivs_chunk, ivs_key, n_iv, c, read0);
+    const uint64_t next_read = read0 + (1ull << 32);
+    size_t span = n_iv - a < 4096 ? n_iv - a : 4096;
+    if (span == 4096 && (ivs_chunk[a + span - 1] < c || (ivs_chunk[a + span - 1] == c && ivs_key[a + span - 1] < next_read)))
+        span = n_iv - a;                                         // a very deep read: search the rest
+    const size_t b_ = a + lower_bound_ck(ivs_chunk + a, ivs_key + a, span, c, next_read);
+    const int64_t n_start_lt = (int64_t)lower_bound_ck(ivs_chunk + a, ivs_key + a, b_ - a, c, key);
+    const int64_t n_end_le = (int64_t)lower_bound_ck(ive_chunk + a, ive_key + a, b_ - a, c, key + 1);
     int64_t con = n_start_lt - n_end_le;
     if (con - v < mc) return;
     for (size_t i = b; i < e; ++i) ev_supported[i] = 1;      // contiguous bytes; v is at most the read depth
