@@ -202,8 +202,9 @@ __device__ __forceinline__ uint64_t load_window8(const uint8_t *codes, long long
 }
 
 // One lane per task: a square block is compared 8 bases at a time and given up at the third mismatch (kmax <= 3
-// would still pass with 3), so the typical task costs 8-9 iterations of two 8-byte loads; the runs of the tasks
-// that finish here are allocated with one pool request per wave.
+// would still pass with 3), so the typical task costs 8-9 iterations of two 8-byte loads; a block with m != n gets
+// its common prefix / suffix measured the same way (second certificate below); the runs of the tasks that finish
+// here are allocated with one pool request per wave.
 __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls, unsigned long long *stats) {
     __shared__ unsigned long long s_stat[WAVES][N_ALIGN_STATS];
     const int lane = threadIdx.x & 63;
@@ -244,10 +245,57 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
                 }
             }
         }
-        const bool fast = try_fast && !ambig && k <= a.kmax;
+        bool fast = try_fast && !ambig && k <= a.kmax;
         uint32_t runs[7];
         uint32_t nr = 0;
-        if (fast) {
+        int fast_score = a.match * (m - k) - a.mismatch * k;
+        // Second certificate, blocks with m != n: if a prefix on the start diagonal and a suffix on the end diagonal
+        // match exactly and together cover the shorter sequence, "prefix, ONE gap of |n - m|, suffix" scores
+        // match * min(m,n) - open - ext * |n - m|, which no alignment of an m x n block can beat (fewer columns or
+        // more gap cost).  Every optimal alignment is then of this form; the traceback prefers the diagonal on ties,
+        // i.e. it leaves the end diagonal as late as it can: the gap sits at the leftmost admissible place.
+        if (live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
+            const bool rev = (tk.kind & TASK_REV) != 0;
+            const int mn = m < n ? m : n;
+            int lcp = 0, lcs = 0;
+            bool amb = false, open = true;
+            for (int x = 0; x < mn && open; x += 8) {                       // common prefix, elements x..x+7
+                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
+                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
+                const int left = mn - x;
+                const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
+                const uint64_t d = (q8 ^ t8) & keep;
+                const int same = d ? (__ffsll((long long)d) - 1) >> 3 : (left < 8 ? left : 8);
+                const uint64_t seen = same >= 8 ? ~0ull : (1ull << (8 * same)) - 1ull;
+                amb |= ((q8 | t8) & seen & 0x0404040404040404ull) != 0;
+                lcp = x + same;
+                open = d == 0;
+            }
+            open = true;
+            for (int y = 0; y < mn && open; y += 8) {                       // common suffix (all of it: it decides where
+                                                                              // the gap goes), elements end-8-y..end-1-y
+                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, m - 8 - y);
+                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, n - 8 - y);
+                const int left = mn - y;
+                const uint64_t keep = left >= 8 ? ~0ull : ~0ull << (8 * (8 - left));
+                const uint64_t d = (q8 ^ t8) & keep;
+                const int same = d ? __clzll((long long)d) >> 3 : (left < 8 ? left : 8);
+                const uint64_t seen = same >= 8 ? ~0ull : (same ? ~0ull << (8 * (8 - same)) : 0ull);
+                amb |= ((q8 | t8) & seen & 0x0404040404040404ull) != 0;
+                lcs = y + same;
+                open = d == 0;
+            }
+            if (!amb && lcp + lcs >= mn) {
+                const int gap = n > m ? n - m : m - n;
+                const int p0 = mn - lcs > 0 ? mn - lcs : 0;                   // leftmost place the suffix allows (<= lcp)
+                if (p0 > 0) runs[nr++] = (uint32_t)p0 << 4 | OP_EQ;
+                runs[nr++] = (uint32_t)gap << 4 | (n > m ? OP_D : OP_I);
+                if (mn - p0 > 0) runs[nr++] = (uint32_t)(mn - p0) << 4 | OP_EQ;
+                fast_score = a.match * mn - a.go - a.ge * gap;
+                fast = true;
+                c = 0;
+            }
+        } else if (fast) {
             c = 0;
             int prev = 0, xs = -1, xe = -1;
             for (int i = 0; i < k; ++i) {
@@ -271,7 +319,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         }
         if (fast) {
             if (ok) for (uint32_t q = 0; q < nr; ++q) a.runs[base + mine + q] = runs[q];
-            a.out[ti] = TaskOut{a.match * (m - k) - a.mismatch * k, m, n, base + mine, ok ? nr : 0, 1};
+            a.out[ti] = TaskOut{fast_score, m, n, base + mine, ok ? nr : 0, 1};
         } else if (live && c == 0) {
             a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
         }
