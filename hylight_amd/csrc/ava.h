@@ -12,7 +12,7 @@ namespace hlmi {
 
 // ---- spec constants (same values as oracle/ava_oracle.c) -------------------------------------
 constexpr int CHAIN_PRED = 64;
-constexpr int BLOCK_MIN = 64;
+constexpr int BLOCK_MIN = 32;
 constexpr int BLOCK_MAX = 256;
 constexpr int BAND_W = 64;
 constexpr int BAND_PAD = 12;

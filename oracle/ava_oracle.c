@@ -27,7 +27,7 @@ typedef struct {
 
 /* ---- fixed constants of the spec -------------------------------------------- */
 #define CHAIN_PRED   64      /* predecessors examined per anchor                            */
-#define BLOCK_MIN    64      /* min distance between alignment fixed points                 */
+#define BLOCK_MIN    32      /* min distance between alignment fixed points                 */
 #define BLOCK_MAX    256     /* max rows / cols of one alignment block                      */
 #define BAND_W       64      /* diagonals per block                                         */
 #define BAND_PAD     12      /* padding around [min(0,delta), max(0,delta)]                 */
