@@ -118,7 +118,7 @@ struct KTimer {
 };
 void ktimer_flush();
 
-// Host wall-clock of a scope (stream drained at both ends) -> stats "host_s.<name>"
+// Host wall-clock of a scope (stream drained at both ends) -> stats "host_s.<name>"; active only with HLMI_HOST_TIMERS set
 struct HostTimer {
     explicit HostTimer(const char *name);
     ~HostTimer();
