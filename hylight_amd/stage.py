@@ -40,23 +40,25 @@ class StageRunner:
             all_mz, all_cnt, total = mz[:max(n, 1)], cnt, n
         else:
             import torch.distributed as dist
-            sizes = torch.tensor([n, hi - lo], dtype=torch.int64, device=dev)
-            gathered = torch.empty(world * 2, dtype=torch.int64, device=dev)      # flat: gloo and RCCL both take it
+            # RCCL moves device buffers directly; a gloo group (tests: two ranks sharing one GPU) stages through the host
+            xdev = "cpu" if dev == "cuda" and dist.get_backend(self.group) == "gloo" else dev
+            sizes = torch.tensor([n, hi - lo], dtype=torch.int64, device=xdev)
+            gathered = torch.empty(world * 2, dtype=torch.int64, device=xdev)     # flat: gloo and RCCL both take it
             dist.all_gather_into_tensor(gathered, sizes, group=self.group)
             g = gathered.view(world, 2).cpu().tolist()
             max_n, max_q = max(max(x[0] for x in g), 1), max(max(x[1] for x in g), 1)
-            # RCCL all-gather of equally sized slabs (ring over xGMI: (N-1)/N of the sketch per link)
-            send = torch.zeros((max_n, 2), dtype=torch.int64, device=dev)
-            send[:n] = mz[:n]
-            recv = torch.empty(world * max_n * 2, dtype=torch.int64, device=dev)
+            # all-gather of equally sized slabs (RCCL: ring over xGMI, (N-1)/N of the sketch per link)
+            send = torch.zeros((max_n, 2), dtype=torch.int64, device=xdev)
+            send[:n] = mz[:n].to(xdev)
+            recv = torch.empty(world * max_n * 2, dtype=torch.int64, device=xdev)
             dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)
             recv = recv.view(world * max_n, 2)
-            csend = torch.zeros(max_q, dtype=torch.int32, device=dev)
-            csend[:hi - lo] = cnt[:hi - lo]
-            crecv = torch.empty(world * max_q, dtype=torch.int32, device=dev)
+            csend = torch.zeros(max_q, dtype=torch.int32, device=xdev)
+            csend[:hi - lo] = cnt[:hi - lo].to(xdev)
+            crecv = torch.empty(world * max_q, dtype=torch.int32, device=xdev)
             dist.all_gather_into_tensor(crecv, csend, group=self.group)
-            all_mz = torch.cat([recv[r * max_n:r * max_n + g[r][0]] for r in range(world)]).contiguous()
-            all_cnt = torch.cat([crecv[r * max_q:r * max_q + g[r][1]] for r in range(world)]).contiguous()
+            all_mz = torch.cat([recv[r * max_n:r * max_n + g[r][0]] for r in range(world)]).contiguous().to(dev)
+            all_cnt = torch.cat([crecv[r * max_q:r * max_q + g[r][1]] for r in range(world)]).contiguous().to(dev)
             total = int(sum(x[0] for x in g))
             if all_mz.shape[0] == 0:
                 all_mz = torch.zeros((1, 2), dtype=torch.int64, device=dev)
