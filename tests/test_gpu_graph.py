@@ -50,9 +50,9 @@ def test_miniasm_messy_graphs(golden, tmp_path, seed, tag):
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/miniasm not built")
-@pytest.mark.parametrize("seed", [11, 12])
-def test_miniasm_against_compiled_reference(tmp_path, seed):
-    reads, paf = S.messy_graph_paf(seed, n_reads=400, genome=120_000, fake=60)
+@pytest.mark.parametrize("seed,n_reads,genome,fake", [(11, 400, 120_000, 60), (12, 400, 120_000, 60), (14, 250, 40_000, 120)])
+def test_miniasm_against_compiled_reference(tmp_path, seed, n_reads, genome, fake):
+    reads, paf = S.messy_graph_paf(seed, n_reads=n_reads, genome=genome, fake=fake)
     p = tmp_path / "m.paf"
     p.write_text("\n".join(paf) + "\n")
     fa = tmp_path / "m.fa"
