@@ -63,6 +63,9 @@ struct AvaInput {
     uint32_t n_chunks = 1;
     const Mz *d_qmz = nullptr;             // complete query sketch
     std::vector<uint64_t> qmz_off;         // host: nQ+1 offsets into d_qmz
+    // all-vs-all on one read set: local target t is query t_query[t], so its minimizers are already in d_qmz and
+    // the target sketch is a gather instead of a second pass over the bases (empty: targets are sketched)
+    std::vector<uint32_t> t_query;
 };
 
 struct AvaRows {            // overlapper output in stream order (chunk, query, target, strand, chain, piece)

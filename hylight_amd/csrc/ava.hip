@@ -87,6 +87,22 @@ void name_ranks(const std::vector<std::string> &a, const std::vector<std::string
     for (size_t i = 0; i < b.size(); ++i) { rb[i] = rank_of(b[i]); name_of_rank[rb[i]] = b[i]; }
 }
 
+// one wave per target: copy its minimizers out of the query sketch, read id rewritten to the local target index
+__global__ __launch_bounds__(WG) void gather_sketch_kernel(const Mz *qmz, const uint64_t *src_off, const uint64_t *dst_off, size_t n_t,
+                                                            Mz *out) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t t = wave; t < n_t; t += n_waves) {
+        const uint64_t s = src_off[t], d = dst_off[t], cnt = dst_off[t + 1] - d;
+        for (uint64_t k = lane; k < cnt; k += 64) {
+            Mz z = qmz[s + k];
+            z.y = (uint64_t)t << 32 | (z.y & 0xffffffffull);
+            out[d + k] = z;
+        }
+    }
+}
+
 void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     out = AvaRows();
     out.chunk_row_start.assign(in.n_chunks + 1, 0);
@@ -101,7 +117,23 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     DevIndex ix;
     {
         HostTimer ht("index");
-        sketch_device(*in.T, o.k, o.w, o.hpc, 0, tsk);
+        if (in.t_query.size() == nT && in.d_qmz) {
+            std::vector<uint64_t> src(nT), dst(nT + 1, 0);
+            for (size_t t = 0; t < nT; ++t) {
+                src[t] = in.qmz_off[in.t_query[t]];
+                dst[t + 1] = dst[t] + (in.qmz_off[in.t_query[t] + 1] - src[t]);
+            }
+            tsk.n = dst[nT];
+            tsk.mz.alloc(tsk.n ? tsk.n : 1);
+            DBuf<uint64_t> d_src, d_dst;
+            d_src.upload(src);
+            d_dst.upload(dst);
+            hipLaunchKernelGGL(gather_sketch_kernel, dim3((unsigned)std::min<size_t>(cdiv(nT, (size_t)(WG / 64)), 256 * 32)), dim3(WG), 0,
+                               stream(), in.d_qmz, d_src.p, d_dst.p, nT, tsk.mz.p);
+            HIP_CHECK(hipGetLastError());
+        } else {
+            sketch_device(*in.T, o.k, o.w, o.hpc, 0, tsk);
+        }
         build_index(tsk, in.d_chunk_of_t, in.d_rank_t, in.n_chunks, o, ix);
         tsk.mz.release();
     }
