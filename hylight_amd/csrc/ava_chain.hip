@@ -198,10 +198,6 @@ __global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, s
     key[g] = 0xffffu - (sz < 0xffffu ? sz : 0xffffu);
     order[g] = (uint32_t)g;
 }
-__global__ void group_head_kernel(const uint64_t *key, size_t n, int pb, uint8_t *head) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) head[i] = (i == 0 || (key[i] >> pb) != (key[i - 1] >> pb)) ? 1 : 0;
-}
 
 // ---------------------------------------------------------------------------------------------
 // chains
@@ -668,11 +664,8 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         if (vb) sort_keys_u64(akey, A, vb + pb, vb + pb + 1 + tb);
         else sort_pairs_u64_u64(akey.p, aval.p, A, pb, pb + 1 + tb);
     }
-    DBuf<uint8_t> head(A);
-    hipLaunchKernelGGL(group_head_kernel, grid1(A), dim3(WG), 0, stream(), akey.p, A, vb + pb, head.p);
     DBuf<uint32_t> gstart(A);
-    const size_t G = select_flagged_indices(head.p, gstart.p, A);
-    head.release();
+    const size_t G = select_run_heads_u64(akey.p, A, vb + pb, gstart.p);
     st.groups += G;
     delete ht_s;
 

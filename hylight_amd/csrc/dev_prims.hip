@@ -111,6 +111,36 @@ void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n) {
 // Three small launches instead of rocprim::select: set bits per 64 flags (ballot), their exclusive scan, scatter by
 // ballot rank.  The flags are read twice (1 B each); on the 5e7-element head arrays of the anchor batches this is
 // several times quicker than the look-back partition, and most calls of a step are such selections.
+// the same two passes with the predicate "key[i] >> shift differs from key[i-1] >> shift" (first element: true)
+// computed from the sorted keys themselves: no flag array in between
+__global__ __launch_bounds__(WG) void head_count_kernel(const uint64_t *key, size_t n, int shift, uint32_t *cnt) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const bool f = i < n && (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift));
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) cnt[i >> 6] = (uint32_t)__popcll(m);
+}
+__global__ __launch_bounds__(WG) void head_scatter_kernel(const uint64_t *key, size_t n, int shift, const uint32_t *off, uint32_t *out_idx,
+                                                           uint32_t *total) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const bool f = i < n && (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift));
+    const unsigned long long m = __ballot(f);
+    if (f) out_idx[off[i >> 6] + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)i;
+    if (i == n - 1) *total = off[i >> 6] + (uint32_t)__popcll(m);
+}
+
+size_t select_run_heads_u64(const uint64_t *key, size_t n, int shift, uint32_t *out_idx) {
+    if (!n) return 0;
+    if (n >= (1ull << 32)) fail(HLMI_EINVAL, "select_run_heads_u64: more than 2^32 elements");
+    const size_t nw = (n + 63) / 64;
+    DBuf<uint32_t> cnt(nw), off(nw), total(1);
+    const dim3 grid(cdiv(n, WG));
+    hipLaunchKernelGGL(head_count_kernel, grid, dim3(WG), 0, stream(), key, n, shift, cnt.p);
+    exclusive_scan_u32(cnt.p, off.p, nw);
+    hipLaunchKernelGGL(head_scatter_kernel, grid, dim3(WG), 0, stream(), key, n, shift, off.p, out_idx, total.p);
+    HIP_CHECK(hipGetLastError());
+    return (size_t)download_one(total.p);
+}
+
 void select_flagged_indices_async(const uint8_t *flags, uint32_t *out_idx, size_t n, uint32_t *d_count) {
     if (!n) { HIP_CHECK(hipMemsetAsync(d_count, 0, 4, stream())); return; }
     if (n >= (1ull << 32)) fail(HLMI_EINVAL, "select_flagged_indices: more than 2^32 elements");
