@@ -153,10 +153,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    api.init(local, 0)
+    # one rank per GPU; HL_BENCH_BACKEND=gloo lets several ranks share a card (the 1-GPU rehearsal of the N > 1 flow:
+    # RCCL wants one device per rank)
+    backend = os.environ.get("HL_BENCH_BACKEND", "nccl")
+    dev_id = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_id)
+    api.init(dev_id, 0)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     wl = WORKLOADS[args.workload]
     work = os.environ.get("HL_BENCH_DIR") or tempfile.mkdtemp(prefix="hl_bench_")
@@ -168,11 +176,12 @@ def main():
         obj = [fa]
         dist.broadcast_object_list(obj, src=0)
         fa = obj[0]
+        work = os.path.dirname(fa)          # every rank writes its part next to rank 0's files: rank 0 merges them
         dist.barrier()
 
     from hylight_amd.stage import StageRunner
     runner = StageRunner(fa, fa, wl["nsplit"], long_mode=True, rank=rank, world=world)
-    out_paf = os.path.join(work, f"out.rank{rank}.paf")
+    out_paf = os.path.join(work, "out.paf")         # N > 1: ranks write out.paf.part<rank>, rank 0 merges into out.paf
 
     def step():
         return runner.run(out_paf, **wl.get("stage", STAGE))
@@ -194,7 +203,7 @@ def main():
     fence()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
