@@ -33,10 +33,14 @@ std::string read_file(const char *path) {
 void write_lines(const char *path, const std::vector<std::string> &lines) {
     FILE *f = fopen(path, "wb");
     if (!f) fail(HLMI_EIO, "cannot write %s: %s", path, strerror(errno));
+    std::string buf;                             // one buffer, few large writes
+    buf.reserve(8u << 20);
     for (auto &l : lines) {
-        fwrite(l.data(), 1, l.size(), f);
-        fputc('\n', f);
+        buf.append(l);
+        buf.push_back('\n');
+        if (buf.size() > (7u << 20)) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
     }
+    if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
     if (fclose(f) != 0) fail(HLMI_EIO, "write error on %s", path);
 }
 
