@@ -10,6 +10,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/hylight_mi.h"
@@ -95,14 +96,7 @@ struct DBuf {
         if (count) HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, stream()));
     }
     void upload(const std::vector<T> &h) { upload(h.data(), h.size()); }
-    std::vector<T> download(size_t count) const {
-        std::vector<T> h(count);
-        if (count) {
-            HIP_CHECK(hipMemcpyAsync(h.data(), p, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
-            HIP_CHECK(hipStreamSynchronize(stream()));
-        }
-        return h;
-    }
+    std::vector<T> download(size_t count) const;
     std::vector<T> download() const { return download(n); }
 };
 
@@ -126,12 +120,33 @@ struct HostTimer {
     double t0;
 };
 
+// 64 KiB of pinned host memory for the small device -> host read-backs (counts, totals): a copy into pageable
+// memory takes a staging detour on every one of the ~200 round trips of a stage pass
+void *pinned_scratch();
+constexpr size_t PINNED_SCRATCH_BYTES = 64 << 10;
+
+template <typename T>
+std::vector<T> DBuf<T>::download(size_t count) const {
+    std::vector<T> h(count);
+    if (!count) return h;
+    if (count * sizeof(T) <= PINNED_SCRATCH_BYTES) {
+        T *slot = (T *)pinned_scratch();
+        HIP_CHECK(hipMemcpyAsync(slot, p, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        std::copy(slot, slot + count, h.begin());
+    } else {
+        HIP_CHECK(hipMemcpyAsync(h.data(), p, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+    return h;
+}
+
 template <typename T>
 T download_one(const T *dev) {
-    T v;
-    HIP_CHECK(hipMemcpyAsync(&v, dev, sizeof(T), hipMemcpyDeviceToHost, stream()));
+    T *slot = (T *)pinned_scratch();
+    HIP_CHECK(hipMemcpyAsync(slot, dev, sizeof(T), hipMemcpyDeviceToHost, stream()));
     sync();
-    return v;
+    return *slot;
 }
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

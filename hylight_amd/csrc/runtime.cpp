@@ -19,6 +19,12 @@ const std::string &last_error() { return g_last_error; }
 
 int host_threads() { return g_threads; }
 
+void *pinned_scratch() {
+    static void *p = nullptr;
+    if (!p) HIP_CHECK(hipHostMalloc(&p, PINNED_SCRATCH_BYTES, hipHostMallocDefault));
+    return p;
+}
+
 void init_device(int device, int threads) {
     std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
