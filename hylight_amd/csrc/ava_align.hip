@@ -28,6 +28,8 @@ constexpr int WAVES = WG / 64;
 constexpr int SEQ_T_MAX = EXT_MAX + BAND_W;     // 320
 constexpr int NR_SHORT = 128;                   // rows of an align_narrow_kernel<NR_SHORT> task; longer near-diagonal
                                                 // blocks (3-4 % of them) run in the <BLOCK_MAX> instance with twice the LDS
+constexpr int WIDE_SHORT = 128;                 // rows of an align_kernel<WIDE_SHORT> task (most extensions are short): half the
+                                                // plane LDS of the <EXT_MAX> instance, twice the resident waves
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 
 struct Task {               // 32 B, self-contained: the kernels reach the bases without touching Piece / offset tables
@@ -170,7 +172,7 @@ __device__ __forceinline__ uint32_t load_window4(const uint8_t *codes, long long
 
 // ---- pass 1: classification + diagonal fast path, one lane per task --------------------------------
 // cls[task] = 0 done here (empty task or fast path), 1 / 3 DP in the 16-diagonal band (<= / > NR_SHORT rows),
-// 2 DP in the 64-diagonal band.
+// 4 / 2 DP in the 64-diagonal band (<= / > WIDE_SHORT rows).
 // Fast path: square block, no ambiguous base, at most kmax substitutions.  With delta = 0 any gapped path has
 // >= 1 insertion and >= 1 deletion and <= m-1 diagonal moves, i.e. scores <= match*(m-1) - 2*(open+ext); the
 // all-diagonal path with k mismatches scores match*(m-k) - mismatch*k, which is strictly larger while
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         if (live) {
             if (m <= 0 || n <= 0) c = 0;
             else if ((tk.kind & 3) == 0) { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
+            if (c == 2 && (m < n - tk.dlo ? m : n - tk.dlo) <= WIDE_SHORT) c = 4;      // rows the 64-diagonal kernel really runs
         }
         int k = 0, mpos[3] = {0, 0, 0};
         bool ambig = false;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
                 if (c == 0) ++st[ST_FAST];
                 else {
                     ++st[ST_DP];
-                    if (c == 2) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
+                    if (c == 2 || c == 4) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
                     else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m; }
                 }
             }
@@ -361,9 +364,9 @@ __global__ void task_rows_key_kernel(const Task *tasks, const uint32_t *list, si
     if (i < n) key[i] = (uint32_t)tasks[list[i]].m >> 2;
 }
 
-__global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, uint8_t *f2, uint8_t *f3) {
+__global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, uint8_t *f2, uint8_t *f3, uint8_t *f4) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) { f1[i] = cls[i] == 1; f2[i] = cls[i] == 2; f3[i] = cls[i] == 3; }
+    if (i < n) { f1[i] = cls[i] == 1; f2[i] = cls[i] == 2; f3[i] = cls[i] == 3; f4[i] = cls[i] == 4; }
 }
 
 // ---- pass 2a: DP of near-diagonal blocks, FOUR tasks per wave (one per row of 16 lanes) --------------------------
@@ -586,9 +589,8 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
 // best row and the 64 lanes are compared once at the end; only there the cells outside 0 <= j <= n are masked.
 constexpr int WT_PAD = 64;                                  // st index of target offset 0 (dlo >= -51)
 constexpr int WT_LEN = WT_PAD + SEQ_T_MAX + 64;
-constexpr int W_CHUNKS = EXT_MAX / 32;
 
-template <bool AMBI, bool EXT>
+template <bool AMBI, bool EXT, int W_CHUNKS>
 __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int dlo, int lane, int end_row,
                                           const uint8_t *sq, const uint8_t *st, uint32_t (*pl)[W_CHUNKS][64], int &Hend,
                                           int &best_h, int &best_i) {
@@ -642,9 +644,11 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
     }
 }
 
+template <int ROWS_MAX>
 __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
+    constexpr int W_CHUNKS = ROWS_MAX / 32;
     __shared__ uint32_t s_pl[WAVES][N_PLANES][W_CHUNKS][64];
-    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][EXT_MAX + 4];
+    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][ROWS_MAX + 4];
     __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][WT_LEN];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
@@ -686,11 +690,11 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         int Hend = 0, best_h = 0, best_i = 0;
         const bool amb = __any(ambig);
         if (kind == 0) {
-            if (amb) wide_rows<true, false>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
-            else wide_rows<false, false>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            if (amb) wide_rows<true, false, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            else wide_rows<false, false, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
         } else {
-            if (amb) wide_rows<true, true>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
-            else wide_rows<false, true>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            if (amb) wide_rows<true, true, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            else wide_rows<false, true, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
         }
         int ei, ej, score;
         if (kind == 0) {
@@ -869,10 +873,10 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     DBuf<TaskOut> tout(NT);
     DBuf<uint32_t> counters(2);
     DBuf<unsigned long long> astats(N_ALIGN_STATS);
-    // runs + one open chunk per allocating lane of every launch: classify and align_kernel (one per wave), the two
+    // runs + one open chunk per allocating lane of every launch: classify and the two align_kernel (one per wave), the two
     // align_narrow_kernel instances (one per 16-lane group)
     constexpr size_t MAX_BLOCKS = 256 * 16;
-    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + MAX_BLOCKS * (2 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL);
+    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + MAX_BLOCKS * (3 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL);
     DBuf<uint32_t> runs;
     for (int attempt = 0;; ++attempt) {
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
@@ -891,22 +895,23 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         }
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         // pass 1: classify every task, finish the diagonal fast path right away
-        DBuf<uint8_t> cls(NT), f1(NT), f2(NT), f3(NT);
+        DBuf<uint8_t> cls(NT), f1(NT), f2(NT), f3(NT), f4(NT);
         {
             KTimer kt("align_classify");
             const unsigned nbc = (unsigned)std::min<size_t>(cdiv(NT, (size_t)WG), MAX_BLOCKS);
             astats.zero();
             hipLaunchKernelGGL(classify_kernel, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
         }
-        hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p, f3.p);
+        hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p, f3.p, f4.p);
         HIP_CHECK(hipGetLastError());
-        DBuf<uint32_t> list1(NT), list2(NT), list3(NT);
-        DBuf<uint32_t> list_n(3);
+        DBuf<uint32_t> list1(NT), list2(NT), list3(NT), list4(NT);
+        DBuf<uint32_t> list_n(4);
         select_flagged_indices_async(f1.p, list1.p, NT, list_n.p);
         select_flagged_indices_async(f2.p, list2.p, NT, list_n.p + 1);
         select_flagged_indices_async(f3.p, list3.p, NT, list_n.p + 2);
-        const std::vector<uint32_t> hn = list_n.download(3);
-        const size_t n1 = hn[0], n2 = hn[1], n3 = hn[2];
+        select_flagged_indices_async(f4.p, list4.p, NT, list_n.p + 3);
+        const std::vector<uint32_t> hn = list_n.download(4);
+        const size_t n1 = hn[0], n2 = hn[1], n3 = hn[2], n4 = hn[3];
         for (int which = 0; which < 2; ++which) {
             uint32_t *lst = which ? list3.p : list1.p;
             const size_t nl = which ? n3 : n1;
@@ -933,9 +938,15 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             KTimer kt("align_wide");
             aa.list = list2.p; aa.n_list = n2;
             const unsigned nb = (unsigned)std::min<size_t>((n2 + WAVES - 1) / WAVES, 256 * 16);
-            hipLaunchKernelGGL(align_kernel, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+            hipLaunchKernelGGL(align_kernel<EXT_MAX>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
-        if (attempt == 0) { stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)n2); }
+        if (n4) {
+            KTimer kt("align_wide_short");
+            aa.list = list4.p; aa.n_list = n4;
+            const unsigned nb = (unsigned)std::min<size_t>((n4 + WAVES - 1) / WAVES, 256 * 16);
+            hipLaunchKernelGGL(align_kernel<WIDE_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+        }
+        if (attempt == 0) { stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)(n2 + n4)); }
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> hc = counters.download(2);
         if (!hc[1]) break;
