@@ -257,7 +257,32 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         // match * min(m,n) - open - ext * |n - m|, which no alignment of an m x n block can beat (fewer columns or
         // more gap cost).  Every optimal alignment is then of this form; the traceback prefers the diagonal on ties,
         // i.e. it leaves the end diagonal as late as it can: the gap sits at the leftmost admissible place.
-        if (live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
+        // Third certificate, the end extensions: if the two sequences agree base for base over L = min(m, n) elements
+        // (no ambiguous base), the cell (L, L) scores match * L and every other cell (i, j) at most match * min(i, j):
+        // it is the unique best cell and the alignment is L matches.  With an end bonus in play (short mode) a cell of
+        // the bonus row could outrank it, so the certificate then needs (L, L) to lie in that row itself.
+        uint32_t ext_flag = 0;
+        if (live && c != 0 && (tk.kind & 3) != 0 && a.kmax >= 0) {
+            const bool rev = (tk.kind & TASK_REV) != 0, left = (tk.kind & 3) == 1;
+            const int L = m < n ? m : n;
+            const int end_row = (int)(tk.narrow >> 1) - 1;
+            bool same = a.end_bonus == 0 || end_row < 0 || L == end_row;
+            for (int x = 0; x < L && same; x += 8) {
+                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, left != rev, rev, x);
+                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, left, false, x);
+                const int rest = L - x;
+                const uint64_t keep = rest >= 8 ? ~0ull : (1ull << (8 * rest)) - 1ull;
+                same = ((q8 ^ t8) & keep) == 0 && ((q8 | t8) & keep & 0x0404040404040404ull) == 0;
+            }
+            if (same) {
+                runs[nr++] = (uint32_t)L << 4 | OP_EQ;
+                fast_score = a.match * L;
+                // the row that reaches the query end earns the bonus in the caller's keep / drop decision
+                ext_flag = L == end_row ? 0x80000000u : 0u;
+                fast = true;
+                c = 0;
+            }
+        } else if (live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
             const bool rev = (tk.kind & TASK_REV) != 0;
             const int mn = m < n ? m : n;
             int lcp = 0, lcs = 0;
@@ -322,7 +347,9 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         }
         if (fast) {
             if (ok) for (uint32_t q = 0; q < nr; ++q) a.runs[base + mine + q] = runs[q];
-            a.out[ti] = TaskOut{fast_score, m, n, base + mine, ok ? nr : 0, 1};
+            const bool ext = (tk.kind & 3) != 0;              // extensions report the cell they stop in
+            const int L = m < n ? m : n;
+            a.out[ti] = TaskOut{fast_score, ext ? L : m, ext ? L : n, base + mine, ok ? nr : 0, 1u | ext_flag};
         } else if (live && c == 0) {
             a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
         }
