@@ -199,6 +199,23 @@ __global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, s
     order[g] = (uint32_t)g;
 }
 
+// HLMI_GROUP_HIST=1: groups and anchors per power-of-two size class (tuning aid, statistics group_hist_*)
+__global__ void group_hist_kernel(const uint32_t *gstart, size_t n_groups, size_t n_anchors, unsigned long long *hist) {
+    __shared__ unsigned long long h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (g < n_groups) {
+        const size_t e = g + 1 < n_groups ? gstart[g + 1] : n_anchors;
+        const uint32_t sz = (uint32_t)(e - gstart[g]);
+        const int c = 31 - __clz((int)sz);
+        atomicAdd(&h[c], 1ull);
+        atomicAdd(&h[32 + c], (unsigned long long)sz);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // chains
 // ---------------------------------------------------------------------------------------------
@@ -235,7 +252,8 @@ struct ChainArgs {
     Piece *pieces;
     FixPt *fps;
     uint32_t cap_pieces, cap_fps;
-    uint32_t *counters;               // [0] pieces, [1] fixed-point slots reserved, [2] overflow flag, [3] fixed points written
+    int stop_after;                   // tuning aid (HLMI_CHAIN_STOP): 1 = leave a group after the DP, 2 = after the member lists
+    uint32_t *counters;               // [0] pieces, [1] unused, [2] overflow flag, [3] fixed points written
 };
 
 // target position, query position, span of anchor idx
@@ -253,30 +271,57 @@ __device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, in
 // in both sequences (or the last member) comes from one ballot instead of a scan over ~16 anchors.
 // One pass: the fixed points go into a range reserved for the worst case (a chain of len members has at most
 // 2 * len of them: one per member plus one more per piece), every piece takes its slot when it closes.
+// Finished pieces wait in a small LDS buffer of the wave and go out PIECE_BUF at a time: one returning atomic on
+// the piece counter per flush instead of one per piece (2 M pieces a step on one address cost a third of the
+// kernel), and the records leave as one coalesced store.
+constexpr int PIECE_BUF = 32;
+__device__ __forceinline__ void flush_pieces(const ChainArgs &a, int lane, const Piece *buf, int &n_buf) {
+    if (!n_buf) return;
+    uint32_t slot = 0;
+    if (lane == 0) slot = atomicAdd(&a.counters[0], (uint32_t)n_buf);
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+    if ((unsigned long long)slot + (unsigned)n_buf > a.cap_pieces) { if (lane == 0) a.counters[2] = 1; }
+    else if (lane < n_buf) a.pieces[slot + lane] = buf[lane];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    n_buf = 0;
+}
 __device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step, int lane, const int *mem, int s, int len,
-                           uint32_t q, uint32_t t, uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t fp_base) {
+                           uint32_t q, uint32_t t, uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t fp_base,
+                           Piece *buf, int &n_buf) {
     bool open = false;
     int cq = 0, ct = 0;
     uint32_t np = 0, nf = 0, piece_fp0 = 0;
     const bool wr = lane == 0;
     auto close_piece = [&]() {
-        if (wr) {
-            const uint32_t slot = atomicAdd(&a.counters[0], 1u);
-            if (slot < a.cap_pieces) a.pieces[slot] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
-            else a.counters[2] = 1;
-        }
+        if (wr) buf[n_buf] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
         ++np;
+        if (++n_buf == PIECE_BUF) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); flush_pieces(a, lane, buf, n_buf); }
     };
     int base = -(1 << 30), te_l = 0, qe_l = 0, sp_l = 0;
+    // Successor links of the window (long chains): nxt = the member that becomes the next fixed point when this one
+    // is the current one (64: none inside the window), okm = lanes whose block to that successor passes block_ok.
+    // Member coordinates grow strictly, so "far enough in both sequences, or the last member" is monotone along
+    // the window: a 6-round binary search per lane, once per window; the serial part of a run of fixed points is
+    // then one readlane per fixed point, and the run is stored by all its lanes at once.
+    int nxt = 64, links_base = -(1 << 30);
+    unsigned long long okm = 0;
+    // windows of 64 members, the next one already in flight while this one is worked on (two dependent reads each)
+    auto load_window = [&](int x0, int &te, int &qe, int &sp) {
+        te = qe = sp = 0;
+        if (x0 + lane < len) {
+            const int idx = mem[x0 + lane];
+            anchor_fields(a, (size_t)((long long)g_first + g_step * idx), te, qe, sp);
+            ++te; ++qe;
+        }
+    };
+    int te_n = 0, qe_n = 0, sp_n = 0;
     for (int x = 0; x < len;) {
-        if (x < base || x >= base + 64) {                      // load the window of members x .. x+63
+        if (x >= base + 64) {                                  // (always the window that follows: x never skips one)
+            if (x == base + 64) { te_l = te_n; qe_l = qe_n; sp_l = sp_n; }
+            else load_window(x, te_l, qe_l, sp_l);             // the first window
             base = x;
-            te_l = qe_l = sp_l = 0;
-            if (x + lane < len) {
-                const int idx = mem[x + lane];
-                anchor_fields(a, (size_t)((long long)g_first + g_step * idx), te_l, qe_l, sp_l);
-                ++te_l; ++qe_l;
-            }
+            if (base + 64 < len) load_window(base + 64, te_n, qe_n, sp_n);
         }
         if (!open) {                                           // a piece starts at the START of member x
             const int l = x - base;
@@ -304,10 +349,39 @@ __device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step,
         const int l = __ffsll((long long)m) - 1;
         const int te = __builtin_amdgcn_readlane(te_l, l), qe = __builtin_amdgcn_readlane(qe_l, l);
         if (block_ok(cq, ct, qe, te)) {
-            if (wr) a.fps[fp_base + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
-            ++nf;
-            cq = qe; ct = te;
-            x = base + l + 1;
+            const int wend = len - base < 64 ? len - base : 64;
+            if (wend - l < 8) {                                // few members left in the window: one at a time
+                if (wr) a.fps[fp_base + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
+                ++nf;
+                cq = qe; ct = te;
+                x = base + l + 1;
+                continue;
+            }
+            if (links_base != base) {
+                links_base = base;
+                int lo = lane + 1, hi = wend;
+                for (int r = 0; r < 6; ++r) {
+                    const int mid = (lo + hi) >> 1;
+                    const int qm = __shfl(qe_l, mid & 63, 64), tm = __shfl(te_l, mid & 63, 64);
+                    const bool far = (qm - qe_l >= BLOCK_MIN && tm - te_l >= BLOCK_MIN) || base + mid == len - 1;
+                    if (lo < hi) { if (far) hi = mid; else lo = mid + 1; }
+                }
+                nxt = lo < wend ? lo : 64;
+                const int qn = __shfl(qe_l, nxt & 63, 64), tn = __shfl(te_l, nxt & 63, 64);
+                okm = __ballot(nxt < 64 && block_ok(qe_l, te_l, qn, tn));
+            }
+            unsigned long long vis = 0;                        // l and the fixed points that follow it in this window
+            int e = l;
+            for (;;) {
+                vis |= 1ull << e;
+                if (!((okm >> e) & 1ull)) break;               // successor outside the window, or a split: generic path
+                e = __builtin_amdgcn_readlane(nxt, e);
+            }
+            if ((vis >> lane) & 1ull)
+                a.fps[fp_base + nf + (uint32_t)__popcll(vis & ((1ull << lane) - 1ull))] = FixPt{(uint32_t)qe_l, (uint32_t)te_l};
+            nf += (uint32_t)__popcll(vis);
+            cq = __builtin_amdgcn_readlane(qe_l, e); ct = __builtin_amdgcn_readlane(te_l, e);
+            x = base + e + 1;
         } else {                                               // split: close here, reopen at this member
             close_piece();
             open = false;
@@ -328,17 +402,26 @@ constexpr int PEN_TAB = 2048;         // gap-cost table entries (bandwidth + 2 m
 constexpr int BC_RING = 256;         // best-child ring: this block, the two before (still read), one spare
 constexpr int CHAIN_GROUPS = 4;
 constexpr int CHAIN_WAVES = 1;      // (4 waves sharing one gap-cost table measured 5 % slower)
-// TAB: 0 = gap cost computed, 1 = byte table (the index is the LDS address), 2 = 16-bit table
+// TAB: 0 = gap cost computed, 1 = byte table (the index is the LDS address), 2 = 16-bit table,
+//      3 = packed DP state (score << 8 | predecessor stamp, see below) with a 32-bit table of -(cost << 8)
+constexpr int PK_NONE = 255;         // stamp of "no predecessor"
+constexpr int PK_NEG = -(1 << 30);   // candidate that loses against every state (scores stay below 2^22)
 template <int TAB>
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
-    typedef typename std::conditional<TAB == 1, uint8_t, uint16_t>::type pen_t;
+    typedef typename std::conditional<TAB == 1, uint8_t, typename std::conditional<TAB == 3, int, uint16_t>::type>::type pen_t;
     __shared__ pen_t pen_tab[TAB ? PEN_TAB : 1];
     __shared__ unsigned long long s_bc[CHAIN_WAVES][BC_RING];      // best child of the anchors of the last few blocks
     unsigned long long *bc = s_bc[threadIdx.x >> 6];
+    __shared__ Piece s_pieces[CHAIN_WAVES][PIECE_BUF];
+    Piece *pbuf = s_pieces[threadIdx.x >> 6];
+    int n_pbuf = 0;
     const int lane = threadIdx.x & 63;
     if (TAB) {
-        for (int d = threadIdx.x; d < a.bw + 2; d += 64 * CHAIN_WAVES)
-            pen_tab[d] = (pen_t)(d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0);
+        for (int d = threadIdx.x; d < a.bw + 2; d += 64 * CHAIN_WAVES) {
+            const int pen = d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0;
+            // packed form: (1 - cost) << 8 (the 1 undoes the -1 the gap terms carry), entry bw + 1 rejects
+            pen_tab[d] = TAB == 3 ? (pen_t)(d <= a.bw ? (1 - pen) * 256 : PK_NEG) : (pen_t)pen;
+        }
         __syncthreads();
     }
     const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
@@ -439,6 +522,63 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             // three ahead (this block's own are still read when the next one is resolved)
             bc[(i - 64) & (BC_RING - 1)] = 0;
         };
+        if constexpr (TAB == 3) {
+            // Packed state: one word per lane = best score << 8 | stamp of the predecessor that gave it (PK_NONE: none,
+            // the score is then the anchor's own span).  Step jl of a block stamps 64 + jl; when a block ends every
+            // lane holds an anchor of the next block and real stamps drop by 64, so that a finished anchor of block B
+            // reads predecessor = 64 (B - 1) + stamp.  "candidate >= best, later predecessor wins ties, the first
+            // predecessor must beat span" is then ONE signed max: stamps grow with the step, PK_NONE beats every
+            // stamp at equal score.  Positions are kept times 4 (the gap difference is the byte offset into the
+            // table) and minus one anchor step (0 <= 4 (gap - 1) < 4 max_gap is one unsigned compare per sequence).
+            // 19 vector instructions per step instead of 30.
+            const int lim4 = 4 * a.max_gap, bw4 = 4 * (a.bw + 1);
+            auto scale = [&](int &t, int &q, int &sp) { t <<= 2; q = q == DEAD_Q ? DEAD_Q : q << 2; sp = (sp << 2) - 4; };
+            scale(M_t, M_q, M_s);
+            scale(N_t, N_q, N_s);
+            int M_pk = ((M_s + 4) << 6) | PK_NONE;
+            auto prepare4 = [&](int jl, int &w) {
+                const int tj = scalar_add(__builtin_amdgcn_readlane(M_t, jl), 4), qj = scalar_add(__builtin_amdgcn_readlane(M_q, jl), 4);
+                const unsigned long long me = 1ull << jl;
+                M_t = select_by_mask(me, N_t, M_t); M_q = select_by_mask(me, N_q, M_q); M_s = select_by_mask(me, N_s, M_s);
+                const int dr = M_t - tj, dq = M_q - qj;          // 4 (gap - 1)
+                const bool ok = ((uint32_t)dr < (uint32_t)lim4) & ((uint32_t)dq < (uint32_t)lim4);
+                uint32_t di = sad_u32((uint32_t)dr, (uint32_t)dq, 0u);
+                di = di < (uint32_t)bw4 ? di : (uint32_t)bw4;
+                const int pen = *(const int *)((const char *)pen_tab + di);
+                int mn = dr < dq ? dr : dq;
+                mn = mn < M_s ? mn : M_s;
+                w = ok ? mn * 64 + pen : PK_NEG;
+            };
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                if (i0) { N_t = P_t; N_q = P_q; N_s = P_s; }
+                load_block(i0 + 128, P_t, P_q, P_s);          // in flight during this block
+                scale(P_t, P_q, P_s);
+                const int N_pk = ((N_s + 4) << 6) | PK_NONE;
+                const int nb = __builtin_amdgcn_readfirstlane(n - i0 < 64 ? n - i0 : 64);
+                int O_pk = PK_NONE;
+                int w_cur;
+                prepare4(0, w_cur);
+                for (int jl = 0; jl < nb; ++jl) {
+                    const int sb = __builtin_amdgcn_readlane(M_pk, jl);
+                    O_pk = writelane_i32(O_pk, sb, jl);
+                    M_pk = select_by_mask(1ull << jl, N_pk, M_pk);
+                    const int cand = ((sb & ~255) + 64 + jl) + w_cur;
+                    M_pk = cand > M_pk ? cand : M_pk;
+                    int w_nxt;
+                    prepare4((jl + 1) & 63, w_nxt);           // (past the block end: hands a lane over twice, w unused)
+                    w_cur = w_nxt;
+                }
+                if (nb == 64) M_pk -= (M_pk & 255) != PK_NONE ? 64 : 0;
+                const int O_f = O_pk >> 8, O_st = O_pk & 255;
+                const int O_p = O_st == PK_NONE ? -1 : i0 - 64 + O_st;
+                if (i0 + lane < n && O_p >= 0)
+                    atomicMax(&bc[O_p & (BC_RING - 1)], (unsigned long long)(uint32_t)O_f << 32 | (0xffffffffu - (uint32_t)(i0 + lane)));
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                if (i0) resolve(i0 - 64, P1_f, P1_p, P2_f);
+                P2_f = P1_f; P1_f = O_f; P1_p = O_p;
+            }
+        } else
         for (int i0 = 0; i0 < n; i0 += 64) {
             if (i0) { N_t = P_t; N_q = P_q; N_s = P_s; }
             load_block(i0 + 128, P_t, P_q, P_s);              // in flight during this block
@@ -472,6 +612,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         }
         resolve((n - 1) & ~63, P1_f, P1_p, P2_f);
         __threadfence_block();
+        if (a.stop_after == 1) continue;
         int moff = 0;                                      // member lists of the group's chains are disjoint
         for (int s0 = 0; s0 < n; s0 += 64) {
             int pk_i = 0;
@@ -503,17 +644,20 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                     best_len += __popcll(mm);
                 }
                 moff += best_len;
-                if (best_len < a.min_cnt) continue;
+                if (best_len < a.min_cnt || a.stop_after == 2) continue;
                 __threadfence_block();
-                uint32_t np = 0, nf = 0, fb = 0;
-                if (lane == 0) fb = atomicAdd(&a.counters[1], 2u * (uint32_t)best_len);
-                fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)fb);
-                if ((unsigned long long)fb + 2ull * (unsigned long long)best_len > a.cap_fps) { if (lane == 0) a.counters[2] = 1; continue; }
-                emit_chain(a, g_first, g_step, lane, mem, s, best_len, qg, tg, strand, np, nf, fb);
+                // fixed points of this chain: at most 2 per member, and the member lists of a batch are disjoint
+                // ranges of the anchor array - twice the list's own offset is a private range, no counter needed
+                uint32_t np = 0, nf = 0;
+                const uint32_t fb = 2u * (uint32_t)(b + (size_t)(moff - best_len));
+                emit_chain(a, g_first, g_step, lane, mem, s, best_len, qg, tg, strand, np, nf, fb, pbuf, n_pbuf);
                 wave_fps += nf;
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    flush_pieces(a, lane, pbuf, n_pbuf);
     if (lane == 0 && wave_fps) atomicAdd(&a.counters[3], wave_fps);
 }
 
@@ -647,7 +791,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     st.anchors += A;
     stat_add("anchor_bytes", (double)A * (vb ? 8.0 : 16.0));
     if (!A) return;
-    if (A >= (1ull << 32)) fail(HLMI_EINVAL, "anchor batch too large");
+    if (A >= (1ull << 31) - 1024) fail(HLMI_EINVAL, "anchor batch too large");      // fixed points sit at 2 x anchor offsets
     HostTimer *ht_s = new HostTimer("seed_sort_phase");
     DBuf<uint64_t> akey(A), aval(vb ? 1 : A);
     {
@@ -678,6 +822,17 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (G) {
         hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p);
         sort_pairs_u32_u32(gkey.p, gorder.p, G, 0, 16);
+        if (getenv("HLMI_GROUP_HIST")) {
+            DBuf<unsigned long long> hist(64);
+            hist.zero();
+            hipLaunchKernelGGL(group_hist_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, hist.p);
+            const std::vector<unsigned long long> h = hist.download(64);
+            for (int c = 0; c < 32; ++c) if (h[c]) {
+                char nm[48];
+                snprintf(nm, sizeof nm, "group_hist_n_%02d", c); stat_add(nm, (double)h[c]);
+                snprintf(nm, sizeof nm, "group_hist_a_%02d", c); stat_add(nm, (double)h[32 + c]);
+            }
+        }
     }
     ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
     DBuf<int> mem(A), root(A);
@@ -687,9 +842,10 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     ca.sbase = sbase.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
+    if (const char *e = getenv("HLMI_CHAIN_STOP")) ca.stop_after = atoi(e);
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
     ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);
-    ca.cap_fps = (uint32_t)std::min<size_t>(2 * A + 1024, 0xfffffff0u);
+    ca.cap_fps = (uint32_t)(2 * A + 1024);
     out.pieces.alloc(ca.cap_pieces);
     out.fps.alloc(ca.cap_fps);
     ca.pieces = out.pieces.p; ca.fps = out.fps.p; ca.counters = counters.p;
@@ -697,14 +853,17 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     {
         KTimer kt("chain");
         const dim3 grid(n_blocks ? n_blocks : 1), block(64 * CHAIN_WAVES);
-        if (o.bandwidth + 2 > PEN_TAB) hipLaunchKernelGGL(chain_kernel<0>, grid, block, 0, stream(), ca);
+        // packed DP state: scores (< longest query + one span) must stay below 2^22, positions * 4 inside 31 bits
+        const bool packed = o.bandwidth + 2 <= PEN_TAB && max_qlen + 256 < (1ull << 22) && pb <= 24 && o.max_gap < (1 << 24) &&
+                            !getenv("HLMI_CHAIN_UNPACKED");
+        if (packed) hipLaunchKernelGGL(chain_kernel<3>, grid, block, 0, stream(), ca);
+        else if (o.bandwidth + 2 > PEN_TAB) hipLaunchKernelGGL(chain_kernel<0>, grid, block, 0, stream(), ca);
         else if ((o.bandwidth * o.k) / 100 + 16 <= 255) hipLaunchKernelGGL(chain_kernel<1>, grid, block, 0, stream(), ca);
         else hipLaunchKernelGGL(chain_kernel<2>, grid, block, 0, stream(), ca);
     }
     HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> hc = counters.download(4);
-    if (hc[2]) fail(HLMI_ENOMEM, "chain output buffers overflowed (pieces %u/%u, fixed points %u/%u)", hc[0],
-                    ca.cap_pieces, hc[1], ca.cap_fps);
+    if (hc[2]) fail(HLMI_ENOMEM, "chain output buffer overflowed (pieces %u/%u)", hc[0], ca.cap_pieces);
     out.n_pieces = hc[0];
     out.n_fp = hc[3];
 }

@@ -91,6 +91,24 @@ __device__ __forceinline__ int select_by_mask(unsigned long long mask, int yes, 
     return r;
 }
 
+// |a - b| + c on unsigned operands in one instruction
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+#endif
+    return r;
+}
+
+// a + b on the scalar unit, opaque to the optimiser (keeps it from re-associating the sum into per-lane adds)
+__device__ __forceinline__ int scalar_add(int a, int b) {
+    int r = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("s_add_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+#endif
+    return r;
+}
+
 // zero-filling one-lane shifts: a single v_mov_b32_dpp ... bound_ctrl:1 (no `old` register to prepare)
 __device__ __forceinline__ int row_shl1_z(int x) { return __builtin_amdgcn_mov_dpp(x, 0x101, 0xf, 0xf, true); }
 __device__ __forceinline__ int wave_shl1_z(int x) { return __builtin_amdgcn_mov_dpp(x, 0x130, 0xf, 0xf, true); }

@@ -74,6 +74,21 @@ def test_ava_key_value_anchor_form(tmp_path, monkeypatch):
     assert open(tmp_path / "pairs.paf").read() == open(tmp_path / "packed.paf").read()
 
 
+def test_ava_chain_state_forms(tmp_path, monkeypatch):
+    """The chaining DP keeps score and predecessor in one packed word per lane when scores stay below 2^22 (every
+    real read set); HLMI_CHAIN_UNPACKED forces the two-register form longer sequences take.  Same chains, and both
+    equal to the oracle."""
+    reads = _sim(33, 80, n_strains=3, genome_len=20000, err_sub=0.02, err_ins=0.01, err_del=0.01)
+    fa = _write(tmp_path, "r.fa", reads)
+    api.ava(fa, fa, tmp_path / "packed.paf")
+    monkeypatch.setenv("HLMI_CHAIN_UNPACKED", "1")
+    api.ava(fa, fa, tmp_path / "unpacked.paf")
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    want = open(tmp_path / "o.paf").read()
+    assert open(tmp_path / "packed.paf").read() == want
+    assert open(tmp_path / "unpacked.paf").read() == want
+
+
 def test_ava_target_subset_and_ambiguous_bases(tmp_path):
     reads = _sim(41, 36)
     reads[2].seq[1000:1004] = ord("N")
