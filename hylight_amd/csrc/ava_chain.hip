@@ -401,7 +401,7 @@ constexpr int PEN_TAB = 2048;         // gap-cost table entries (bandwidth + 2 m
 // groups left the SIMDs at 3 of 8 resident waves on average).
 constexpr int BC_RING = 256;         // best-child ring: this block, the two before (still read), one spare
 constexpr int CHAIN_GROUPS = 4;
-constexpr int CHAIN_WAVES = 1;      // (4 waves sharing one gap-cost table measured 5 % slower)
+constexpr int CHAIN_WAVES = 4;      // waves per workgroup sharing one gap-cost table: LDS per wave sets the occupancy (1: 3.4 waves/SIMD, 74 ms; 2: 64 ms; 4: 58 ms; 8: 60 ms on C2)
 // TAB: 0 = gap cost computed, 1 = byte table (the index is the LDS address), 2 = 16-bit table,
 //      3 = packed DP state (score << 8 | predecessor stamp, see below) with a 32-bit table of -(cost << 8)
 constexpr int PK_NONE = 255;         // stamp of "no predecessor"
