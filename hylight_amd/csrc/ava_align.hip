@@ -114,6 +114,7 @@ struct AlignArgs {
     uint32_t *runs;
     uint32_t cap_runs;
     uint32_t *counters;     // [0] runs cursor, [1] overflow
+    uint32_t run_buf_cap;   // runs the first traceback walk may keep in LDS (test hook HLMI_RUN_BUF_CAP lowers it)
 };
 
 // exclusive prefix sum over the wave; total = sum of all lanes
@@ -437,15 +438,22 @@ struct NarrowWalk {
     bool keep_order;                        // left extensions: the reversed sequences make end -> start the forward order
     __device__ __forceinline__ uint32_t word(int plane, int c, int lane) const { return pl[(plane * chunks + c) * 64 + lane]; }
 };
-// Traceback of one task by one lane.  Emits the runs in reverse (end -> start); with `out` they are written to
-// out[total-1 .. 0].  Returns the number of runs.  Every iteration consumes a row or a column or switches
-// from state 0 to a gap state, so 2 * (m + n) + 2 bounds the trip count; the cap only guards a corrupted plane.
-__device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total) {
+// Traceback of one task by one lane.  Emits the runs in reverse (end -> start) and returns their number.  The
+// first `cap` of them are kept in `buf` (LDS, emission order): a task with no more than that is walked once and its
+// runs copied out by the whole group; with `out` (second walk of a longer task) they are written to
+// out[total-1 .. 0].  Every iteration consumes a row or a column or switches from state 0 to a gap state, so
+// 2 * (m + n) + 2 bounds the trip count; the cap only guards a corrupted plane.
+__device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total, uint32_t *buf = nullptr, uint32_t cap = 0) {
     int i = w.m, j = w.n, state = 0;
     uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
+    auto put = [&]() {
+        if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op;
+        else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
+        ++n_runs;
+    };
     auto emit = [&](uint32_t op, uint32_t len) {
         if (op == cur_op) { cur_len += len; return; }
-        if (cur_len) { if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
+        if (cur_len) put();
         cur_op = op; cur_len = len;
     };
     for (int it = 0; (i > 0 || j > 0) && it < 4 * (EXT_MAX + SEQ_T_MAX); ++it) {
@@ -481,9 +489,10 @@ __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t tot
             --i;
         }
     }
-    if (cur_len) { if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op; ++n_runs; }
+    if (cur_len) put();
     return n_runs;
 }
+constexpr int RUN_BUF_NARROW = 48, RUN_BUF_WIDE = 128;   // runs kept in LDS by the first walk (per task)
 
 template <bool AMBI, int NR_CHUNKS>
 __device__ __forceinline__ void narrow_rows(const AlignArgs &a, int rows, int m, int dlo, int l, const uint8_t *sq,
@@ -546,6 +555,7 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
     __shared__ uint32_t s_pl[WAVES][N_PLANES][NR_CHUNKS][64];
     __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES * 4][NR_MAX + 4];
     __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES * 4][NR_MAX + NT_EXTRA];
+    __shared__ uint32_t s_runs[WAVES * 4][RUN_BUF_NARROW];
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15, wv = threadIdx.x >> 6;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -596,15 +606,25 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         const int score = __shfl(Hend, g * 16 + ((n - m - dlo) & (NARROW_W - 1)), 64) - DP_BIAS;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        uint32_t *rbuf = s_runs[wv * 4 + g];
+        const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_NARROW ? a.run_buf_cap : (uint32_t)RUN_BUF_NARROW;
+        uint32_t cp_n = 0, cp_off = 0;                          // runs the group copies out of LDS
         if (live && l == 0) {
             const NarrowWalk w{&pl[0][0][0], NR_CHUNKS, g * 16, m, n, dlo, NARROW_W - 1, false};
-            const uint32_t n_runs = narrow_walk(w, nullptr, 0);
+            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
-            if (ok && n_runs) narrow_walk(w, a.runs + off, n_runs);
+            if (ok && n_runs) {
+                if (n_runs <= rcap) { cp_n = n_runs; cp_off = off; }
+                else narrow_walk(w, a.runs + off, n_runs);
+            }
             a.out[ti] = TaskOut{score, m, n, off, ok ? n_runs : 0, 2u | (uint32_t)m << 2};
         }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        cp_n = (uint32_t)__shfl((int)cp_n, g * 16, 64); cp_off = (uint32_t)__shfl((int)cp_off, g * 16, 64);
+        for (uint32_t k = (uint32_t)l; k < cp_n; k += 16) a.runs[cp_off + k] = rbuf[cp_n - 1 - k];   // forward order
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -677,6 +697,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     __shared__ uint32_t s_pl[WAVES][N_PLANES][W_CHUNKS][64];
     __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][ROWS_MAX + 4];
     __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][WT_LEN];
+    __shared__ uint32_t s_runs[WAVES][RUN_BUF_WIDE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -745,16 +766,27 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        uint32_t *rbuf = s_runs[wv];
+        const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_WIDE ? a.run_buf_cap : (uint32_t)RUN_BUF_WIDE;
+        uint32_t cp_n = 0, cp_off = 0;
         if (lane == 0) {
             const NarrowWalk w{&pl[0][0][0], W_CHUNKS, 0, ei, ej, dlo, BAND_W - 1, kind == 1};
-            const uint32_t n_runs = narrow_walk(w, nullptr, 0);
+            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
-            if (ok && n_runs) narrow_walk(w, a.runs + off, n_runs);
+            if (ok && n_runs) {
+                if (n_runs <= rcap) { cp_n = n_runs; cp_off = off; }
+                else narrow_walk(w, a.runs + off, n_runs);
+            }
             a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0,
                                 2u | ((uint32_t)m & 0xfffffu) << 2 | (kind != 0 && ei == end_row ? 0x80000000u : 0u)};
         }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        cp_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cp_n); cp_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)cp_off);
+        for (uint32_t k = (uint32_t)lane; k < cp_n; k += 64)     // left extensions keep the emission order
+            a.runs[cp_off + k] = rbuf[kind == 1 ? k : cp_n - 1 - k];
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -921,6 +953,8 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             if (o.match <= 0 || o.gap_open < 0 || o.gap_ext <= 0) aa.kmax = -1;   // proof needs sane scores
         }
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
+        aa.run_buf_cap = 0xffffffffu;
+        if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
         // pass 1: classify every task, finish the diagonal fast path right away
         DBuf<uint8_t> cls(NT), f1(NT), f2(NT), f3(NT), f4(NT);
         {

@@ -89,6 +89,21 @@ def test_ava_chain_state_forms(tmp_path, monkeypatch):
     assert open(tmp_path / "unpacked.paf").read() == want
 
 
+def test_ava_traceback_run_buffer_overflow(tmp_path, monkeypatch):
+    """The traceback keeps a task's runs in LDS and walks once; a task with more runs than the buffer holds is
+    walked a second time straight into the pool.  HLMI_RUN_BUF_CAP=3 sends nearly every DP task down that path."""
+    reads = _sim(34, 50, n_strains=2, genome_len=15000, err_sub=0.03, err_ins=0.02, err_del=0.02)
+    fa = _write(tmp_path, "r.fa", reads)
+    api.ava(fa, fa, tmp_path / "a.paf")
+    monkeypatch.setenv("HLMI_RUN_BUF_CAP", "3")
+    api.ava(fa, fa, tmp_path / "b.paf")
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    want = open(tmp_path / "o.paf").read()
+    assert len(want.splitlines()) > 50
+    assert open(tmp_path / "a.paf").read() == want
+    assert open(tmp_path / "b.paf").read() == want
+
+
 def test_ava_target_subset_and_ambiguous_bases(tmp_path):
     reads = _sim(41, 36)
     reads[2].seq[1000:1004] = ord("N")
