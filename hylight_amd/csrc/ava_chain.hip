@@ -146,23 +146,33 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
         }
     }
     uint32_t my_cnt = 0;
-    for (int b = 0; b < 64; ++b) {
+    // the runs are served one after the other; the first 64 entries of the next run are already in flight while
+    // this one is worked on (two dependent reads per run would otherwise sit on the critical path 64 times)
+    unsigned long long todo = __ballot(hi != lo);
+    uint64_t y_p = 0;
+    uint32_t rt_p = 0;
+    auto prefetch = [&](int bn) {
+        const unsigned long long e = __shfl((unsigned long long)lo, bn, 64) + lane;
+        if (e < __shfl((unsigned long long)hi, bn, 64)) { if (FILL) y_p = a.iy[e]; rt_p = a.irk[e]; }
+    };
+    if (todo) prefetch(__ffsll((long long)todo) - 1);
+    while (todo) {
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
         const unsigned long long lo_b = __shfl((unsigned long long)lo, b, 64), hi_b = __shfl((unsigned long long)hi, b, 64);
-        if (hi_b == lo_b) continue;                     // wave-uniform
         const uint32_t rq_b = __shfl(rq, b, 64);
         const unsigned long long zx = __shfl((unsigned long long)z.x, b, 64), zy = __shfl((unsigned long long)z.y, b, 64);
         unsigned long long w = FILL ? __shfl((unsigned long long)w0, b, 64) : 0;
         const uint32_t ql_b = FILL ? __shfl(ql, b, 64) : 0;
         uint32_t c = 0;
+        uint64_t y = y_p;
+        uint32_t rt = rt_p;
+        if (todo) prefetch(__ffsll((long long)todo) - 1);
         for (unsigned long long e0 = lo_b; e0 < hi_b; e0 += 64) {
             const unsigned long long e = e0 + lane;
-            bool ok = false;
-            uint64_t y = 0;
-            if (e < hi_b) {
-                if (FILL) y = a.iy[e];
-                const uint32_t rt = a.irk[e];                        // bit 31: too frequent inside its chunk
-                ok = a.pair_once ? rq_b < rt && !(rt >> 31) : rq_b != (rt & 0x7fffffffu) && !(rt >> 31);   // pair once / never self
-            }
+            if (e0 != lo_b && e < hi_b) { if (FILL) y = a.iy[e]; rt = a.irk[e]; }
+            // bit 31 of rt: too frequent inside its chunk
+            const bool ok = e < hi_b && (a.pair_once ? rq_b < rt && !(rt >> 31) : rq_b != (rt & 0x7fffffffu) && !(rt >> 31));   // pair once / never self
             const unsigned long long mask = __ballot(ok);
             if (FILL && ok) {
                 const uint32_t qspan = (uint32_t)(zx & 0xff), qpos = (uint32_t)zy >> 1, qz = (uint32_t)zy & 1;

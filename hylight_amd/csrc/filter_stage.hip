@@ -315,16 +315,20 @@ __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
     return v;
 }
 
+// maxv[0] / maxv[1]: largest read id / read length among the selected rows (they size the event sort key)
 __global__ __launch_bounds__(WG) void snp_count_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
                                                         const uint8_t *sel, size_t n, int long_mode, uint32_t *n_ev,
-                                                        uint32_t *n_iv) {
+                                                        uint32_t *n_iv, uint32_t *maxv) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t max_id = 0, max_len = 0;
     for (size_t i = wave; i < n; i += n_waves) {
         uint32_t ne = 0, ni = 0;
         if (sel[i]) {
             const PafRec &r = recs[grows[i]];
+            max_id = max(max_id, max(r.qid, r.tid));
+            max_len = max(max_len, max(r.qlen, r.tlen));
             const uint32_t *o = ops + r.cig_off;
             for (uint32_t k0 = 0; k0 < r.cig_n; k0 += 64)
                 ne += (uint32_t)__popcll(__ballot(k0 + lane < r.cig_n && (o[k0 + lane] & 15u) == OP_X));
@@ -333,13 +337,17 @@ __global__ __launch_bounds__(WG) void snp_count_kernel(const PafRec *recs, const
         }
         if (lane == 0) { n_ev[i] = ne; n_iv[i] = ni; }
     }
+    if (lane == 0 && (max_id | max_len)) { atomicMax(&maxv[0], max_id); atomicMax(&maxv[1], max_len); }
 }
 
 __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
                                                        const uint8_t *sel, size_t n, int long_mode, const uint32_t *ev_off,
                                                        const uint32_t *iv_off, const uint32_t *pseg_start, size_t n_pseg,
-                                                       uint32_t *ev_chunk, uint64_t *ev_key, uint32_t *ev_pair,
-                                                       uint32_t *iv_chunk, uint64_t *iv_skey, uint64_t *iv_ekey) {
+                                                       int hb, int lb, uint64_t *ev_ck, uint32_t *ev_pair,
+                                                       uint64_t *iv_sck, uint64_t *iv_eck) {
+    // sort word of (chunk, read, position): chunk | read (hb bits) | position (lb bits) - numeric order = the
+    // lexicographic order of the triple
+    auto ck = [&](uint32_t chunk, uint32_t id, uint32_t pos) { return ((uint64_t)chunk << hb | id) << lb | pos; };
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -348,12 +356,8 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
         const PafRec r = recs[grows[i]];
         if (lane == 0) {
             uint32_t w = iv_off[i];
-            if (r.ts < r.te) {
-                iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.tid << 32 | r.ts; iv_ekey[w] = (uint64_t)r.tid << 32 | r.te; ++w;
-            }
-            if (long_mode && r.qs < r.qe) {
-                iv_chunk[w] = r.chunk; iv_skey[w] = (uint64_t)r.qid << 32 | r.qs; iv_ekey[w] = (uint64_t)r.qid << 32 | r.qe;
-            }
+            if (r.ts < r.te) { iv_sck[w] = ck(r.chunk, r.tid, r.ts); iv_eck[w] = ck(r.chunk, r.tid, r.te); ++w; }
+            if (long_mode && r.qs < r.qe) { iv_sck[w] = ck(r.chunk, r.qid, r.qs); iv_eck[w] = ck(r.chunk, r.qid, r.qe); }
         }
         // the pair group of this row = the pair every event of the row counts for (read and partner are the row's
         // two names): last group start <= i
@@ -381,9 +385,9 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
                 uint32_t at = e + (uint32_t)__popcll(xm & ((1ull << lane) - 1ull)) * (long_mode ? 2u : 1u);
                 if (long_mode) {
                     const uint32_t qp = rev ? r.qlen - q1 + 1 : q1;    // slr2:357
-                    ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.qid << 32 | qp; ev_pair[at] = pg; ++at;
+                    ev_ck[at] = ck(r.chunk, r.qid, qp); ev_pair[at] = pg; ++at;
                 }
-                ev_chunk[at] = r.chunk; ev_key[at] = (uint64_t)r.tid << 32 | q2; ev_pair[at] = pg;
+                ev_ck[at] = ck(r.chunk, r.tid, q2); ev_pair[at] = pg;
             }
             p1 += (uint32_t)__shfl((int)s1, 63, 64);
             p2 += (uint32_t)__shfl((int)s2, 63, 64);
@@ -399,39 +403,42 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
 // further spanning reads) and writes the verdict over the key's event range; (2) one thread per EVENT of a
 // supported key bumps the counter of its row's pair group (recorded with the event).  (A key on a deeply covered read has
 // hundreds of events; a single thread walking them all was the long pole of the filter stage.)
-__global__ void snp_support_kernel(const uint32_t *ev_chunk, const uint64_t *ev_key, const uint32_t *kseg_start,
-                                   size_t n_kseg, size_t n_ev, const uint32_t *ivs_chunk, const uint64_t *ivs_key,
-                                   const uint32_t *ive_chunk, const uint64_t *ive_key, size_t n_iv, int mc,
+__device__ __forceinline__ size_t lower_bound_u64(const uint64_t *v, size_t n, uint64_t k) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (v[mid] < k) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ void snp_support_kernel(const uint64_t *ev_ck, const uint32_t *kseg_start, size_t n_kseg, size_t n_ev,
+                                   const uint64_t *ivs_ck, const uint64_t *ive_ck, size_t n_iv, int lb, int mc,
                                    uint8_t *ev_supported) {
     size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (s >= n_kseg) return;
     size_t b = kseg_start[s], e = (s + 1 < n_kseg) ? kseg_start[s + 1] : n_ev;
     int64_t v = (int64_t)(e - b);
     if (v < mc) return;
-    const uint32_t c = ev_chunk[b];
-    const uint64_t key = ev_key[b];
-    const uint64_t read0 = key & 0xffffffff00000000ull;
+    const uint64_t key = ev_ck[b];
+    const uint64_t read0 = key >> lb << lb;                       // (chunk, read, position 0)
     // #intervals of this read with start < pos  minus  #with end <= pos   (start < end holds for all).
     // Both arrays hold the same intervals grouped by (chunk, read), so the read's block [a, b) is the same index
     // range in both: one full search for a, a short one for b (a read rarely has more than a few thousand
     // intervals in a chunk), then two searches inside the block.
-    const size_t a = lower_bound_ck(ivs_chunk, ivs_key, n_iv, c, read0);
-    const uint64_t next_read = read0 + (1ull << 32);
+    const size_t a = lower_bound_u64(ivs_ck, n_iv, read0);
+    const uint64_t next_read = read0 + (1ull << lb);
     size_t span = n_iv - a < 4096 ? n_iv - a : 4096;
-    if (span == 4096 && (ivs_chunk[a + span - 1] < c || (ivs_chunk[a + span - 1] == c && ivs_key[a + span - 1] < next_read)))
-        span = n_iv - a;                                         // a very deep read: search the rest
-    const size_t b_ = a + lower_bound_ck(ivs_chunk + a, ivs_key + a, span, c, next_read);
-    const int64_t n_start_lt = (int64_t)lower_bound_ck(ivs_chunk + a, ivs_key + a, b_ - a, c, key);
-    const int64_t n_end_le = (int64_t)lower_bound_ck(ive_chunk + a, ive_key + a, b_ - a, c, key + 1);
+    if (span == 4096 && ivs_ck[a + span - 1] < next_read) span = n_iv - a;      // a very deep read: search the rest
+    const size_t b_ = a + lower_bound_u64(ivs_ck + a, span, next_read);
+    const int64_t n_start_lt = (int64_t)lower_bound_u64(ivs_ck + a, b_ - a, key);
+    const int64_t n_end_le = (int64_t)lower_bound_u64(ive_ck + a, b_ - a, key + 1);
     int64_t con = n_start_lt - n_end_le;
     if (con - v < mc) return;
     for (size_t i = b; i < e; ++i) ev_supported[i] = 1;      // contiguous bytes; v is at most the read depth
 }
 
-__global__ void snp_pair_count_kernel(const uint32_t *ev_pair, const uint32_t *ev_perm, const uint8_t *ev_supported,
-                                      size_t n_ev, uint32_t *pair_mut) {
+// ev_pair travelled through the sort as the value of its event: a streaming read, one atomic per supported event
+__global__ void snp_pair_count_kernel(const uint32_t *ev_pair_sorted, const uint8_t *ev_supported, size_t n_ev,
+                                      uint32_t *pair_mut) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n_ev && ev_supported[i]) atomicAdd(&pair_mut[ev_pair[ev_perm[i]]], 1u);
+    if (i < n_ev && ev_supported[i]) atomicAdd(&pair_mut[ev_pair_sorted[i]], 1u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -563,7 +570,9 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
 
     // ---- a4 ------------------------------------------------------------------------------
     DBuf<uint8_t> keep1(n);
+    { KTimer kt("filter_v4");
     window_filter_device(d_recs, n, chunk_row_start, 4, cfg.v4_min_len, cfg.v4_min_iden, cfg.v4_min_o, keep1.p);
+    }
     DBuf<uint32_t> rows(n);
     const size_t m = select_flagged_indices(keep1.p, rows.p, n);
     out.n_after_v4 = m;
@@ -589,8 +598,10 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     // ---- a5: events + intervals -------------------------------------------------------------------
     DBuf<uint32_t> n_ev(m), n_iv(m), ev_off(m), iv_off(m);
     const dim3 rows_grid((unsigned)std::min<size_t>(cdiv(m ? m : 1, WG / 64), 65536));    // one wave per row, grid-stride
+    DBuf<uint32_t> maxv(2);
+    maxv.zero();
     hipLaunchKernelGGL(snp_count_kernel, rows_grid, dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm, n_ev.p,
-                       n_iv.p);
+                       n_iv.p, maxv.p);
     exclusive_scan_u32(n_ev.p, ev_off.p, m);
     exclusive_scan_u32(n_iv.p, iv_off.p, m);
     const size_t E = (size_t)download_one(ev_off.p + (m - 1)) + download_one(n_ev.p + (m - 1));
@@ -599,26 +610,33 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     DBuf<uint32_t> pair_mut(n_pseg);
     pair_mut.zero();
     if (E) {
-        DBuf<uint32_t> ev_chunk(E), ev_pair(E), iv_chunk(I ? I : 1);
-        DBuf<uint64_t> ev_key(E), iv_skey(I ? I : 1), iv_ekey(I ? I : 1);
+        // one sort word per event / interval end: chunk | read | position, as wide as this call's ids and lengths need
+        const std::vector<uint32_t> mx = maxv.download(2);
+        const int cb = bits_for(n_chunks > 1 ? n_chunks - 1 : 1), hb = bits_for(mx[0] ? mx[0] : 1), lb = bits_for((uint64_t)mx[1] + 1);
+        if (cb + hb + lb > 64) fail(HLMI_EINVAL, "SNP pile-up key needs %d bits (chunks %d, reads %d, positions %d)", cb + hb + lb, cb, hb, lb);
+        DBuf<uint32_t> ev_pair(E);
+        DBuf<uint64_t> ev_ck(E), iv_sck(I ? I : 1), iv_eck(I ? I : 1);
+    { KTimer kt("filter_event_fill");
         hipLaunchKernelGGL(snp_fill_kernel, rows_grid, dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm,
-                           ev_off.p, iv_off.p, pseg_start.p, n_pseg, ev_chunk.p, ev_key.p, ev_pair.p, iv_chunk.p, iv_skey.p,
-                           iv_ekey.p);
-        SortedCK sev, sis, sie;
-        sort_chunk_key(ev_chunk.p, ev_key.p, E, n_chunks, sev);
-        sort_chunk_key(iv_chunk.p, iv_skey.p, I, n_chunks, sis);
-        sort_chunk_key(iv_chunk.p, iv_ekey.p, I, n_chunks, sie);
-        DBuf<uint8_t> khead(E);
-        hipLaunchKernelGGL(head_flags_kernel, grid1(E), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p, khead.p, E);
+                           ev_off.p, iv_off.p, pseg_start.p, n_pseg, hb, lb, ev_ck.p, ev_pair.p, iv_sck.p, iv_eck.p);
+    }
+    { KTimer kt("filter_event_sort");
+        sort_pairs_u64_u32(ev_ck, ev_pair, E, 0, cb + hb + lb);      // the pair group rides along: no gather afterwards
+        sort_keys_u64(iv_sck, I, 0, cb + hb + lb);
+        sort_keys_u64(iv_eck, I, 0, cb + hb + lb);
+    }
         DBuf<uint32_t> kseg_start(E);
-        const size_t n_kseg = select_flagged_indices(khead.p, kseg_start.p, E);
+        const size_t n_kseg = select_run_heads_u64(ev_ck.p, E, 0, kseg_start.p);
         // ---- a6 ---------------------------------------------------------------------------------
         DBuf<uint8_t> ev_sup(E);
         ev_sup.zero();
-        hipLaunchKernelGGL(snp_support_kernel, grid1(n_kseg), dim3(WG), 0, stream(), sev.chunk.p, sev.key.p, kseg_start.p,
-                           n_kseg, E, sis.chunk.p, sis.key.p, sie.chunk.p, sie.key.p, I, cfg.mc, ev_sup.p);
-        hipLaunchKernelGGL(snp_pair_count_kernel, grid1(E), dim3(WG), 0, stream(), ev_pair.p, sev.perm.p, ev_sup.p, E,
-                           pair_mut.p);
+    { KTimer kt("filter_support");
+        hipLaunchKernelGGL(snp_support_kernel, grid1(n_kseg), dim3(WG), 0, stream(), ev_ck.p, kseg_start.p, n_kseg, E,
+                           iv_sck.p, iv_eck.p, I, lb, cfg.mc, ev_sup.p);
+    }
+    { KTimer kt("filter_pair_count");
+        hipLaunchKernelGGL(snp_pair_count_kernel, grid1(E), dim3(WG), 0, stream(), ev_pair.p, ev_sup.p, E, pair_mut.p);
+    }
         HIP_CHECK(hipGetLastError());
         sync();
     }
