@@ -16,6 +16,8 @@
 // All of it is integer / byte work bounded by HBM traffic; no MFMA.
 #include "filter_stage.h"
 
+#include <memory>
+
 #include <algorithm>
 
 #include "dev_prims.h"
@@ -337,7 +339,12 @@ __global__ __launch_bounds__(WG) void snp_count_kernel(const PafRec *recs, const
         }
         if (lane == 0) { n_ev[i] = ne; n_iv[i] = ni; }
     }
-    if (lane == 0 && (max_id | max_len)) { atomicMax(&maxv[0], max_id); atomicMax(&maxv[1], max_len); }
+    // (a quarter of a million waves on one counter word would serialise: only a wave that raises the maximum it
+    // can see sends an atomic)
+    if (lane == 0) {
+        if (max_id > __hip_atomic_load(&maxv[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxv[0], max_id);
+        if (max_len > __hip_atomic_load(&maxv[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxv[1], max_len);
+    }
 }
 
 __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
@@ -568,6 +575,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     const uint32_t n_chunks = std::max<uint32_t>((uint32_t)(chunk_row_start.size() - 1), cfg.chunk_id_bound);
     const int lm = cfg.long_mode ? 1 : 0;
 
+    std::unique_ptr<HostTimer> ht(new HostTimer("filter_v4_select"));
     // ---- a4 ------------------------------------------------------------------------------
     DBuf<uint8_t> keep1(n);
     { KTimer kt("filter_v4");
@@ -578,6 +586,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     out.n_after_v4 = m;
     if (!m) return;
 
+    ht.reset(); ht.reset(new HostTimer("filter_pair_groups"));
     // ---- group by (chunk, unordered pair) ------------------------------------------------------
     DBuf<uint32_t> rchunk(m);
     DBuf<uint64_t> rkey(m);
@@ -595,6 +604,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     hipLaunchKernelGGL(pair_order_select_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, grows.p, pseg_start.p,
                        n_pseg, m, lm, sel.p);
 
+    ht.reset(); ht.reset(new HostTimer("filter_events"));
     // ---- a5: events + intervals -------------------------------------------------------------------
     DBuf<uint32_t> n_ev(m), n_iv(m), ev_off(m), iv_off(m);
     const dim3 rows_grid((unsigned)std::min<size_t>(cdiv(m ? m : 1, WG / 64), 65536));    // one wave per row, grid-stride
@@ -627,6 +637,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     }
         DBuf<uint32_t> kseg_start(E);
         const size_t n_kseg = select_run_heads_u64(ev_ck.p, E, 0, kseg_start.p);
+
         // ---- a6 ---------------------------------------------------------------------------------
         DBuf<uint8_t> ev_sup(E);
         ev_sup.zero();
@@ -641,6 +652,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
         sync();
     }
 
+    ht.reset(); ht.reset(new HostTimer("filter_pass2_order"));
     // ---- a7 ---------------------------------------------------------------------------------------
     DBuf<uint8_t> keep2(m);
     DBuf<uint32_t> xdig(m);
