@@ -113,18 +113,21 @@ void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n) {
 // several times quicker than the look-back partition, and most calls of a step are such selections.
 // the same two passes with the predicate "key[i] >> shift differs from key[i-1] >> shift" (first element: true)
 // computed from the sorted keys themselves: no flag array in between
-__global__ __launch_bounds__(WG) void head_count_kernel(const uint64_t *key, size_t n, int shift, uint32_t *cnt) {
+__global__ __launch_bounds__(WG) void head_count_kernel(const uint64_t *key, size_t n, int shift, uint32_t *cnt,
+                                                         unsigned long long *mask) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const bool f = i < n && (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift));
     const unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) cnt[i >> 6] = (uint32_t)__popcll(m);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) { cnt[i >> 6] = (uint32_t)__popcll(m); mask[i >> 6] = m; }
 }
-__global__ __launch_bounds__(WG) void head_scatter_kernel(const uint64_t *key, size_t n, int shift, const uint32_t *off, uint32_t *out_idx,
-                                                           uint32_t *total) {
+// second pass: the ballots of the first (8 B per 64 keys) instead of the keys again
+__global__ __launch_bounds__(WG) void head_scatter_kernel(const unsigned long long *mask, size_t n, const uint32_t *off,
+                                                           uint32_t *out_idx, uint32_t *total) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const bool f = i < n && (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift));
-    const unsigned long long m = __ballot(f);
-    if (f) out_idx[off[i >> 6] + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)i;
+    if (i >= n) return;
+    const unsigned long long m = mask[i >> 6];
+    const int lane = (int)(threadIdx.x & 63);
+    if ((m >> lane) & 1ull) out_idx[off[i >> 6] + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
     if (i == n - 1) *total = off[i >> 6] + (uint32_t)__popcll(m);
 }
 
@@ -133,10 +136,11 @@ size_t select_run_heads_u64(const uint64_t *key, size_t n, int shift, uint32_t *
     if (n >= (1ull << 32)) fail(HLMI_EINVAL, "select_run_heads_u64: more than 2^32 elements");
     const size_t nw = (n + 63) / 64;
     DBuf<uint32_t> cnt(nw), off(nw), total(1);
+    DBuf<unsigned long long> mask(nw);
     const dim3 grid(cdiv(n, WG));
-    hipLaunchKernelGGL(head_count_kernel, grid, dim3(WG), 0, stream(), key, n, shift, cnt.p);
+    hipLaunchKernelGGL(head_count_kernel, grid, dim3(WG), 0, stream(), key, n, shift, cnt.p, mask.p);
     exclusive_scan_u32(cnt.p, off.p, nw);
-    hipLaunchKernelGGL(head_scatter_kernel, grid, dim3(WG), 0, stream(), key, n, shift, off.p, out_idx, total.p);
+    hipLaunchKernelGGL(head_scatter_kernel, grid, dim3(WG), 0, stream(), mask.p, n, off.p, out_idx, total.p);
     HIP_CHECK(hipGetLastError());
     return (size_t)download_one(total.p);
 }
