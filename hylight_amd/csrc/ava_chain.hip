@@ -518,8 +518,12 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             }
             if (live) {
                 a.root[b + i] = val;
-                if (val == i) a.sbase[b + i] = (uint32_t)(pi < 0 ? 0 : (pi >= w0 ? f_same : f_before)) | (has_child ? 0x80000000u : 0u);
+                if (val == i) {
+                    a.sbase[b + i] = (uint32_t)(pi < 0 ? 0 : (pi >= w0 ? f_same : f_before)) | (has_child ? 0x80000000u : 0u);
+                    a.peak[b + i] = 0;                     // a chain's peak word starts here: every vote for it comes later,
+                }                                          // from this wave (no memset of the whole array per batch)
             }
+            __builtin_amdgcn_s_waitcnt(0);                 // the zeros are out before the first votes (same wave, same address)
             prev_root = val;
             // peaks: f << 32 | ~index, max = highest f, first index among equals
             const uint32_t k32 = live ? (uint32_t)Rf << 6 | (uint32_t)(63 - lane) : 0u;
@@ -846,8 +850,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     }
     ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
     DBuf<int> mem(A), root(A);
-    DBuf<unsigned long long> peak(A);
-    peak.zero();
+    DBuf<unsigned long long> peak(A);             // written by the kernel at every chain start before it is voted on
     DBuf<uint32_t> sbase(A);
     ca.sbase = sbase.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
