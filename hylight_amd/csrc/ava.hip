@@ -14,7 +14,7 @@ namespace {
 constexpr int WG = 256;
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 constexpr size_t ANCHOR_BATCH = 128u << 20;  // anchors per query batch (8 or 16 B each, x2 for the sort; 48 M measured 6 % slower on C2)
-constexpr size_t QUERY_BATCH = 2048;
+constexpr size_t QUERY_BATCH = 1u << 16;     // queries per batch (ava_chain.hip: QL_BITS)
 
 __global__ void lens_kernel(const uint64_t *off, size_t n, uint32_t *len) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -149,11 +149,32 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     }
     size_t anchor_batch = ANCHOR_BATCH;
     if (const char *e = getenv("HLMI_ANCHOR_BATCH_M")) anchor_batch = (size_t)std::max(1, atoi(e)) << 20;   // tuning hook
+    // batches of equal anchor counts (not full ones and a remainder: the last launches of a step would be small ones),
+    // and no more queries than keep the anchor a single 64-bit word (seed_and_chain: "fits")
+    uint64_t total_anchors = 0;
+    for (size_t i = 0; i < nQ; ++i) total_anchors += plan.per_query[i];
+    const uint64_t n_batches = std::max<uint64_t>(1, (total_anchors + anchor_batch - 1) / anchor_batch);
+    const uint64_t batch_target = (total_anchors + n_batches - 1) / n_batches;
+    size_t q_cap = QUERY_BATCH;
+    {
+        uint64_t max_tlen = 1;
+        for (size_t t = 0; t < nT; ++t) max_tlen = std::max<uint64_t>(max_tlen, in.T->h_off[t + 1] - in.T->h_off[t]);
+        // query position bits of a typical batch: the 98th percentile of the query lengths (a batch that holds one of
+        // the few longer reads takes the key + value form, the others are not made smaller for its sake)
+        std::vector<uint64_t> ql(nQ);
+        for (size_t i = 0; i < nQ; ++i) ql[i] = in.Q->h_off[i + 1] - in.Q->h_off[i];
+        const size_t k98 = (nQ - 1) * 98 / 100;
+        std::nth_element(ql.begin(), ql.begin() + (std::ptrdiff_t)k98, ql.end());
+        const int spare = 64 - (bits_for(nT > 1 ? nT - 1 : 1) + 1 + bits_for(max_tlen) + bits_for(std::max<uint64_t>(ql[k98], 1)) + 8);
+        // (never below 2048: a batch of many short reads rather takes the key + value form than ends early)
+        q_cap = std::min<size_t>(q_cap, std::max<size_t>(2048, (size_t)1 << std::max(0, std::min(spare, 16))));
+    }
     size_t q = 0;
     while (q < nQ) {
         uint64_t acc = 0;
         size_t hi = q;
-        while (hi < nQ && hi - q < QUERY_BATCH && (hi == q || acc + plan.per_query[hi] <= anchor_batch)) acc += plan.per_query[hi++];
+        while (hi < nQ && hi - q < q_cap && (hi == q || acc < batch_target) && (hi == q || acc + plan.per_query[hi] <= anchor_batch + anchor_batch / 4))
+            acc += plan.per_query[hi++];
         ChainOut ch;
         {
             HostTimer ht("seed_and_chain");

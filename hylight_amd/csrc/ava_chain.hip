@@ -30,7 +30,7 @@ constexpr int WG = 256;
 constexpr int HB = 1024;             // occurrence histogram bins per chunk
 // anchor key = qlocal | target | strand | tpos, packed with the bit widths the batch actually needs (pb bits of
 // target position, tb bits of target id): the anchor radix sort then runs 5 passes instead of 8 on C2
-constexpr int QL_BITS = 11, T_BITS_MAX = 21, TPOS_BITS_MAX = 24;     // chain scores (<= target length) carry 6 tie-break bits in 32
+constexpr int QL_BITS = 16, T_BITS_MAX = 21, TPOS_BITS_MAX = 24;     // chain scores (<= target length) carry 6 tie-break bits in 32
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 
 __device__ __forceinline__ size_t lower_bound_u64(const uint64_t *a, size_t n, uint64_t v) {
