@@ -59,6 +59,7 @@ struct AvaInput {
     const DevReads *Q = nullptr;           // all queries
     const uint32_t *d_rank_t = nullptr;    // strcmp rank of each target / query name (equal names, equal rank)
     const uint32_t *d_rank_q = nullptr;
+    uint64_t n_ranks = 0;                  // every rank is below this (number of distinct names)
     const uint32_t *d_chunk_of_t = nullptr;  // chunk slot (0..n_chunks) of each local target
     uint32_t n_chunks = 1;
     const Mz *d_qmz = nullptr;             // complete query sketch

@@ -134,7 +134,8 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         } else {
             sketch_device(*in.T, o.k, o.w, o.hpc, 0, tsk);
         }
-        build_index(tsk, in.d_chunk_of_t, in.d_rank_t, in.n_chunks, o, ix);
+        if (!in.n_ranks) fail(HLMI_EINVAL, "AvaInput::n_ranks not set");
+        build_index(tsk, in.d_chunk_of_t, in.d_rank_t, in.n_chunks, in.n_ranks, o, ix);
         tsk.mz.release();
     }
     stat_add("index_entries", (double)ix.n);
@@ -274,6 +275,7 @@ void ava_files(const char *target_fa, const char *query_fa, const hlmi_ava_opts 
     std::vector<uint32_t> qc = qsk.counts.download(Q.size());
     AvaInput in;
     in.T = &dT; in.Q = &dQ; in.d_rank_t = d_rt.p; in.d_rank_q = d_rq.p; in.d_chunk_of_t = d_chunk.p; in.n_chunks = 1;
+    in.n_ranks = name_of_rank.size();
     in.d_qmz = qsk.mz.p;
     in.qmz_off.assign(Q.size() + 1, 0);
     for (size_t i = 0; i < Q.size(); ++i) in.qmz_off[i + 1] = in.qmz_off[i] + qc[i];

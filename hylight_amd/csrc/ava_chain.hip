@@ -87,7 +87,23 @@ __global__ void index_rank_kernel(const uint64_t *y, const uint32_t *occ, const 
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t t = (uint32_t)(y[i] >> 32);
-    rk[i] = rank_t[t] | (occ[i] > mid_occ[chunk_of_t[t]] ? 0x80000000u : 0u);
+    rk[i] = occ[i] > mid_occ[chunk_of_t[t]] ? 0u : rank_t[t] + 1u;      // 0: too frequent inside its chunk
+}
+__global__ void compose_ck_kernel(const uint64_t *key, const uint32_t *rk, size_t n, int rb, uint64_t *ck) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) ck[i] = key[i] << rb | rk[i];
+}
+__global__ void iota_u32_kernel(uint32_t *v, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+__global__ void gather_key_kernel(const uint64_t *src, const uint32_t *perm, size_t n, uint64_t *dst) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+__global__ void gather_entry_kernel(const uint64_t *y, const uint32_t *rk, const uint32_t *perm, size_t n, uint64_t *y2, uint32_t *rk2) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) { y2[i] = y[perm[i]]; rk2[i] = rk[perm[i]]; }
 }
 __global__ void index_bucket_kernel(const uint64_t *key, size_t n, int shift, size_t n_buckets, uint32_t *bucket) {
     size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -100,7 +116,8 @@ __global__ void index_bucket_kernel(const uint64_t *key, size_t n, int shift, si
 struct SeedArgs {
     const Mz *qmz;              // first minimizer of the batch
     size_t n_mz;
-    const uint64_t *ikey, *iy;
+    const uint64_t *ikey, *iy, *ick;    // ick: key << rb | rank word (rb = 0: not built)
+    int rb;
     const uint32_t *irk, *bucket, *rank_q, *qlen;
     uint32_t *run_lo, *run_len; // occurrence run of every query minimizer: written by the counting pass, read by the fill
     int bucket_shift;
@@ -138,13 +155,43 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
             const uint64_t key = z.x >> 8;
             const size_t b = (size_t)(key >> a.bucket_shift);
             const size_t b_lo = a.bucket[b], b_hi = a.bucket[b + 1];
-            lo = b_lo + lower_bound_u64(a.ikey + b_lo, b_hi - b_lo, key);
-            hi = lo;
-            if (lo < b_hi && a.ikey[lo] == key) hi = lo + lower_bound_u64(a.ikey + lo, b_hi - lo, key + 1);
+            // the entries are ordered by (key, rank word) with rank word 0 = too frequent, else name rank + 1: the ones
+            // this query may pair with are a suffix of the key's run - counting is two searches, not a scan
+            // (the searches are bound by the 64-byte lines they touch: one word per entry, one read per step)
+            auto first_ge = [&](size_t from, uint64_t k, uint32_t r) {       // first entry >= (k, r) in [from, b_hi)
+                size_t l = from, h = b_hi;
+                if (a.rb) {
+                    const uint64_t want = k << a.rb | r;
+                    while (l < h) {
+                        const size_t mid = (l + h) >> 1;
+                        if (a.ick[mid] < want) l = mid + 1; else h = mid;
+                    }
+                    return l;
+                }
+                while (l < h) {
+                    const size_t mid = (l + h) >> 1;
+                    const uint64_t km = a.ikey[mid];
+                    if (km < k || (km == k && a.irk[mid] < r)) l = mid + 1; else h = mid;
+                }
+                return l;
+            };
+            uint32_t c = 0;
+            if (a.pair_once) {                                   // only partners that rank above the query
+                lo = first_ge(b_lo, key, rq + 2);
+                hi = first_ge(lo, key + 1, 0u);
+                c = (uint32_t)(hi - lo);
+            } else {                                             // every partner but the read itself
+                lo = first_ge(b_lo, key, 1u);
+                const size_t e0 = first_ge(lo, key, rq + 1), e1 = first_ge(e0, key, rq + 2);
+                hi = first_ge(e1, key + 1, 0u);
+                c = (uint32_t)((hi - lo) - (e1 - e0));
+            }
             a.run_lo[m] = (uint32_t)lo;
             a.run_len[m] = (uint32_t)(hi - lo);
+            cnt[m] = c;
         }
     }
+    if (!FILL) return;
     uint32_t my_cnt = 0;
     // the runs are served one after the other; the first 64 entries of the next run are already in flight while
     // this one is worked on (two dependent reads per run would otherwise sit on the critical path 64 times)
@@ -153,7 +200,7 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
     uint32_t rt_p = 0;
     auto prefetch = [&](int bn) {
         const unsigned long long e = __shfl((unsigned long long)lo, bn, 64) + lane;
-        if (e < __shfl((unsigned long long)hi, bn, 64)) { if (FILL) y_p = a.iy[e]; rt_p = a.irk[e]; }
+        if (e < __shfl((unsigned long long)hi, bn, 64)) { y_p = a.iy[e]; if (!a.pair_once) rt_p = a.irk[e]; }
     };
     if (todo) prefetch(__ffsll((long long)todo) - 1);
     while (todo) {
@@ -170,9 +217,9 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
         if (todo) prefetch(__ffsll((long long)todo) - 1);
         for (unsigned long long e0 = lo_b; e0 < hi_b; e0 += 64) {
             const unsigned long long e = e0 + lane;
-            if (e0 != lo_b && e < hi_b) { if (FILL) y = a.iy[e]; rt = a.irk[e]; }
-            // bit 31 of rt: too frequent inside its chunk
-            const bool ok = e < hi_b && (a.pair_once ? rq_b < rt && !(rt >> 31) : rq_b != (rt & 0x7fffffffu) && !(rt >> 31));   // pair once / never self
+            if (e0 != lo_b && e < hi_b) { y = a.iy[e]; if (!a.pair_once) rt = a.irk[e]; }
+            // the run holds partners only (counting pass), except the read itself when pairs are taken both ways
+            const bool ok = e < hi_b && (a.pair_once || rt != rq_b + 1u);
             const unsigned long long mask = __ballot(ok);
             if (FILL && ok) {
                 const uint32_t qspan = (uint32_t)(zx & 0xff), qpos = (uint32_t)zy >> 1, qz = (uint32_t)zy & 1;
@@ -191,7 +238,7 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
         }
         if (lane == b) my_cnt = c;
     }
-    if (!FILL && live) cnt[m] = my_cnt;
+    (void)my_cnt;
 }
 
 __global__ void gather_u64_at_kernel(const uint64_t *src, const uint64_t *idx, uint64_t *dst, size_t n) {
@@ -681,7 +728,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
 // host
 // ---------------------------------------------------------------------------------------------
 void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint32_t *d_rank_t, uint32_t n_chunks,
-                 const hlmi_ava_opts &o, DevIndex &ix) {
+                 uint64_t n_names, const hlmi_ava_opts &o, DevIndex &ix) {
     const size_t n = tsk.n;
     ix.n = n;
     ix.pair_once = o.pair_once;
@@ -728,6 +775,28 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint3
     ix.bucket.alloc(nb + 1);
     if (n) hipLaunchKernelGGL(index_rank_kernel, grid1(n), dim3(WG), 0, stream(), ix.y.p, ix.occ.p, ix.mid_occ.p, d_chunk_of_t,
                               d_rank_t, n, ix.rk.p);
+    if (n > 1) {
+        // order the entries of every key by their rank word (too frequent first, then ascending name rank), entries of
+        // one target stay in position order: two stable sorts, by rank word and then by key again.  A query's partners
+        // are then a suffix of the key's run (seed_kernel<count>).
+        if (n >= (1ull << 32)) fail(HLMI_EINVAL, "index larger than 2^32 entries");
+        DBuf<uint32_t> perm(n), rkey(n);
+        DBuf<uint64_t> key2(n);
+        hipLaunchKernelGGL(iota_u32_kernel, grid1(n), dim3(WG), 0, stream(), perm.p, n);
+        HIP_CHECK(hipMemcpyAsync(rkey.p, ix.rk.p, n * 4, hipMemcpyDeviceToDevice, stream()));
+        sort_pairs_u32_u32(rkey.p, perm.p, n, 0, 32);
+        hipLaunchKernelGGL(gather_key_kernel, grid1(n), dim3(WG), 0, stream(), ix.key.p, perm.p, n, key2.p);
+        sort_pairs_u64_u32(key2, perm, n, 0, 2 * o.k);
+        DBuf<uint64_t> y2(n);
+        hipLaunchKernelGGL(gather_entry_kernel, grid1(n), dim3(WG), 0, stream(), ix.y.p, ix.rk.p, perm.p, n, y2.p, rkey.p);
+        std::swap(ix.y, y2);
+        std::swap(ix.rk, rkey);
+    }
+    ix.rank_bits = bits_for(n_names + 1);
+    if (2 * o.k + ix.rank_bits > 64 || getenv("HLMI_NO_RANK_WORD")) ix.rank_bits = 0;      // (the variable: test hook)
+    ix.ck.alloc(n && ix.rank_bits ? n : 1);
+    if (n && ix.rank_bits)
+        hipLaunchKernelGGL(compose_ck_kernel, grid1(n), dim3(WG), 0, stream(), ix.key.p, ix.rk.p, n, ix.rank_bits, ix.ck.p);
     hipLaunchKernelGGL(index_bucket_kernel, grid1(nb + 1), dim3(WG), 0, stream(), ix.key.p, n, ix.bucket_shift, nb, ix.bucket.p);
     HIP_CHECK(hipGetLastError());
     sync();
@@ -739,7 +808,7 @@ static SeedArgs make_seed_args(const AvaInput &in, const DevIndex &ix, const See
     sa.pair_once = ix.pair_once;
     sa.qmz = in.d_qmz + in.qmz_off[q_lo];
     sa.n_mz = in.qmz_off[q_hi] - in.qmz_off[q_lo];
-    sa.ikey = ix.key.p; sa.iy = ix.y.p; sa.irk = ix.rk.p; sa.bucket = ix.bucket.p; sa.bucket_shift = ix.bucket_shift;
+    sa.ikey = ix.key.p; sa.iy = ix.y.p; sa.irk = ix.rk.p; sa.ick = ix.ck.p; sa.rb = ix.rank_bits; sa.bucket = ix.bucket.p; sa.bucket_shift = ix.bucket_shift;
     sa.run_lo = plan.lo.p + in.qmz_off[q_lo]; sa.run_len = plan.len.p + in.qmz_off[q_lo];
     sa.rank_q = in.d_rank_q; sa.qlen = d_qlen;
     sa.n_idx = ix.n;

@@ -7,18 +7,20 @@ namespace hlmi {
 // ---- S2: index over the targets of this run (all chunks together, per-chunk semantics kept) ----
 struct DevIndex {
     size_t n = 0;
-    DBuf<uint64_t> key;      // minimizer hash (x >> 8), ascending; equal keys ordered by (target, pos)
+    DBuf<uint64_t> key;      // minimizer hash (x >> 8), ascending; equal keys ordered by (rank word, target position)
     DBuf<uint64_t> y;        // target << 32 | pos << 1 | strand
-    DBuf<uint32_t> occ;      // occurrences of this key inside the entry's chunk
+    DBuf<uint32_t> occ;      // occurrences of this key inside the entry's chunk (order of the first sort; build only)
     DBuf<uint32_t> mid_occ;  // per chunk: occurrence cut-off
-    DBuf<uint32_t> rk;       // name rank of the entry's target | (too frequent in its chunk) << 31: all a seed needs to
-                             // accept or reject the occurrence, read in step with y
+    DBuf<uint32_t> rk;       // rank word: 0 = too frequent in its chunk, else name rank of the entry's target + 1;
+                             // ascending inside a key, so the partners of a query are a suffix of the key's run
+    DBuf<uint64_t> ck;       // key << rank_bits | rank word: ONE ascending word per entry for the counting searches
+    int rank_bits = 0;       // (0: key and rank word do not fit 64 bits together, the searches compare both arrays)
     DBuf<uint32_t> bucket;   // first entry of every value of the top bucket_bits key bits (2^bits + 1 offsets)
     int bucket_shift = 0, bucket_bits = 0;
     int pair_once = 1;       // seeding rule carried with the index (hlmi_ava_opts::pair_once)
 };
 void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint32_t *d_rank_t, uint32_t n_chunks,
-                 const hlmi_ava_opts &o, DevIndex &ix);
+                 uint64_t n_names, const hlmi_ava_opts &o, DevIndex &ix);      // n_names: bound of the name ranks
 
 // ---- S3/S4 output: alignment pieces = lists of fixed points -----------------------------------
 struct Piece {               // 32 B

@@ -132,6 +132,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         AvaInput in;
         in.T = &dT; in.Q = &m.dQ; in.d_rank_t = d_rt.p; in.d_rank_q = m.d_rank_q.p; in.d_chunk_of_t = d_ct.p;
         in.n_chunks = n_my; in.d_qmz = m.d_qmz; in.qmz_off = m.qmz_off;
+        in.n_ranks = m.name_of_rank.size();
         if (m.dT == &m.dQ) in.t_query = tids;         // reads vs themselves: the targets' minimizers are in the query sketch
         AvaRows rows;
         ava_device(in, m.opts, rows);

@@ -74,6 +74,24 @@ def test_ava_key_value_anchor_form(tmp_path, monkeypatch):
     assert open(tmp_path / "pairs.paf").read() == open(tmp_path / "packed.paf").read()
 
 
+def test_ava_index_search_forms(tmp_path, monkeypatch):
+    """Seed counting searches one word per index entry (hash ‖ rank word); HLMI_NO_RANK_WORD forces the two-array
+    comparison that long k-mers with many reads take.  Both pairing rules: every pair once (long mode) and every
+    partner but the read itself (short mode: a key's run is counted as suffix minus the read's own entries)."""
+    reads = _sim(35, 70, n_strains=3, genome_len=15000, err_sub=0.01, err_ins=0.005, err_del=0.005)
+    fa = _write(tmp_path, "r.fa", reads)
+    OA.ava(fa, fa, tmp_path / "o1.paf")
+    OA.ava(fa, fa, tmp_path / "o2.paf", OA.opts_short())
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("HLMI_NO_RANK_WORD", env)
+        api.ava(fa, fa, tmp_path / "g1.paf")
+        api.ava(fa, fa, tmp_path / "g2.paf", api.ava_opts_short())
+        assert open(tmp_path / "g1.paf").read() == open(tmp_path / "o1.paf").read()
+        assert open(tmp_path / "g2.paf").read() == open(tmp_path / "o2.paf").read()
+    assert len(open(tmp_path / "o2.paf").read().splitlines()) > 20
+
+
 def test_ava_chain_state_forms(tmp_path, monkeypatch):
     """The chaining DP keeps score and predecessor in one packed word per lane when scores stay below 2^22 (every
     real read set); HLMI_CHAIN_UNPACKED forces the two-register form longer sequences take.  Same chains, and both
