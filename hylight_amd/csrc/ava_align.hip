@@ -441,8 +441,8 @@ struct NarrowWalk {
 // Traceback of one task by one lane.  Emits the runs in reverse (end -> start) and returns their number.  The
 // first `cap` of them are kept in `buf` (LDS, emission order): a task with no more than that is walked once and its
 // runs copied out by the whole group; with `out` (second walk of a longer task) they are written to
-// out[total-1 .. 0].  Every iteration consumes a row or a column or switches from state 0 to a gap state, so
-// 2 * (m + n) + 2 bounds the trip count; the cap only guards a corrupted plane.
+// out[total-1 .. 0].  Every iteration consumes at least one row or column, so m + n + 1 bounds the trip count; the
+// cap only guards a corrupted plane.
 __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total, uint32_t *buf = nullptr, uint32_t cap = 0) {
     int i = w.m, j = w.n, state = 0;
     uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
@@ -451,43 +451,47 @@ __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t tot
         else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
         ++n_runs;
     };
-    auto emit = [&](uint32_t op, uint32_t len) {
-        if (op == cur_op) { cur_len += len; return; }
-        if (cur_len) put();
-        cur_op = op; cur_len = len;
-    };
+    // One segment per iteration - a stretch of '=' or of 'X' on a diagonal (as far as one plane word reaches), or one
+    // gap base - through ONE body without state-specific branches: the few lanes of a wave that walk at the same time
+    // are in different states, and every branch they disagree on is executed for each of them in turn.
     for (int it = 0; (i > 0 || j > 0) && it < 4 * (EXT_MAX + SEQ_T_MAX); ++it) {
-        if (i == 0) { emit(OP_D, (uint32_t)j); j = 0; break; }       // row 0: H(0,j) is a gap from the corner
-        const int d = w.lb + ((j - i - w.dlo) & w.wmask);
-        const int c = (i - 1) >> 5, sh = 31 - ((i - 1) & 31);          // row i = bit sh of word c; row i-1 = bit sh+1
-        if (state == 0) {
-            const uint32_t inv = ~(w.word(PL_DIAG, c, d) >> sh);         // bit 0 = row i, bit 1 = row i-1, ... zeros above
-            const int r = inv ? __ffs((int)inv) - 1 : 32;              // diagonal moves in a row
-            if (r == 0) { state = ((w.word(PL_EGEF, c, d) >> sh) & 1u) ? 1 : 2; continue; }
-            uint32_t x = (w.word(PL_NE, c, d) >> sh) & (r == 32 ? 0xffffffffu : (1u << r) - 1u);
-            int done = 0;
-            while (x) {
-                const int p0 = __ffs((int)x) - 1;                      // next mismatch
-                if (p0 > done) emit(OP_EQ, (uint32_t)(p0 - done));
-                const uint32_t y = ~(x >> p0);
-                const int q = y ? __ffs((int)y) - 1 : 32;              // mismatches in a row
-                emit(OP_X, (uint32_t)q);
-                done = p0 + q;
-                x = done >= 32 ? 0u : x & ~((1u << done) - 1u);
-            }
-            if (r > done) emit(OP_EQ, (uint32_t)(r - done));
-            i -= r; j -= r;
-        } else if (state == 1) {
-            emit(OP_D, 1);
-            if (!((w.word(PL_EEXT, c, (d - 1) & 63) >> sh) & 1u)) state = 0;
-            --j;
+        uint32_t op, len;
+        if (i == 0) {                                          // row 0: H(0,j) is a gap from the corner
+            op = OP_D; len = (uint32_t)j; j = 0;
         } else {
-            emit(OP_I, 1);
-            bool ext = false;
-            if (i > 1) ext = (w.word(PL_FEXT, (i - 2) >> 5, (d + 1) & 63) >> (31 - ((i - 2) & 31))) & 1u;
-            if (!ext) state = 0;
-            --i;
+            const int d = w.lb + ((j - i - w.dlo) & w.wmask);
+            const int c = (i - 1) >> 5, sh = 31 - ((i - 1) & 31);          // row i = bit sh of word c; row i-1 = bit sh+1
+            // the five words an iteration can need, requested together
+            const uint32_t dg = w.word(PL_DIAG, c, d) >> sh;   // bit 0 = row i, bit 1 = row i-1, ... zeros above the word
+            const uint32_t ne = w.word(PL_NE, c, d) >> sh;
+            const uint32_t eg = w.word(PL_EGEF, c, d) >> sh;
+            const uint32_t ee = w.word(PL_EEXT, c, (d - 1) & 63) >> sh;
+            const int i2 = i > 1 ? i - 2 : 0;
+            const uint32_t fe = w.word(PL_FEXT, i2 >> 5, (d + 1) & 63) >> (31 - (i2 & 31));
+            // a cell reached in state 0 that did not take the diagonal opens a gap: E if e >= f, else F
+            const int st = state != 0 ? state : ((dg & 1u) ? 0 : ((eg & 1u) ? 1 : 2));
+            if (st == 0) {
+                const uint32_t inv = ~dg;
+                const int r = inv ? __ffs((int)inv) - 1 : 32;                 // diagonal moves in a row (this word)
+                const bool isx = (ne & 1u) != 0;
+                const uint32_t flip = isx ? ~ne : ne;                         // first row whose '=' / 'X' kind differs
+                int l = flip ? __ffs((int)flip) - 1 : 32;
+                l = l < r ? l : r;
+                op = isx ? OP_X : OP_EQ; len = (uint32_t)l;
+                i -= l; j -= l;
+                state = 0;
+            } else if (st == 1) {
+                op = OP_D; len = 1;
+                state = (ee & 1u) ? 1 : 0;                     // E of this cell extends the E of the cell to the left
+                --j;
+            } else {
+                op = OP_I; len = 1;
+                state = (i > 1 && (fe & 1u)) ? 2 : 0;          // F of this cell extends the F of the cell above
+                --i;
+            }
         }
+        if (op == cur_op) cur_len += len;
+        else { if (cur_len) put(); cur_op = op; cur_len = len; }
     }
     if (cur_len) put();
     return n_runs;
