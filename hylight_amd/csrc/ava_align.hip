@@ -182,7 +182,8 @@ __device__ __forceinline__ uint32_t load_window4(const uint8_t *codes, long long
 
 // stats[]: 0 bases (Lq + Lt) of all tasks, 1 of the square blocks compared here, 2 of the narrow DP tasks, 3 of the
 // wide DP tasks, 4 tasks finished on the diagonal fast path, 5 DP tasks, 6 DP rows
-enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, N_ALIGN_STATS };
+enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, N_ALIGN_STATS };
+constexpr int NR_SMALL = 64;                    // narrow tasks with fewer rows than this run in the instance with half the plane LDS
 
 // 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
 __device__ __forceinline__ uint64_t load_codes8(const uint8_t *base, long long idx, long long total) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
-    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0};      // < 2^32 per thread by far
+    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
     const size_t rounds = (a.n_tasks + n_thr - 1) / n_thr;            // uniform trip count: the allocation is per wave
     for (size_t r = 0; r < rounds; ++r) {
         const size_t ti = r * n_thr + tid;
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
                 else {
                     ++st[ST_DP];
                     if (c == 2 || c == 4) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
-                    else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m; }
+                    else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m; if (c == 1 && m < NR_SMALL) ++st[ST_NARROW_SMALL]; }
                 }
             }
         }
@@ -438,18 +439,27 @@ struct NarrowWalk {
     bool keep_order;                        // left extensions: the reversed sequences make end -> start the forward order
     __device__ __forceinline__ uint32_t word(int plane, int c, int lane) const { return pl[(plane * chunks + c) * 64 + lane]; }
 };
+struct WalkScore {                          // score of the walked path from its runs (no ambiguous base on it)
+    int match, mismatch, go, ge;
+    int total;
+};
 // Traceback of one task by one lane.  Emits the runs in reverse (end -> start) and returns their number.  The
 // first `cap` of them are kept in `buf` (LDS, emission order): a task with no more than that is walked once and its
 // runs copied out by the whole group; with `out` (second walk of a longer task) they are written to
 // out[total-1 .. 0].  Every iteration consumes at least one row or column, so m + n + 1 bounds the trip count; the
 // cap only guards a corrupted plane.
-__device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total, uint32_t *buf = nullptr, uint32_t cap = 0) {
+__device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total, uint32_t *buf = nullptr, uint32_t cap = 0,
+                                WalkScore *ws = nullptr) {
     int i = w.m, j = w.n, state = 0;
     uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
     auto put = [&]() {
         if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op;
         else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
         ++n_runs;
+        // a merged gap run is one gap of the DP (with open > 0 a gap never re-opens next to itself; with open = 0 it
+        // costs the same either way)
+        if (ws) ws->total += cur_op == OP_EQ ? ws->match * (int)cur_len
+                           : (cur_op == OP_X ? -ws->mismatch * (int)cur_len : -(ws->go + ws->ge * (int)cur_len));
     };
     // One segment per iteration - a stretch of '=' or of 'X' on a diagonal (as far as one plane word reaches), or one
     // gap base - through ONE body without state-specific branches: the few lanes of a wave that walk at the same time
@@ -629,6 +639,210 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         __builtin_amdgcn_wave_barrier();
         cp_n = (uint32_t)__shfl((int)cp_n, g * 16, 64); cp_off = (uint32_t)__shfl((int)cp_off, g * 16, 64);
         for (uint32_t k = (uint32_t)l; k < cp_n; k += 16) a.runs[cp_off + k] = rbuf[cp_n - 1 - k];   // forward order
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- pass 2a, packed: EIGHT tasks per wave -------------------------------------------------------------------------
+// Two tasks share every lane of a 16-lane group: their scores are the 16-bit halves of one register (bias 2^13, block
+// scores stay within +-4096 of it - the host checks the scoring constants), the recurrences are v_pk_* instructions
+// and every DPP move shifts both halves at once; only the ten compare + add-with-carry pairs of the bit planes are per
+// task.  22 vector instructions per task row instead of 31, and eight lanes of a wave walk the tracebacks instead of four.
+// The score of a task comes out of its walk (sum over the runs); a quad with an ambiguous base keeps H of the last row
+// per task instead (a base pair with an ambiguous code scores -ambi whether it reads '=' or 'X').
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 s2_of(int x) { return __builtin_bit_cast(s2, x); }
+__device__ __forceinline__ int int_of(s2 x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ s2 splat2(int v) { return s2{(short)v, (short)v}; }
+__device__ __forceinline__ s2 max2(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+// per-half min(x, 1) and a * b + c (the C++ forms of these come out as compares and selects)
+__device__ __forceinline__ s2 pk_min_u16(s2 x, s2 y) {
+    s2 r = x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+#endif
+    return r;
+}
+__device__ __forceinline__ s2 pk_mad_i16(s2 x, s2 y, s2 z) {
+    s2 r = x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+#endif
+    return r;
+}
+// lane l <- lane l-n of its row of 16, zero where there is none (no `old` register to prepare)
+template <int CTRL>
+__device__ __forceinline__ int dpp_z(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
+constexpr int DP_BIAS16 = 1 << 13;
+constexpr int PK_T0 = 12;                    // s_t2 index of target element dlo (dlo >= -(NARROW_PAD + NARROW_DELTA) = -10)
+
+// sq2[i] = base i of the query windows of both tasks (A | B << 8); st2[PK_T0 - dlo + x] = target base x of each task,
+// i.e. both tasks read their row-i base of lane l at the same index PK_T0 + l - 1 + i
+template <bool AMBI, int NR_CHUNKS>
+__device__ __forceinline__ void narrow_rows_pk(const AlignArgs &a, int rows, int mA, int mB, int dloA, int dloB, int l,
+                                               const uint16_t *sq2, const uint16_t *st2, uint32_t (*plA)[NR_CHUNKS][64],
+                                               uint32_t (*plB)[NR_CHUNKS][64], int lane, int &HendA, int &HendB) {
+    const int go = a.go, ge = a.ge, goe = go + ge;
+    const s2 v_goe = splat2(goe), v_ge = splat2(ge), v_go = splat2(go), v_gel = splat2(ge * l), v_goel = splat2(go + ge * l);
+    auto h0 = [&](int j0) { return j0 == 0 ? DP_BIAS16 : (j0 > 0 ? DP_BIAS16 - (go + ge * j0) : 0); };
+    s2 H = s2{(short)h0(dloA + l), (short)h0(dloB + l)};              // row 0 of both tasks
+    s2 G = H - v_goe;
+    uint32_t a0A = 0, a1A = 0, a2A = 0, a3A = 0, a4A = 0, a0B = 0, a1B = 0, a2B = 0, a3B = 0, a4B = 0;
+    const uint16_t *tp = st2 + PK_T0 + l - 1;                         // target bases of row i: tp[i]
+    s2 v_match = splat2(a.match), v_dm = splat2(-(a.match + a.mismatch)), v_one = splat2(1);
+    const s2 v_ambi = splat2(a.ambi);
+    asm volatile("" : "+v"(v_match), "+v"(v_dm), "+v"(v_one));        // keep the operands of the two asm forms in registers
+    auto row = [&](int i, int qb, int tb) {                           // qb / tb: base of task A | base of task B << 8
+        const s2 x = s2_of((int)__builtin_amdgcn_perm(0u, (uint32_t)(qb ^ tb), 0x0c010c00u));   // A | B << 16
+        s2 s = pk_mad_i16(pk_min_u16(x, v_one), v_dm, v_match);       // match, or -mismatch where the bases differ
+        if (AMBI) {
+            const s2 amb01 = s2_of((int)__builtin_amdgcn_perm(0u, (uint32_t)(((qb | tb) >> 2) & 0x0101), 0x0c010c00u));
+            s = s - amb01 * (s + v_ambi);
+        }
+        const s2 mm = H + s;
+        const s2 f = s2_of(dpp_z<0x101>(int_of(G)));                  // from lane d+1 of the row above
+        const s2 ht = max2(mm, f);
+        // E by a prefix max over the row of 16; the zero a lane without a source receives is this band's -inf
+        s2 p = ht + v_gel;
+        p = max2(p, s2_of(dpp_z<0x111>(int_of(p))));
+        p = max2(p, s2_of(dpp_z<0x112>(int_of(p))));
+        p = max2(p, s2_of(dpp_z<0x114>(int_of(p))));
+        p = max2(p, s2_of(dpp_z<0x118>(int_of(p))));
+        const s2 e = s2_of(dpp_z<0x111>(int_of(p))) - v_goel;
+        const s2 h = max2(ht, e);
+        const s2 fo = h - v_goe, fe = f - v_ge, eo = e + v_go;
+        a0A = shift_in(a0A, mm.x == h.x);   a0B = shift_in(a0B, mm.y == h.y);
+        a1A = shift_in(a1A, e.x >= f.x);    a1B = shift_in(a1B, e.y >= f.y);
+        a2A = shift_in(a2A, eo.x > h.x);    a2B = shift_in(a2B, eo.y > h.y);
+        a3A = shift_in(a3A, fe.x > fo.x);   a3B = shift_in(a3B, fe.y > fo.y);
+        a4A = shift_in(a4A, x.x != 0);      a4B = shift_in(a4B, x.y != 0);
+        G = max2(fo, fe);
+        H = h;
+        if (AMBI) { if (i == mA) HendA = h.x; if (i == mB) HendB = h.y; }
+    };
+    auto flush = [&](int c, int up) {
+        plA[PL_DIAG][c][lane] = a0A << up; plA[PL_EGEF][c][lane] = a1A << up; plA[PL_EEXT][c][lane] = a2A << up;
+        plA[PL_FEXT][c][lane] = a3A << up; plA[PL_NE][c][lane] = a4A << up;
+        plB[PL_DIAG][c][lane] = a0B << up; plB[PL_EGEF][c][lane] = a1B << up; plB[PL_EEXT][c][lane] = a2B << up;
+        plB[PL_FEXT][c][lane] = a3B << up; plB[PL_NE][c][lane] = a4B << up;
+    };
+    int qa = sq2[0], ta = tp[1];
+    int i = 1;
+    for (; i < rows; i += 2) {                                        // two rows per trip, the next two rows' bases in flight
+        const int qb = sq2[i], tb = tp[i + 1], qc = sq2[i + 1], tc = tp[i + 2];
+        row(i, qa, ta);
+        row(i + 1, qb, tb);
+        qa = qc; ta = tc;
+        if (((i + 1) & 31) == 0) flush(((i + 1) >> 5) - 1, 0);
+    }
+    if (i == rows) row(i, qa, ta);                                    // odd row count (no word boundary here)
+    if (rows & 31) flush(rows >> 5, 32 - (rows & 31));                // partial word: its first row up to bit 31
+}
+
+constexpr int PK_WAVES = 2;          // waves per workgroup of the packed kernel: 13 KB of LDS per wave, small workgroups pack the CU better
+template <int NR_MAX>
+__global__ __launch_bounds__(64 * PK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void align_narrow_pk_kernel(AlignArgs a) {
+    constexpr int NR_CHUNKS = NR_MAX / 32, NQ_STEPS = NR_MAX / 64, NT_STEPS = NR_MAX / 64 + 1;
+    constexpr int T2_LEN = NR_MAX + PK_T0 + NARROW_W + NARROW_DELTA + 12;
+    __shared__ uint32_t s_pl[PK_WAVES][2][N_PLANES][NR_CHUNKS][64];
+    __shared__ uint16_t s_q2[PK_WAVES * 4][NR_MAX + 4];
+    __shared__ uint16_t s_t2[PK_WAVES * 4][T2_LEN];
+    __shared__ uint32_t s_runs[PK_WAVES * 8][RUN_BUF_NARROW];
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15, wv = threadIdx.x >> 6;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t chunk_off = 0, chunk_left = 0;
+    const size_t n_octs = (a.n_list + 7) / 8;
+    uint8_t *q2b = (uint8_t *)s_q2[wv * 4 + g], *t2b = (uint8_t *)s_t2[wv * 4 + g];
+    for (size_t oc = wave; oc < n_octs; oc += n_waves) {
+        // group g works on tasks 8 oc + 2 g (half A of its lanes) and 8 oc + 2 g + 1 (half B)
+        const size_t liA = oc * 8 + (size_t)g * 2, liB = liA + 1;
+        const bool liveA = liA < a.n_list, liveB = liB < a.n_list;
+        size_t tiA = 0, tiB = 0;
+        Task tA{}, tB{};
+        if (liveA) { tiA = a.list[liA]; tA = a.tasks[tiA]; }
+        if (liveB) { tiB = a.list[liB]; tB = a.tasks[tiB]; }
+        bool ambig = false;
+        auto stage = [&](const Task &t, int hf) {     // 4 bases per lane and step, stored as the bytes `hf` of the pair arrays
+            const bool rev = (t.kind & TASK_REV) != 0;
+            uint32_t vq[NQ_STEPS], vt[NT_STEPS];
+#pragma unroll
+            for (int r = 0; r < NQ_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                vq[r] = 0;
+                if (x < t.m) vq[r] = load_window4(a.qcodes, a.q_total, (long long)t.qa, rev, rev, x);
+            }
+#pragma unroll
+            for (int r = 0; r < NT_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                vt[r] = 0;
+                if (x < t.n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)t.ta, false, false, x);
+            }
+#pragma unroll
+            for (int r = 0; r < NQ_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                if (x < t.m) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q2b[2 * (x + k) + hf] = (uint8_t)(vq[r] >> (8 * k));
+                    ambig |= (vq[r] & 0x04040404u) != 0;
+                }
+            }
+            const int t0 = PK_T0 - t.dlo;
+#pragma unroll
+            for (int r = 0; r < NT_STEPS; ++r) {
+                const int x = 4 * (l + 16 * r);
+                if (x < t.n) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t2b[2 * (t0 + x + k) + hf] = (uint8_t)(vt[r] >> (8 * k));
+                    ambig |= (vt[r] & 0x04040404u) != 0;
+                }
+            }
+        };
+        if (liveA) stage(tA, 0);
+        if (liveB) stage(tB, 1);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int mA = tA.m, mB = tB.m;
+        const int rows = (int)wave_max_u32_dpp((uint32_t)(mA > mB ? mA : mB));       // (idle halves: m = 0)
+        int HendA = 0, HendB = 0;
+        const bool amb = __any(ambig);
+        if (amb) narrow_rows_pk<true, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, s_q2[wv * 4 + g], s_t2[wv * 4 + g], s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
+        else narrow_rows_pk<false, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, s_q2[wv * 4 + g], s_t2[wv * 4 + g], s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
+        // H(m, n) of each task sits in the lane of its end diagonal (quads with an ambiguous base only)
+        const int endA = __shfl(HendA, g * 16 + ((tA.n - mA - tA.dlo) & (NARROW_W - 1)), 64) - DP_BIAS16;
+        const int endB = __shfl(HendB, g * 16 + ((tB.n - mB - tB.dlo) & (NARROW_W - 1)), 64) - DP_BIAS16;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // lanes 0 and 1 of every group walk the two tasks of the group
+        const int hf = l & 1;
+        const bool walker = l < 2 && (hf ? liveB : liveA);
+        const int wm = hf ? tB.m : tA.m, wn = hf ? tB.n : tA.n, wd = hf ? tB.dlo : tA.dlo;
+        uint32_t *rbuf = s_runs[(wv * 4 + g) * 2 + hf];
+        const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_NARROW ? a.run_buf_cap : (uint32_t)RUN_BUF_NARROW;
+        uint32_t cp_n = 0, cp_off = 0;
+        if (walker) {
+            const NarrowWalk w{&s_pl[wv][0][0][0][0] + hf * (N_PLANES * NR_CHUNKS * 64), NR_CHUNKS, g * 16, wm, wn, wd, NARROW_W - 1, false};
+            WalkScore ws{a.match, a.mismatch, a.go, a.ge, 0};
+            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap, &ws);
+            uint32_t off = 0;
+            bool ok = true;
+            if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
+            if (ok && n_runs) {
+                if (n_runs <= rcap) { cp_n = n_runs; cp_off = off; }
+                else narrow_walk(w, a.runs + off, n_runs);
+            }
+            const int score = amb ? (hf ? endB : endA) : ws.total;
+            a.out[hf ? tiB : tiA] = TaskOut{score, wm, wn, off, ok ? n_runs : 0, 2u | (uint32_t)wm << 2};
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // both run buffers of the group go out through all its lanes (forward order)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const uint32_t n2 = (uint32_t)__shfl((int)cp_n, g * 16 + h2, 64), o2 = (uint32_t)__shfl((int)cp_off, g * 16 + h2, 64);
+            const uint32_t *rb = s_runs[(wv * 4 + g) * 2 + h2];
+            for (uint32_t k = (uint32_t)l; k < n2; k += 16) a.runs[o2 + k] = rb[n2 - 1 - k];
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -939,7 +1153,10 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     // runs + one open chunk per allocating lane of every launch: classify and the two align_kernel (one per wave), the two
     // align_narrow_kernel instances (one per 16-lane group)
     constexpr size_t MAX_BLOCKS = 256 * 16;
-    size_t cap_runs = std::max<size_t>(NT * 6, 1 << 16) + MAX_BLOCKS * (3 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL);
+    // (a pool that overflows costs a second run of every DP kernel: 12 runs per task cover read sets with a few per cent
+    // of errors, where the average is 8)
+    size_t cap_runs = std::max<size_t>(NT * 12, 1 << 16) + MAX_BLOCKS * (3 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL) +
+                      (size_t)2 * 256 * 32 * 8 * PK_WAVES * RUN_CHUNK_SMALL;  // (two packed launches: 8 allocating lanes per wave)
     DBuf<uint32_t> runs;
     for (int attempt = 0;; ++attempt) {
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
@@ -986,11 +1203,32 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             sort_pairs_u32_u32(key.p, lst, nl, 0, 7);
         }
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
+        // packed form (two tasks per lane, 16-bit scores): block scores must stay within +-4096 of the bias
+        const int worst = std::max(std::max(o.match, o.mismatch), std::max(o.ambi, o.gap_open + o.gap_ext));
+        const bool packed = worst > 0 && (long long)worst * (BLOCK_MAX + NARROW_W + 2) <= 4000 && o.match >= 0 && o.mismatch >= 0 &&
+                            o.ambi >= 0 && o.gap_open >= 0 && o.gap_ext >= 0 && !getenv("HLMI_NARROW_UNPACKED");
         if (n1) {
             KTimer kt("align_narrow");
             aa.list = list1.p; aa.n_list = n1;
-            const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
-            hipLaunchKernelGGL(align_narrow_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+            if (packed) {
+                // the list is in ascending row order: its head (fewer than NR_SMALL rows, counted by the classifier)
+                // runs in the instance with half the plane LDS and twice the resident waves
+                size_t n_small = 0;
+                if (n1 >= 8) n_small = std::min<size_t>(n1, (size_t)astats.download(N_ALIGN_STATS)[ST_NARROW_SMALL]);
+                if (n_small) {
+                    aa.n_list = n_small;
+                    const unsigned nb = (unsigned)std::min<size_t>(((n_small + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
+                    hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SMALL>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
+                }
+                if (n1 > n_small) {
+                    aa.list = list1.p + n_small; aa.n_list = n1 - n_small;
+                    const unsigned nb = (unsigned)std::min<size_t>(((aa.n_list + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
+                    hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
+                }
+            } else {
+                const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
+                hipLaunchKernelGGL(align_narrow_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+            }
         }
         if (n3) {
             KTimer kt("align_narrow_long");

@@ -107,6 +107,27 @@ def test_ava_chain_state_forms(tmp_path, monkeypatch):
     assert open(tmp_path / "unpacked.paf").read() == want
 
 
+def test_ava_narrow_band_kernel_forms(tmp_path, monkeypatch):
+    """Near-diagonal blocks run eight per wave with two tasks sharing each lane (16-bit halves of one register, score
+    from the walked runs, or H of the last row when the quad holds an ambiguous base); HLMI_NARROW_UNPACKED forces the
+    four-per-wave 32-bit form that unusual scoring constants take.  Reads with errors and a few N so that both forms see
+    DP tasks with and without ambiguous bases."""
+    reads = _sim(36, 60, n_strains=2, genome_len=15000, err_sub=0.02, err_ins=0.01, err_del=0.01)
+    for k in (3, 11, 17, 29, 41):
+        reads[k].seq[700:703] = ord("N")
+        reads[k].seq[len(reads[k].seq) // 2] = ord("N")
+    fa = _write(tmp_path, "r.fa", reads)
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    want = open(tmp_path / "o.paf").read()
+    assert len(want.splitlines()) > 50
+    api.ava(fa, fa, tmp_path / "pk.paf")
+    assert open(tmp_path / "pk.paf").read() == want
+    assert api.last_stats()["align_tasks_narrow"] > 1000
+    monkeypatch.setenv("HLMI_NARROW_UNPACKED", "1")
+    api.ava(fa, fa, tmp_path / "un.paf")
+    assert open(tmp_path / "un.paf").read() == want
+
+
 def test_ava_traceback_run_buffer_overflow(tmp_path, monkeypatch):
     """The traceback keeps a task's runs in LDS and walks once; a task with more runs than the buffer holds is
     walked a second time straight into the pool.  HLMI_RUN_BUF_CAP=3 sends nearly every DP task down that path."""
