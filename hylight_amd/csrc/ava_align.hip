@@ -739,21 +739,25 @@ __device__ __forceinline__ void narrow_rows_pk(const AlignArgs &a, int rows, int
     if (rows & 31) flush(rows >> 5, 32 - (rows & 31));                // partial word: its first row up to bit 31
 }
 
-constexpr int PK_WAVES = 2;          // waves per workgroup of the packed kernel: 13 KB of LDS per wave, small workgroups pack the CU better
+constexpr int PK_WAVES = 1;          // waves per workgroup of the packed kernel: its LDS (12 KB per wave with 128 rows) sets the occupancy
 template <int NR_MAX>
 __global__ __launch_bounds__(64 * PK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void align_narrow_pk_kernel(AlignArgs a) {
     constexpr int NR_CHUNKS = NR_MAX / 32, NQ_STEPS = NR_MAX / 64, NT_STEPS = NR_MAX / 64 + 1;
     constexpr int T2_LEN = NR_MAX + PK_T0 + NARROW_W + NARROW_DELTA + 12;
+    // the run buffers of the walks share the LDS of the staged sequences (dead once the rows are done)
+    constexpr int Q2_LEN = NR_MAX + 4, RUN_BUF = NR_MAX >= 128 ? RUN_BUF_NARROW : 40;
+    constexpr int SEQ_WORDS = 4 * (Q2_LEN + T2_LEN + 1) / 2 + 2;
+    static_assert(8 * RUN_BUF <= SEQ_WORDS, "run buffers do not fit the sequence area");
     __shared__ uint32_t s_pl[PK_WAVES][2][N_PLANES][NR_CHUNKS][64];
-    __shared__ uint16_t s_q2[PK_WAVES * 4][NR_MAX + 4];
-    __shared__ uint16_t s_t2[PK_WAVES * 4][T2_LEN];
-    __shared__ uint32_t s_runs[PK_WAVES * 8][RUN_BUF_NARROW];
+    __shared__ uint32_t s_seq[PK_WAVES][SEQ_WORDS];
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15, wv = threadIdx.x >> 6;
+    uint16_t *const q2 = (uint16_t *)s_seq[wv] + g * Q2_LEN, *const t2 = (uint16_t *)s_seq[wv] + 4 * Q2_LEN + g * T2_LEN;
+    uint32_t (*const s_runs)[RUN_BUF] = (uint32_t (*)[RUN_BUF])s_seq[wv];
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     uint32_t chunk_off = 0, chunk_left = 0;
     const size_t n_octs = (a.n_list + 7) / 8;
-    uint8_t *q2b = (uint8_t *)s_q2[wv * 4 + g], *t2b = (uint8_t *)s_t2[wv * 4 + g];
+    uint8_t *q2b = (uint8_t *)q2, *t2b = (uint8_t *)t2;
     for (size_t oc = wave; oc < n_octs; oc += n_waves) {
         // group g works on tasks 8 oc + 2 g (half A of its lanes) and 8 oc + 2 g + 1 (half B)
         const size_t liA = oc * 8 + (size_t)g * 2, liB = liA + 1;
@@ -806,8 +810,8 @@ __global__ __launch_bounds__(64 * PK_WAVES) __attribute__((amdgpu_waves_per_eu(4
         const int rows = (int)wave_max_u32_dpp((uint32_t)(mA > mB ? mA : mB));       // (idle halves: m = 0)
         int HendA = 0, HendB = 0;
         const bool amb = __any(ambig);
-        if (amb) narrow_rows_pk<true, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, s_q2[wv * 4 + g], s_t2[wv * 4 + g], s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
-        else narrow_rows_pk<false, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, s_q2[wv * 4 + g], s_t2[wv * 4 + g], s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
+        if (amb) narrow_rows_pk<true, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, q2, t2, s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
+        else narrow_rows_pk<false, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, q2, t2, s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
         // H(m, n) of each task sits in the lane of its end diagonal (quads with an ambiguous base only)
         const int endA = __shfl(HendA, g * 16 + ((tA.n - mA - tA.dlo) & (NARROW_W - 1)), 64) - DP_BIAS16;
         const int endB = __shfl(HendB, g * 16 + ((tB.n - mB - tB.dlo) & (NARROW_W - 1)), 64) - DP_BIAS16;
@@ -817,8 +821,8 @@ __global__ __launch_bounds__(64 * PK_WAVES) __attribute__((amdgpu_waves_per_eu(4
         const int hf = l & 1;
         const bool walker = l < 2 && (hf ? liveB : liveA);
         const int wm = hf ? tB.m : tA.m, wn = hf ? tB.n : tA.n, wd = hf ? tB.dlo : tA.dlo;
-        uint32_t *rbuf = s_runs[(wv * 4 + g) * 2 + hf];
-        const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_NARROW ? a.run_buf_cap : (uint32_t)RUN_BUF_NARROW;
+        uint32_t *rbuf = s_runs[g * 2 + hf];
+        const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF ? a.run_buf_cap : (uint32_t)RUN_BUF;
         uint32_t cp_n = 0, cp_off = 0;
         if (walker) {
             const NarrowWalk w{&s_pl[wv][0][0][0][0] + hf * (N_PLANES * NR_CHUNKS * 64), NR_CHUNKS, g * 16, wm, wn, wd, NARROW_W - 1, false};
@@ -840,9 +844,10 @@ __global__ __launch_bounds__(64 * PK_WAVES) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const uint32_t n2 = (uint32_t)__shfl((int)cp_n, g * 16 + h2, 64), o2 = (uint32_t)__shfl((int)cp_off, g * 16 + h2, 64);
-            const uint32_t *rb = s_runs[(wv * 4 + g) * 2 + h2];
+            const uint32_t *rb = s_runs[g * 2 + h2];
             for (uint32_t k = (uint32_t)l; k < n2; k += 16) a.runs[o2 + k] = rb[n2 - 1 - k];
         }
+        __builtin_amdgcn_s_waitcnt(0);               // the buffers are the next pair's sequence area
         __builtin_amdgcn_wave_barrier();
     }
 }
