@@ -31,6 +31,10 @@ std::string read_file(const char *path) {
 }
 
 void write_lines(const char *path, const std::vector<std::string> &lines) {
+    std::vector<std::string_view> v(lines.begin(), lines.end());
+    write_lines(path, v);
+}
+void write_lines(const char *path, const std::vector<std::string_view> &lines) {
     FILE *f = fopen(path, "wb");
     if (!f) fail(HLMI_EIO, "cannot write %s: %s", path, strerror(errno));
     std::string buf;                             // one buffer, few large writes
@@ -259,6 +263,14 @@ std::string_view field_tail(std::string_view L, int k) {
 }  // namespace
 
 void sort_scored_lines(std::vector<std::string> &lines) {
+    std::vector<std::string_view> v(lines.begin(), lines.end());
+    sort_scored_lines(v);
+    std::vector<std::string> out;
+    out.reserve(lines.size());
+    for (std::string_view x : v) out.emplace_back(x);
+    lines.swap(out);
+}
+void sort_scored_lines(std::vector<std::string_view> &lines) {
     const size_t n = lines.size();
     std::vector<uint32_t> idx(n);
     // The rows this library writes carry "%.4f" scores: non-negative, few integer digits, at most 4 decimals.  Such a
@@ -328,9 +340,9 @@ void sort_scored_lines(std::vector<std::string> &lines) {
             return lines[a] > lines[b];        // last resort, reversed as well
         });
     }
-    std::vector<std::string> out;
+    std::vector<std::string_view> out;
     out.reserve(n);
-    for (uint32_t i : idx) out.push_back(std::move(lines[i]));
+    for (uint32_t i : idx) out.push_back(lines[i]);
     lines.swap(out);
 }
 

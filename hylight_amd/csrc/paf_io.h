@@ -53,8 +53,12 @@ bool format_scored_row(const PafRec &r, const std::string &qname, const std::str
 // `sort -k12 -nr` (utils.py:54,69): numeric descending on column 12, ties by reversed
 // whole-line byte order.  Lines carry no newline.
 void sort_scored_lines(std::vector<std::string> &lines);
+// the same on views into text the caller keeps alive (the stage formats its rows into a few large buffers: one
+// allocation per thread instead of one per line)
+void sort_scored_lines(std::vector<std::string_view> &lines);
 
 void write_lines(const char *path, const std::vector<std::string> &lines);
+void write_lines(const char *path, const std::vector<std::string_view> &lines);
 std::string read_file(const char *path);
 
 }  // namespace hlmi

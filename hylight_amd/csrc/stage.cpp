@@ -3,6 +3,8 @@
 // points used by the multi-GPU driver (sketch shard / install gathered sketch / run chunk share).
 #include "stage.h"
 
+#include <memory>
+#include <string_view>
 #include <thread>
 
 #include <algorithm>
@@ -110,6 +112,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     if (!m.d_qmz && m.Q.size()) fail(HLMI_ESTATE, "hlmi_job_run before a query sketch was installed");
     stat_reset();
     const double t0 = now_s();
+    struct ExitStamp { double t0; ~ExitStamp() { stat_set("t_with_cleanup_s", now_s() - t0); } } exit_stamp{t0};   // runs after the locals are gone
     // ---- this rank's chunks and targets ---------------------------------------------------------------
     std::vector<uint32_t> tids, chunk_of_t;
     uint32_t n_my = 0;
@@ -118,7 +121,9 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         for (uint32_t t = m.chunks[c].first; t < m.chunks[c].second; ++t) { tids.push_back(t); chunk_of_t.push_back(n_my); }
         ++n_my;
     }
-    std::vector<std::string> lines;
+    // the rows' text: every formatting thread appends to a buffer of its own, `lines` are views into those buffers
+    std::vector<std::string_view> lines;
+    std::vector<std::unique_ptr<std::string>> text;
     if (!tids.empty() && m.Q.size()) {
         DevReads dT_sub;
         const bool all_in_order = tids.size() == m.T.size();   // world == 1: every chunk, file order
@@ -160,20 +165,29 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
             std::vector<PafRec> kept = download_rows(rows.recs.p + r0, fo.rows);
             {   // rows -> text on the host threads (three %.4f conversions per row dominate), order kept
                 const size_t nk = kept.size();
-                std::vector<std::string> txt(nk);
-                std::vector<uint8_t> ok(nk, 0);
+                std::vector<uint32_t> at(nk), len(nk, 0);          // span of row i in its thread's buffer (len 0: dropped)
                 const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), nk / 2048));
+                const size_t first_buf = text.size();
+                for (int t = 0; t < nt; ++t) text.emplace_back(new std::string());
                 auto work = [&](int t) {
-                    std::string tmp;
+                    std::string tmp, &buf = *text[first_buf + (size_t)t];
+                    buf.reserve((nk / nt + 1) * 160);
                     for (size_t i = nk * (size_t)t / nt; i < nk * (size_t)(t + 1) / nt; ++i)
                         if (format_scored_row(kept[i], m.name_of_rank[kept[i].qid], m.name_of_rank[kept[i].tid],
-                                              fo.x_digit_sum[i], iden, tmp)) { txt[i] = tmp; ok[i] = 1; }
+                                              fo.x_digit_sum[i], iden, tmp)) {
+                            at[i] = (uint32_t)buf.size(); len[i] = (uint32_t)tmp.size();
+                            buf.append(tmp);
+                        }
                 };
                 std::vector<std::thread> pool;
                 for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
                 work(0);
                 for (auto &th : pool) th.join();
-                for (size_t i = 0; i < nk; ++i) if (ok[i]) lines.push_back(std::move(txt[i]));
+                for (int t = 0; t < nt; ++t) {                      // the buffers are final: views are safe now
+                    const std::string &buf = *text[first_buf + (size_t)t];
+                    for (size_t i = nk * (size_t)t / nt; i < nk * (size_t)(t + 1) / nt; ++i)
+                        if (len[i]) lines.emplace_back(buf.data() + at[i], len[i]);
+                }
             }
             t_fmt += now_s() - tf;
             c0 = c1;
@@ -195,6 +209,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     stat_set("t_format_sort_write_s", now_s() - t3);
     ktimer_flush();
     stat_set("t_total_s", now_s() - t0);
+
     stat_set("bases_q", (double)m.Q.bases.size());
 }
 
