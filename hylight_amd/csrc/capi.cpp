@@ -211,14 +211,16 @@ int hlmi_minimap22sfo(const char *in_paf, const char *out_sfo, int min_overlap_l
 
 int hlmi_merge_scored_paf(const char *const *in_pafs, int n_in, const char *out_paf) {
     return guarded([&] {
-        std::vector<std::string> lines;
+        std::vector<std::string> data((size_t)n_in);         // the parts stay whole, the lines are views into them
+        std::vector<std::string_view> lines;
         for (int i = 0; i < n_in; ++i) {
-            std::string d = read_file(in_pafs[i]);
+            data[(size_t)i] = read_file(in_pafs[i]);
+            const std::string &d = data[(size_t)i];
             size_t pos = 0;
             while (pos < d.size()) {
                 size_t e = d.find('\n', pos);
                 if (e == std::string::npos) e = d.size();
-                lines.emplace_back(d, pos, e - pos);
+                lines.emplace_back(d.data() + pos, e - pos);
                 pos = e + 1;
             }
         }
