@@ -18,6 +18,8 @@ struct FilterCfg {
     int min_o = 4;
     bool long_mode = true;
     uint32_t chunk_id_bound = 0;   // 1 + largest PafRec::chunk value that can occur (0: number of chunks of the call)
+    bool reference_order = true;   // rows come back in the reference's write order; false: any order (the stage sorts
+                                   // everything by score and text afterwards, so the order here cannot show)
 };
 
 // Rows kept by pass 2 BEFORE the score2 >= iden test (that test needs the "%.4f" text and is

@@ -667,6 +667,11 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     hipLaunchKernelGGL(gather_u32_kernel, grid1(nk), dim3(WG), 0, stream(), grows.p, kidx.p, krows.p, nk);
     hipLaunchKernelGGL(gather_u32_kernel, grid1(nk), dim3(WG), 0, stream(), xdig.p, kidx.p, kx.p, nk);
     std::vector<uint32_t> hrows = krows.download(nk), hx = kx.download(nk);
+    if (!cfg.reference_order) {
+        out.rows.swap(hrows);
+        out.x_digit_sum.swap(hx);
+        return;
+    }
     // reference write order: per chunk, the slr2:57 order.  Only kept rows are ordered on the host.
     std::vector<PafRec> hrecs(nk);
     {

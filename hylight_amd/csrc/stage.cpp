@@ -145,6 +145,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         FilterCfg cfg;
         cfg.len_over = len_over; cfg.mc = mc; cfg.long_mode = m.long_mode;
         cfg.chunk_id_bound = n_my;
+        cfg.reference_order = false;          // the rows are sorted by (score, text) below: one total order
         // The chunks are independent (the reference runs one worker per chunk); filter them in groups whose SNP
         // events (<= 2 per X op) stay below the 32-bit offsets the event arrays use.
         const std::vector<uint64_t> chunk_ops = ops_per_chunk(rows.recs.p, rows.n_rows, n_my);
