@@ -741,7 +741,7 @@ __device__ __forceinline__ void narrow_rows_pk(const AlignArgs &a, int rows, int
 
 constexpr int PK_WAVES = 1;          // waves per workgroup of the packed kernel: its LDS (12 KB per wave with 128 rows) sets the occupancy
 template <int NR_MAX>
-__global__ __launch_bounds__(64 * PK_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void align_narrow_pk_kernel(AlignArgs a) {
+__global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArgs a) {
     constexpr int NR_CHUNKS = NR_MAX / 32, NQ_STEPS = NR_MAX / 64, NT_STEPS = NR_MAX / 64 + 1;
     constexpr int T2_LEN = NR_MAX + PK_T0 + NARROW_W + NARROW_DELTA + 12;
     // the run buffers of the walks share the LDS of the staged sequences (dead once the rows are done)
