@@ -276,14 +276,6 @@ __global__ void group_hist_kernel(const uint32_t *gstart, size_t n_groups, size_
 // ---------------------------------------------------------------------------------------------
 // chains
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t u = __shfl_xor(v, o, 64);
-        v = u > v ? u : v;
-    }
-    return v;
-}
 __device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
 
 __device__ __forceinline__ bool block_ok(int q0, int t0, int q1, int t1) {

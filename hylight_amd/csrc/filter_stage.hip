@@ -244,18 +244,6 @@ void sort_chunk_key(const uint32_t *d_chunk, const uint64_t *d_key, size_t n, ui
     }
 }
 
-// first index i in [0,n) with (chunk[i],key[i]) >= (c,k)
-__device__ __forceinline__ size_t lower_bound_ck(const uint32_t *chunk, const uint64_t *key, size_t n, uint32_t c,
-                                                 uint64_t k) {
-    size_t lo = 0, hi = n;
-    while (lo < hi) {
-        size_t mid = (lo + hi) >> 1;
-        bool less = chunk[mid] < c || (chunk[mid] == c && key[mid] < k);
-        if (less) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // ---------------------------------------------------------------------------------------
 // pair groups
 // ---------------------------------------------------------------------------------------
