@@ -115,6 +115,8 @@ struct AlignArgs {
     uint32_t cap_runs;
     uint32_t *counters;     // [0] runs cursor, [1] overflow
     uint32_t run_buf_cap;   // runs the first traceback walk may keep in LDS (test hook HLMI_RUN_BUF_CAP lowers it)
+    uint8_t *defer_flag;    // classification: tasks left to the second pass (flag per task, then their list and its length)
+    const uint32_t *defer_list, *defer_count;
 };
 
 // exclusive prefix sum over the wave; total = sum of all lanes
@@ -209,6 +211,11 @@ __device__ __forceinline__ uint64_t load_window8(const uint8_t *codes, long long
 // would still pass with 3), so the typical task costs 8-9 iterations of two 8-byte loads; a block with m != n gets
 // its common prefix / suffix measured the same way (second certificate below); the runs of the tasks that finish
 // here are allocated with one pool request per wave.
+// Two passes.  PASS 1 goes over all tasks and settles the square blocks; the blocks with m != n and the end
+// extensions (a tenth of the tasks, scattered one or two to a wave, each with two or three times the work of a square
+// block) are only flagged.  PASS 2 runs the second and third certificate over the list of the flagged tasks, every lane
+// busy with the same kind of work (in one pass those few lanes cost a third of the kernel).
+template <int PASS>
 __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls, unsigned long long *stats) {
     __shared__ unsigned long long s_stat[WAVES][N_ALIGN_STATS];
     const int lane = threadIdx.x & 63;
@@ -216,10 +223,12 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
     uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
-    const size_t rounds = (a.n_tasks + n_thr - 1) / n_thr;            // uniform trip count: the allocation is per wave
+    const size_t n_units = PASS == 1 ? a.n_tasks : (size_t)*a.defer_count;
+    const size_t rounds = (n_units + n_thr - 1) / n_thr;              // uniform trip count: the allocation is per wave
     for (size_t r = 0; r < rounds; ++r) {
-        const size_t ti = r * n_thr + tid;
-        const bool live = ti < a.n_tasks;
+        const size_t u = r * n_thr + tid;
+        bool live = u < n_units;
+        const size_t ti = PASS == 1 || !live ? u : (size_t)a.defer_list[u];
         Task tk{};
         if (live) tk = a.tasks[ti];
         const int m = tk.m, n = tk.n;
@@ -229,6 +238,11 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
             if (m <= 0 || n <= 0) c = 0;
             else if ((tk.kind & 3) == 0) { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
             if (c == 2 && (m < n - tk.dlo ? m : n - tk.dlo) <= WIDE_SHORT) c = 4;      // rows the 64-diagonal kernel really runs
+        }
+        if (PASS == 1 && live) {                                      // second / third certificate: the other pass
+            const bool defer = c != 0 && a.kmax >= 0 && ((tk.kind & 3) != 0 || m != n);
+            a.defer_flag[ti] = defer ? 1 : 0;
+            if (defer) { live = false; try_fast = false; }
         }
         int k = 0, mpos[3] = {0, 0, 0};
         bool ambig = false;
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         // it is the unique best cell and the alignment is L matches.  With an end bonus in play (short mode) a cell of
         // the bonus row could outrank it, so the certificate then needs (L, L) to lie in that row itself.
         uint32_t ext_flag = 0;
-        if (live && c != 0 && (tk.kind & 3) != 0 && a.kmax >= 0) {
+        if (PASS == 2 && live && c != 0 && (tk.kind & 3) != 0 && a.kmax >= 0) {
             const bool rev = (tk.kind & TASK_REV) != 0, left = (tk.kind & 3) == 1;
             const int L = m < n ? m : n;
             const int end_row = (int)(tk.narrow >> 1) - 1;
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
                 fast = true;
                 c = 0;
             }
-        } else if (live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
+        } else if (PASS == 2 && live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
             const bool rev = (tk.kind & TASK_REV) != 0;
             const int mn = m < n ? m : n;
             int lcp = 0, lcs = 0;
@@ -1160,7 +1174,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     constexpr size_t MAX_BLOCKS = 256 * 16;
     // (a pool that overflows costs a second run of every DP kernel: 12 runs per task cover read sets with a few per cent
     // of errors, where the average is 8)
-    size_t cap_runs = std::max<size_t>(NT * 12, 1 << 16) + MAX_BLOCKS * (3 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL) +
+    size_t cap_runs = std::max<size_t>(NT * 12, 1 << 16) + MAX_BLOCKS * (4 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL) +
                       (size_t)2 * 256 * 32 * 8 * PK_WAVES * RUN_CHUNK_SMALL;  // (two packed launches: 8 allocating lanes per wave)
     DBuf<uint32_t> runs;
     for (int attempt = 0;; ++attempt) {
@@ -1183,16 +1197,21 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
         // pass 1: classify every task, finish the diagonal fast path right away
         DBuf<uint8_t> cls(NT), f1(NT), f2(NT), f3(NT), f4(NT);
+        DBuf<uint32_t> list1(NT), list2(NT), list3(NT), list4(NT);
+        DBuf<uint32_t> list_n(4);
         {
             KTimer kt("align_classify");
             const unsigned nbc = (unsigned)std::min<size_t>(cdiv(NT, (size_t)WG), MAX_BLOCKS);
             astats.zero();
-            hipLaunchKernelGGL(classify_kernel, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
+            aa.defer_flag = f1.p;                 // (f1 .. f4 are filled by split_class_kernel afterwards)
+            aa.defer_list = list1.p; aa.defer_count = list_n.p;
+            hipLaunchKernelGGL(classify_kernel<1>, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
+            select_flagged_indices_async(f1.p, list1.p, NT, list_n.p);
+            const unsigned nb2 = std::max(1u, nbc / 4);
+            hipLaunchKernelGGL(classify_kernel<2>, dim3(nb2), dim3(WG), 0, stream(), aa, cls.p, astats.p);
         }
         hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p, f3.p, f4.p);
         HIP_CHECK(hipGetLastError());
-        DBuf<uint32_t> list1(NT), list2(NT), list3(NT), list4(NT);
-        DBuf<uint32_t> list_n(4);
         select_flagged_indices_async(f1.p, list1.p, NT, list_n.p);
         select_flagged_indices_async(f2.p, list2.p, NT, list_n.p + 1);
         select_flagged_indices_async(f3.p, list3.p, NT, list_n.p + 2);
