@@ -16,6 +16,8 @@
 // in-place MSD radix sort (ksort.h:132-184) leaves equal keys, so that sort is restated exactly.
 #include "graph.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <array>
 #include <cctype>
@@ -55,12 +57,14 @@ struct SdSeq {
 struct Dict {
     std::vector<SdSeq> seq;
     std::unordered_map<std::string, uint32_t> h;
-    uint32_t put(const char *name, uint32_t len) {
-        auto it = h.find(name);
+    std::string key_;                                  // scratch for look-ups by view
+    uint32_t put(std::string_view name, uint32_t len) {
+        key_.assign(name);
+        auto it = h.find(key_);
         if (it != h.end()) return it->second;
         uint32_t id = (uint32_t)seq.size();
-        seq.push_back(SdSeq{name, len});
-        h.emplace(name, id);
+        seq.push_back(SdSeq{key_, len});
+        h.emplace(key_, id);
         return id;
     }
     int32_t get(const std::string &name) const {
@@ -118,16 +122,35 @@ void radix_sort64(T *beg, T *end, Key key) {
 }
 
 // ---- a9 ------------------------------------------------------------------------------------------
-struct PafRow { uint32_t ql, qs, qe, tl, ts, te, ml, bl; bool rev; std::string qn, tn; };
+struct PafRow { uint32_t ql, qs, qe, tl, ts, te, ml, bl; bool rev; std::string_view qn, tn; };
+// strtol(s, nullptr, 10) on a token that is not NUL-terminated: leading white space, optional sign, digits up to the
+// first other character, saturation at LONG_MIN / LONG_MAX
+long strtol_view(std::string_view t) {
+    size_t i = 0;
+    while (i < t.size() && (t[i] == ' ' || (t[i] >= '\t' && t[i] <= '\r'))) ++i;
+    bool neg = false;
+    if (i < t.size() && (t[i] == '+' || t[i] == '-')) { neg = t[i] == '-'; ++i; }
+    unsigned long long v = 0;
+    const unsigned long long lim = neg ? (unsigned long long)LONG_MAX + 1ull : (unsigned long long)LONG_MAX;
+    bool sat = false;
+    for (; i < t.size() && t[i] >= '0' && t[i] <= '9'; ++i) {
+        if (!sat) {
+            v = v * 10 + (unsigned long long)(t[i] - '0');
+            if (v > lim) { v = lim; sat = true; }
+        }
+    }
+    return neg ? (long)(0ull - v) : (long)v;
+}
 
 std::vector<Hit> read_hits(const char *fn, const Opt &o, Dict &d) {
-    std::string data = read_file(fn);
+    const std::string file = read_file(fn);
+    const std::string_view data(file);
     std::vector<Hit> hits;
     PafRow r{};
     size_t pos = 0, N = data.size();
     while (pos < N) {
         size_t e = data.find('\n', pos);
-        if (e == std::string::npos) e = N;
+        if (e == std::string_view::npos) e = N;
         size_t le = e;
         if (le - pos > 1 && data[le - 1] == '\r') --le;
         // fields (paf.c:34-61): strtol on each numeric column, row skipped when it has < 10 of them
@@ -135,9 +158,9 @@ std::vector<Hit> read_hits(const char *fn, const Opt &o, Dict &d) {
         size_t p = pos;
         while (true) {
             size_t f = data.find('\t', p);
-            if (f == std::string::npos || f > le) f = le;
-            std::string tok = data.substr(p, f - p);
-            const long v = strtol(tok.c_str(), nullptr, 10);
+            if (f == std::string_view::npos || f > le) f = le;
+            const std::string_view tok = data.substr(p, f - p);
+            const long v = t >= 1 && t <= 10 && t != 4 && t != 5 ? strtol_view(tok) : 0;
             switch (t) {
                 case 0: r.qn = tok; break;
                 case 1: r.ql = (uint32_t)v; break;
@@ -161,9 +184,9 @@ std::vector<Hit> read_hits(const char *fn, const Opt &o, Dict &d) {
         // hit.c:85 - unsigned differences, int thresholds
         if (r.qe - r.qs < (uint32_t)o.min_span || r.te - r.ts < (uint32_t)o.min_span || (int)r.ml < o.min_match) continue;
         Hit h{};
-        h.qns = (uint64_t)d.put(r.qn.c_str(), r.ql) << 32 | r.qs;
+        h.qns = (uint64_t)d.put(r.qn, r.ql) << 32 | r.qs;
         h.qe = r.qe;
-        h.tn = d.put(r.tn.c_str(), r.tl);
+        h.tn = d.put(r.tn, r.tl);
         h.ts = r.ts; h.te = r.te; h.rev = r.rev; h.ml = r.ml; h.bl = r.bl & 0x7fffffffu; h.del = 0;
         hits.push_back(h);
         if ((uint32_t)(h.qns >> 32) != h.tn) {      // bi_dir = 1 (main.c:35)
@@ -707,8 +730,6 @@ char comp_base(int c) {                                         // asm.c:220-229
 
 void ug_seq(UGraph &ug, const Dict &d, const std::vector<Sub> &sub, const char *fn) {   // asm.c:232-286
     struct Intv { uint32_t utg, ori, start, len; };
-    SeqSet reads;
-    read_seqs(fn, reads);
     std::vector<Intv> tmp(d.seq.size(), Intv{0, 0, 0, 0});
     for (size_t i = 0; i < ug.u.size(); ++i) {
         Utg &u = ug.u[i];
@@ -721,6 +742,15 @@ void ug_seq(UGraph &ug, const Dict &d, const std::vector<Sub> &sub, const char *
             l += t.len;
         }
     }
+    // only the reads that sit on a unitig bring their bases along (a few hundred of the read set)
+    SeqSet reads;
+    std::string key;
+    const std::function<bool(std::string_view)> on_unitig = [&](std::string_view name) {
+        key.assign(name);
+        const int32_t id = d.get(key);
+        return id >= 0 && tmp[id].len != 0;
+    };
+    read_seqs_subset(fn, &on_unitig, reads);
     for (size_t r = 0; r < reads.size(); ++r) {
         const int32_t id = d.get(reads.names[r]);
         if (id < 0 || tmp[id].len == 0) continue;
@@ -809,8 +839,13 @@ void miniasm_run(const char *paf, const char *reads_fa, int bub_dist, int n_roun
     o.min_ovlp = o.min_span;               // main.c:74
     const std::string fmt = outfmt;
     if (fmt != "ug" && fmt != "sg" && fmt != "paf" && fmt != "bed") fail(HLMI_EINVAL, "outfmt must be ug, sg, paf or bed");
+    stat_reset();
+    const auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = clk();
+    const auto lap = [&](const char *name) { const double t = clk(); stat_set(name, t - t_prev); t_prev = t; };
     Dict d;
     std::vector<Hit> hit = read_hits(paf, o, d);
+    lap("t_graph_read_paf_s");
     size_t n_hits = hit.size();
     // Step 2: 1-pass read selection (main.c:119-126)
     std::vector<Sub> sub = hit_sub(o.min_dp, o.min_iden, hit, n_hits, d.seq.size());
@@ -827,6 +862,7 @@ void miniasm_run(const char *paf, const char *reads_fa, int bub_dist, int n_roun
     }
     n_hits = hit_contained(o, d, sub, n_hits, hit);
     hit.resize(n_hits);
+    lap("t_graph_select_s");
     std::string out;
     if (fmt == "bed") {
         for (size_t i = 0; i < d.seq.size(); ++i)
@@ -841,7 +877,9 @@ void miniasm_run(const char *paf, const char *reads_fa, int bub_dist, int n_roun
     } else {
         Graph sg = sg_gen(o, d, sub, n_hits, hit);
         // Step 4.1 transitive reduction on the GPU (asg.c:148-193), then cleanup + symm on the host
+        lap("t_graph_build_s");
         if (arc_del_trans_device(sg.arc, sg.seq, sg.idx, o.gap_fuzz)) { g_cleanup(sg); g_symm(sg); }
+        lap("t_graph_reduce_s");
         g_cut_tip(sg, o.max_ext);                               // 4.2
         g_pop_bubble(sg, o.bub_dist);
         for (int i = 0; i <= o.n_rounds; ++i) {                 // 4.3 (main.c:167-173, float arithmetic incl. the NaN of -n 1)
@@ -853,9 +891,11 @@ void miniasm_run(const char *paf, const char *reads_fa, int bub_dist, int n_roun
         g_cut_tip(sg, o.max_ext);
         g_pop_bubble(sg, o.bub_dist);
         if (g_del_short(sg, o.final_drop) != 0) { g_cut_tip(sg, o.max_ext); g_pop_bubble(sg, o.bub_dist); }   // 4.5
+        lap("t_graph_clean_s");
         if (fmt == "ug") {
             UGraph ug = ug_gen(sg);
             if (reads_fa) ug_seq(ug, d, sub, reads_fa);
+            lap("t_graph_unitig_seq_s");
             ug_print(ug, d, sub, out);
         } else {
             for (const Arc &p : sg.arc) {                       // ma_sg_print, asm.c:41-55
@@ -867,6 +907,7 @@ void miniasm_run(const char *paf, const char *reads_fa, int bub_dist, int n_roun
         }
     }
     write_text(out_path, out);
+    lap("t_graph_write_s");
 }
 
 // ---- a18: sfo2overlaps.py, --num_pairs 0 branch ----------------------------------------------------------

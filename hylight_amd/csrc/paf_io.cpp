@@ -2,6 +2,16 @@
 // the text boundary the reference pipes between its processes.
 #include "paf_io.h"
 
+#include <functional>
+
+#include <unistd.h>
+
+#include <sys/stat.h>
+
+#include <sys/mman.h>
+
+#include <fcntl.h>
+
 #include <cmath>
 
 #include <charconv>
@@ -148,8 +158,36 @@ void read_paf(const char *path, PafText &out, bool need_tie_rank) {
 // ------------------------------------------------------------------------------------------
 // FASTA / FASTQ
 // ------------------------------------------------------------------------------------------
-void read_seqs(const char *path, SeqSet &out) {
-    std::string d = read_file(path);
+namespace {
+// read-only view of a whole file: mapped when the system allows it (no copy of a read set of hundreds of MB),
+// else read into memory
+struct FileView {
+    const char *p = nullptr;
+    size_t n = 0;
+    bool mapped = false;
+    std::string owned;
+    explicit FileView(const char *path) {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) fail(HLMI_EIO, "cannot open %s: %s", path, strerror(errno));
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { p = (const char *)m; n = (size_t)st.st_size; mapped = true; }
+        }
+        close(fd);
+        if (!mapped) { owned = read_file(path); p = owned.data(); n = owned.size(); }
+    }
+    ~FileView() { if (mapped) munmap((void *)p, n); }
+    FileView(const FileView &) = delete;
+    FileView &operator=(const FileView &) = delete;
+};
+}  // namespace
+
+void read_seqs(const char *path, SeqSet &out) { read_seqs_subset(path, nullptr, out); }
+
+void read_seqs_subset(const char *path, const std::function<bool(std::string_view)> *want, SeqSet &out) {
+    const FileView file(path);
+    const std::string_view d(file.p, file.n);
     size_t N = d.size(), pos = 0;
     uint32_t line_no = 0;
     out.off.push_back(0);
@@ -159,12 +197,12 @@ void read_seqs(const char *path, SeqSet &out) {
         if (e == std::string::npos) e = N;
         size_t end = e;
         if (end > pos && d[end - 1] == '\r') --end;
-        L = std::string_view(d).substr(pos, end - pos);
+        L = d.substr(pos, end - pos);
         pos = e + 1;
         ++line_no;
         return true;
     };
-    out.n_lines = (uint64_t)std::count(d.begin(), d.end(), '\n');
+    out.n_lines = want ? 0 : (uint64_t)std::count(d.begin(), d.end(), '\n');     // (only the stage's chunking asks for it)
     std::string_view L;
     bool have = next_line(L);
     while (have) {
@@ -174,15 +212,17 @@ void read_seqs(const char *path, SeqSet &out) {
         }
         bool fq = L[0] == '@';
         size_t ws = L.find_first_of(" \t", 1);
-        out.names.emplace_back(L.substr(1, (ws == std::string_view::npos ? L.size() : ws) - 1));
+        const std::string_view name = L.substr(1, (ws == std::string_view::npos ? L.size() : ws) - 1);
+        const bool keep = !want || (*want)(name);             // a record that is not wanted keeps its name, with no bases
+        out.names.emplace_back(name);
         out.first_line.push_back(line_no - 1);
-        size_t start = out.bases.size();
+        size_t slen = 0;
         have = next_line(L);
         while (have && !(L.size() && (L[0] == '>' || L[0] == '@' || L[0] == '+'))) {
-            out.bases.append(L);
+            if (keep) out.bases.append(L);
+            slen += L.size();
             have = next_line(L);
         }
-        size_t slen = out.bases.size() - start;
         if (fq && have && L.size() && L[0] == '+') {
             size_t q = 0;
             have = next_line(L);

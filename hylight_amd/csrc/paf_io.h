@@ -1,6 +1,7 @@
 // paf_io.h - host-side text I/O for the path: PAF parsing, FASTA/FASTQ reading, final row
 // formatting and the GNU-sort orders the reference pipes its text through.
 #pragma once
+#include <functional>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -44,6 +45,9 @@ struct SeqSet {
     uint32_t len(size_t i) const { return (uint32_t)(off[i + 1] - off[i]); }
 };
 void read_seqs(const char *path, SeqSet &out);
+// the same scan, but only the records `want` accepts bring their bases along (the others keep their name and have
+// length 0; n_lines is not counted)
+void read_seqs_subset(const char *path, const std::function<bool(std::string_view)> *want, SeqSet &out);
 
 // Final 14-column row of filter_overlap_slr2.py:142-151 (with the trailing TAB); returns
 // false when the row is dropped by the identity test `float(score2) < iden` (slr2:146).
