@@ -296,6 +296,7 @@ __global__ void pair_order_select_kernel(const PafRec *recs, uint32_t *grows /* 
 // ---------------------------------------------------------------------------------------
 // One wavefront per row: the CIGAR is read 64 ops at a time (coalesced), the positions before each op come from
 // wave prefix sums, every 'X' lane writes its own events.
+constexpr uint32_t NO_PAIR = 0xffffffffu;
 __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(WG) void snp_count_kernel(const PafRec *recs, const
 __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
                                                        const uint8_t *sel, size_t n, int long_mode, const uint32_t *ev_off,
                                                        const uint32_t *iv_off, const uint32_t *pseg_start, size_t n_pseg,
-                                                       int hb, int lb, uint64_t *ev_ck, uint32_t *ev_pair,
+                                                       const uint8_t *pair_live, int hb, int lb, uint64_t *ev_ck, uint32_t *ev_pair,
                                                        uint64_t *iv_sck, uint64_t *iv_eck) {
     // sort word of (chunk, read, position): chunk | read (hb bits) | position (lb bits) - numeric order = the
     // lexicographic order of the triple
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
             size_t lo = 0, hi = n_pseg;
             while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (pseg_start[mid] <= i) lo = mid + 1; else hi = mid; }
             pg = (uint32_t)(lo - 1);
+            if (!pair_live[pg]) pg = NO_PAIR;                      // nobody will read this pair's counter
         }
         const bool rev = r.flags & PF_REV;
         uint32_t p1 = rev ? r.qlen - r.qe : r.qs;   // slr2:334   (positions after the ops handled so far)
@@ -433,12 +435,31 @@ __global__ void snp_support_kernel(const uint64_t *ev_ck, const uint32_t *kseg_s
 __global__ void snp_pair_count_kernel(const uint32_t *ev_pair_sorted, const uint8_t *ev_supported, size_t n_ev,
                                       uint32_t *pair_mut) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n_ev && ev_supported[i]) atomicAdd(&pair_mut[ev_pair_sorted[i]], 1u);
+    if (i < n_ev && ev_supported[i]) {
+        const uint32_t pg = ev_pair_sorted[i];
+        if (pg != NO_PAIR) atomicAdd(&pair_mut[pg], 1u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 // a7: pass 2
 // ---------------------------------------------------------------------------------------
+// Pair groups whose supported-mutation count pass 2 can ever look at: some row passes the tests that do not depend on
+// the count (slr2:102-131).  With len_over near the read length that is a few per cent of the pairs; the events of the
+// others still take part in the support counting, but nobody reads their pair's counter.
+__global__ void pair_live_kernel(const PafRec *recs, const uint32_t *grows, const uint32_t *seg_start, size_t n_seg,
+                                 size_t n_rows, int len_over, int min_o, uint8_t *live) {
+    size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    size_t b = seg_start[s], e = (s + 1 < n_seg) ? seg_start[s + 1] : n_rows;
+    bool any = false;
+    for (size_t i = b; i < e && !any; ++i) {
+        const PafRec &r = recs[grows[i]];
+        any = r.qid != r.tid && (int64_t)r.nmatch >= (int64_t)len_over && !is_internal(r, min_o);
+    }
+    live[s] = any ? 1 : 0;
+}
+
 __global__ void pass2_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
                              const uint32_t *seg_start, size_t n_seg, size_t n_rows, const uint32_t *pair_mut,
                              int long_mode, int len_over, double thre, int min_o, uint8_t *keep, uint32_t *xdig) {
@@ -615,8 +636,11 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
         DBuf<uint32_t> ev_pair(E);
         DBuf<uint64_t> ev_ck(E), iv_sck(I ? I : 1), iv_eck(I ? I : 1);
     { KTimer kt("filter_event_fill");
+        DBuf<uint8_t> pair_live(n_pseg);
+        hipLaunchKernelGGL(pair_live_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, grows.p, pseg_start.p, n_pseg, m,
+                           cfg.len_over, cfg.min_o, pair_live.p);
         hipLaunchKernelGGL(snp_fill_kernel, rows_grid, dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm,
-                           ev_off.p, iv_off.p, pseg_start.p, n_pseg, hb, lb, ev_ck.p, ev_pair.p, iv_sck.p, iv_eck.p);
+                           ev_off.p, iv_off.p, pseg_start.p, n_pseg, pair_live.p, hb, lb, ev_ck.p, ev_pair.p, iv_sck.p, iv_eck.p);
     }
     { KTimer kt("filter_event_sort");
         sort_pairs_u64_u32(ev_ck, ev_pair, E, 0, cb + hb + lb);      // the pair group rides along: no gather afterwards
