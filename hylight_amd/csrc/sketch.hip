@@ -88,20 +88,29 @@ __device__ __forceinline__ uint64_t hash64(uint64_t key, uint64_t mask) {   // L
     return key;
 }
 
-__global__ void kmer_kernel(const uint8_t *codes, const uint64_t *off, const uint32_t *slot_pos,
-                            const uint32_t *slot_rid, const uint32_t *rslot0, size_t ns, int k, int w, int hpc,
-                            uint64_t *sx, uint32_t *spz, uint8_t *sl) {
-    size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+// The symbols of the workgroup's slots and of the w + k - 2 before them sit in LDS (one gather per slot instead of up
+// to w + k - 1 dependent pairs of reads per slot).
+__global__ __launch_bounds__(WG) void kmer_kernel(const uint8_t *codes, const uint64_t *off, const uint32_t *slot_pos,
+                                                   const uint32_t *slot_rid, const uint32_t *rslot0, size_t ns, int k, int w, int hpc,
+                                                   uint64_t *sx, uint32_t *spz, uint8_t *sl) {
+    __shared__ uint8_t s_c[WG + 96];            // w + k - 1 <= 91
+    const int need = w + k - 1;
+    const size_t j0 = blockIdx.x * (size_t)WG;
+    for (int i = threadIdx.x; i < WG + need - 1; i += WG) {
+        const long long si = (long long)j0 - (need - 1) + i;
+        s_c[i] = si >= 0 && (size_t)si < ns ? codes[slot_pos[si]] : (uint8_t)4;
+    }
+    __syncthreads();
+    size_t s = j0 + threadIdx.x;
     if (s >= ns) return;
     const uint32_t r = slot_rid[s];
     const size_t s0 = rslot0[r];
-    const int need = w + k - 1;
     int l = 0;                                  // consecutive symbol slots ending at s, capped at w+k-1
     uint64_t fwd = 0, rev = 0;
     const uint64_t mask = (1ULL << 2 * k) - 1;
     const int shift = 2 * (k - 1);
     while (l < need && s >= s0 + (size_t)l) {
-        uint8_t c = codes[slot_pos[s - l]];
+        uint8_t c = s_c[threadIdx.x + need - 1 - l];
         if (c > 3) break;
         if (l < k) {                            // symbol at distance l from the k-mer's last symbol
             fwd |= (uint64_t)c << (2 * l);
@@ -127,19 +136,38 @@ __global__ void kmer_kernel(const uint8_t *codes, const uint64_t *off, const uin
     sl[s] = (uint8_t)l;
 }
 
-__global__ void pick_kernel(const uint64_t *sx, const uint8_t *sl, const uint32_t *slot_rid, const uint32_t *rslot0,
-                            size_t ns, int k, int w, uint8_t *pick) {
-    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+// A slot is picked when its key is the minimum of some fully valid window of w slots that contains it.  One tile of
+// keys per workgroup in LDS (WG slots + w - 1 on both sides): the window minima once per window end, then every slot
+// looks at the w windows it belongs to - 2 w LDS reads per slot instead of w * w reads of global memory.
+__global__ __launch_bounds__(WG) void pick_kernel(const uint64_t *sx, const uint8_t *sl, const uint32_t *slot_rid,
+                                                   const uint32_t *rslot0, size_t ns, int k, int w, uint8_t *pick) {
+    __shared__ uint64_t s_x[WG + 128];            // keys of slots j0 - (w-1) .. j0 + WG + w - 2   (w <= 64)
+    __shared__ uint64_t s_wm[WG + 64];            // window minima of the windows ending at j0 .. j0 + WG + w - 2
+    const size_t j0 = blockIdx.x * (size_t)WG;
+    const long long lo = (long long)j0 - (w - 1);
+    for (int i = threadIdx.x; i < WG + 2 * (w - 1); i += WG) {
+        const long long s = lo + i;
+        s_x[i] = s >= 0 && (size_t)s < ns ? sx[s] : ~0ull;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < WG + w - 1; i += WG) {            // window ending at slot j0 + i = tile index i + w - 1
+        const size_t s = j0 + (size_t)i;
+        uint64_t mn = ~0ull;
+        if (s < ns && (int)sl[s] >= w + k - 1)                      // window [s-w+1, s] fully valid
+            for (int t = 0; t < w; ++t) { const uint64_t v = s_x[i + w - 1 - t]; mn = v < mn ? v : mn; }
+        else mn = 0;                                                // (never equals a live key: see below)
+        s_wm[i] = mn;
+    }
+    __syncthreads();
+    const size_t j = j0 + threadIdx.x;
     if (j >= ns) return;
-    const uint64_t xj = sx[j];
+    const uint64_t xj = s_x[threadIdx.x + w - 1];
     bool sel = false;
     if (xj != ~0ull) {
         const size_t send = rslot0[slot_rid[j] + 1];   // one past the read's last slot
-        for (size_t s = j; s < j + (size_t)w && s < send && !sel; ++s) {
-            if ((int)sl[s] < w + k - 1) continue;      // window [s-w+1, s] not fully valid
-            uint64_t mn = ~0ull;
-            for (int t = 0; t < w; ++t) { uint64_t v = sx[s - t]; mn = v < mn ? v : mn; }
-            sel = (mn == xj);
+        for (int d = 0; d < w && j + (size_t)d < send && !sel; ++d) {
+            const uint64_t m = s_wm[threadIdx.x + d];
+            sel = m == xj && (int)sl[j + (size_t)d] >= w + k - 1;
         }
     }
     pick[j] = sel ? 1 : 0;
