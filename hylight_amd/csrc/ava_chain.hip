@@ -916,7 +916,14 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     ca.sbase = sbase.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
-    if (const char *e = getenv("HLMI_CHAIN_STOP")) ca.stop_after = atoi(e);
+    if (const char *e = getenv("HLMI_CHAIN_STOP")) {
+        ca.stop_after = atoi(e);
+        static bool warned = false;
+        if (ca.stop_after && !warned) {
+            fprintf(stderr, "hylight-mi: HLMI_CHAIN_STOP=%d is a timing aid - the overlaps of this run are incomplete\n", ca.stop_after);
+            warned = true;
+        }
+    }
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
     ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);
     ca.cap_fps = (uint32_t)(2 * A + 1024);
