@@ -54,54 +54,62 @@ __global__ void piece_task_count_kernel(const Piece *pieces, size_t n, uint32_t 
     if (i < n) cnt[i] = pieces[i].n_fp + 1;      // (n_fp - 1) blocks + 2 extensions
 }
 
+// Where the task records come from: geometry of the pieces (fixed points, read lengths and offsets)
+struct TaskGeom {
+    const Piece *pieces;
+    const FixPt *fps;
+    const uint32_t *task_off;      // first task of every piece
+    const uint32_t *qlen, *tlen;
+    const uint64_t *qoff, *toff;
+};
 // Window element x of a task: query = qcodes[qa + x] (complemented and read downwards, qcodes[qa - x], when exactly one
 // of "left extension" and "reverse strand" holds; complemented whenever the strand is reverse); target =
 // tcodes[ta + x], downwards for a left extension.
-__global__ __launch_bounds__(WG) void make_tasks_kernel(const Piece *pieces, const FixPt *fps, const uint32_t *task_off, size_t n,
-                                                         const uint32_t *qlen, const uint32_t *tlen, const uint64_t *qoff,
-                                                         const uint64_t *toff, Task *tasks) {
-    // one wave per piece, one lane per task: fixed points in, 32-byte records out, both contiguous per wave
+__device__ __forceinline__ Task build_task(const TaskGeom &g, uint32_t i, uint32_t k) {
+    const Piece p = g.pieces[i];
+    const FixPt *fp = g.fps + p.fp_off;
+    const int ql = (int)g.qlen[p.q], tl = (int)g.tlen[p.t];
+    const uint64_t qo = g.qoff[p.q], to = g.toff[p.t];
+    const uint16_t rev = p.strand ? TASK_REV : 0;
+    // aligned query position pos -> offset in qcodes
+    auto qaddr = [&](int pos) { return p.strand ? qo + (uint64_t)(ql - 1 - pos) : qo + (uint64_t)pos; };
+    if (k == 0) {                       // left extension: elements run downwards from the fixed point
+        const int qs = (int)fp[0].q, ts = (int)fp[0].t;
+        return Task{i, (uint16_t)(1u | rev), (uint16_t)(qs <= EXT_MAX ? (qs + 1) << 1 : 0), qaddr(qs - 1),
+                    to + (uint64_t)(ts - 1), (int16_t)(qs < EXT_MAX ? qs : EXT_MAX), (int16_t)(ts < SEQ_T_MAX ? ts : SEQ_T_MAX),
+                    (int16_t)(-(BAND_W / 2 - 1)), 0};
+    }
+    if (k == p.n_fp) {                  // right extension
+        const int qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
+        const int m = ql - qe < EXT_MAX ? ql - qe : EXT_MAX, n2 = tl - te < SEQ_T_MAX ? tl - te : SEQ_T_MAX;
+        return Task{i, (uint16_t)(2u | rev), (uint16_t)(ql - qe <= EXT_MAX ? (ql - qe + 1) << 1 : 0), qaddr(qe),
+                    to + (uint64_t)te, (int16_t)m, (int16_t)n2, (int16_t)(-(BAND_W / 2 - 1)), 0};
+    }
+    const uint32_t b = k - 1;           // block between fixed points k-1 and k
+    const int q0 = (int)fp[b].q, t0 = (int)fp[b].t, m = (int)fp[b + 1].q - q0, n2 = (int)fp[b + 1].t - t0;
+    const int delta = n2 - m;
+    // band rule: near-diagonal blocks use the 16-diagonal band
+    const bool narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
+    return Task{i, rev, (uint16_t)(narrow ? 1 : 0), qaddr(q0), to + (uint64_t)t0, (int16_t)m, (int16_t)n2,
+                (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD)), 0};
+}
+// piece of every task (one wave per piece): the classifier builds its task from the piece, only the tasks that need a
+// DP get a 32-byte record
+__global__ __launch_bounds__(WG) void task_piece_kernel(const Piece *pieces, const uint32_t *task_off, size_t n, uint32_t *task_piece) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t i = wave; i < n; i += n_waves) {
-        const Piece p = pieces[i];
-        Task *out = tasks + task_off[i];
-        const FixPt *fp = fps + p.fp_off;
-        const int ql = (int)qlen[p.q], tl = (int)tlen[p.t];
-        const uint64_t qo = qoff[p.q], to = toff[p.t];
-        const uint16_t rev = p.strand ? TASK_REV : 0;
-        // aligned query position pos -> offset in qcodes
-        auto qaddr = [&](int pos) { return p.strand ? qo + (uint64_t)(ql - 1 - pos) : qo + (uint64_t)pos; };
-        const uint32_t n_tasks = p.n_fp + 1;
-        for (uint32_t k = (uint32_t)lane; k < n_tasks; k += 64) {
-            Task t;
-            if (k == 0) {                       // left extension: elements run downwards from the fixed point
-                const int qs = (int)fp[0].q, ts = (int)fp[0].t;
-                t = Task{(uint32_t)i, (uint16_t)(1u | rev), (uint16_t)(qs <= EXT_MAX ? (qs + 1) << 1 : 0), qaddr(qs - 1),
-                         to + (uint64_t)(ts - 1), (int16_t)(qs < EXT_MAX ? qs : EXT_MAX), (int16_t)(ts < SEQ_T_MAX ? ts : SEQ_T_MAX),
-                         (int16_t)(-(BAND_W / 2 - 1)), 0};
-            } else if (k == p.n_fp) {           // right extension
-                const int qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
-                const int m = ql - qe < EXT_MAX ? ql - qe : EXT_MAX, n2 = tl - te < SEQ_T_MAX ? tl - te : SEQ_T_MAX;
-                t = Task{(uint32_t)i, (uint16_t)(2u | rev), (uint16_t)(ql - qe <= EXT_MAX ? (ql - qe + 1) << 1 : 0), qaddr(qe),
-                         to + (uint64_t)te, (int16_t)m, (int16_t)n2, (int16_t)(-(BAND_W / 2 - 1)), 0};
-            } else {                            // block between fixed points k-1 and k
-                const uint32_t b = k - 1;
-                const int q0 = (int)fp[b].q, t0 = (int)fp[b].t, m = (int)fp[b + 1].q - q0, n2 = (int)fp[b + 1].t - t0;
-                const int delta = n2 - m;
-                // band rule: near-diagonal blocks use the 16-diagonal band
-                const bool narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
-                t = Task{(uint32_t)i, rev, (uint16_t)(narrow ? 1 : 0), qaddr(q0), to + (uint64_t)t0, (int16_t)m, (int16_t)n2,
-                         (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD)), 0};
-            }
-            out[k] = t;
-        }
+        const uint32_t n_tasks = pieces[i].n_fp + 1;
+        uint32_t *out = task_piece + task_off[i];
+        for (uint32_t k = (uint32_t)lane; k < n_tasks; k += 64) out[k] = (uint32_t)i;
     }
 }
 
 struct AlignArgs {
-    const Task *tasks;
+    Task *tasks;            // records of the tasks that need a DP (written by the classifier, read by the DP kernels)
+    TaskGeom geom;
+    const uint32_t *task_piece;
     size_t n_tasks;
     const uint32_t *list;   // task ids this launch works on (n_list of them)
     size_t n_list;
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         bool live = u < n_units;
         const size_t ti = PASS == 1 || !live ? u : (size_t)a.defer_list[u];
         Task tk{};
-        if (live) tk = a.tasks[ti];
+        if (live) { const uint32_t pc = a.task_piece[ti]; tk = build_task(a.geom, pc, (uint32_t)ti - a.geom.task_off[pc]); }
         const int m = tk.m, n = tk.n;
         uint8_t c = 2;
         bool try_fast = false;
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         }
         if (live) {
             cls[ti] = c;
+            if (c != 0) a.tasks[ti] = tk;                      // a DP kernel will want the record
             if (m > 0 && n > 0) {
                 const uint32_t bases = (uint32_t)(m + n);
                 st[ST_BASES] += bases;
@@ -1162,9 +1171,9 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     exclusive_scan_u32(tcnt.p, toff.p, P);
     const size_t NT = ch.n_fp + P;              // a piece of n fixed points has n - 1 blocks and two extensions
     DBuf<Task> tasks(NT);
-    hipLaunchKernelGGL(make_tasks_kernel, dim3((unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
-                       ch.pieces.p, ch.fps.p, toff.p, P, d_qlen, d_tlen,
-                       in.Q->off.p, in.T->off.p, tasks.p);
+    DBuf<uint32_t> task_piece(NT);
+    hipLaunchKernelGGL(task_piece_kernel, dim3((unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
+                       ch.pieces.p, toff.p, P, task_piece.p);
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
     DBuf<uint32_t> counters(2);
@@ -1183,6 +1192,8 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         counters.zero();
         AlignArgs aa{};
         aa.tasks = tasks.p; aa.n_tasks = NT;
+        aa.task_piece = task_piece.p;
+        aa.geom = TaskGeom{ch.pieces.p, ch.fps.p, toff.p, d_qlen, d_tlen, in.Q->off.p, in.T->off.p};
         aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p;
         aa.q_total = (long long)in.Q->total; aa.t_total = (long long)in.T->total;
         aa.end_bonus = o.end_bonus;
