@@ -10,8 +10,14 @@ def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     m = re.search(r"(radix_sort_onesweep_\w+|partition_impl|scan_impl|lookback_scan_\w+|__amd_rocclr_\w+)", name)
     if "rocprim" in name and m:
-        kv = re.search(r"wrapped_radix_sort_onesweep_config<[^,]+, ([^,]+), ([^>]+)>", name)
-        return "rocprim::" + m.group(1) + (f"<{kv.group(1)},{kv.group(2)}>" if kv else "")
+        name = re.sub(r"rocprim::ROCPRIM_\d+_NS::", "", name)
+        # key / value types, and the block shape when the sort was given one (dev_prims.hip)
+        kv = re.search(r"wrapped_radix_sort_onesweep_config<(?:default_config|radix_sort_onesweep_config<.*?\)\d+>), ([^,]+), ([^>]+)>", name)
+        shape = re.search(r"radix_sort_onesweep_config<kernel_config<(\d+)u, (\d+)u, \d+u>, kernel_config<(\d+)u, (\d+)u, \d+u>", name)
+        tag = f"<{kv.group(1)},{kv.group(2)}>" if kv else ""
+        if shape:
+            tag += f"[hist {shape.group(1)}x{shape.group(2)}, sort {shape.group(3)}x{shape.group(4)}]"
+        return "rocprim::" + m.group(1) + tag
     name = re.sub(r"^void ", "", name)
     return name.split("(")[0][:70]
 
