@@ -128,6 +128,23 @@ def test_ava_narrow_band_kernel_forms(tmp_path, monkeypatch):
     assert open(tmp_path / "un.paf").read() == want
 
 
+@pytest.mark.parametrize("seed,errs", [(71, (0.06, 0.03, 0.03)), (72, (0.10, 0.02, 0.02)), (73, (0.02, 0.06, 0.06))])
+def test_ava_noisy_reads(tmp_path, seed, errs):
+    """Raw-read error rates: most blocks need a DP, many of them in the 64-diagonal band or in the long near-diagonal
+    instance, with tens of runs per task (both packed and 32-bit kernels, the second traceback walk, the run pool)."""
+    sub, ins, dele = errs
+    reads = _sim(seed, 36, n_strains=2, genome_len=12000, mean_len=4000, min_len=1500, max_len=8000,
+                 err_sub=sub, err_ins=ins, err_del=dele)
+    fa = _write(tmp_path, "r.fa", reads)
+    api.ava(fa, fa, tmp_path / "g.paf")
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    want = open(tmp_path / "o.paf").read()
+    assert len(want.splitlines()) > 20
+    assert open(tmp_path / "g.paf").read() == want
+    st = api.last_stats()
+    assert st["align_tasks_dp"] > 0.3 * st["align_tasks"]
+
+
 def test_ava_traceback_run_buffer_overflow(tmp_path, monkeypatch):
     """The traceback keeps a task's runs in LDS and walks once; a task with more runs than the buffer holds is
     walked a second time straight into the pool.  HLMI_RUN_BUF_CAP=3 sends nearly every DP task down that path."""
