@@ -48,6 +48,23 @@ def test_short_reads_vs_contigs_matches_oracle(tmp_path):
     assert got == want
 
 
+def test_short_noisy_reads_vs_contigs_matches_oracle(tmp_path):
+    """2 % / 1 % / 1 % read errors: the end bonus now decides between clipped and full-length alignments, extensions
+    rarely match exactly (third certificate with the bonus row in play) and go through the 64-diagonal DP."""
+    reads, strains = S.simulate_reads(seed=94, n_strains=2, genome_len=20000, n_reads=900, mean_len=250, min_len=180,
+                                      max_len=300, err_sub=0.02, err_ins=0.01, err_del=0.01, name_prefix="s")
+    g = strains[0]
+    contigs = [S.Read(f"longr_con_{i}", g[a:b].copy(), None, 0, a, b, False) for i, (a, b) in enumerate([(0, 9000), (9000, 20000)])]
+    q, t = tmp_path / "short.fa", tmp_path / "con.fa"
+    S.write_fasta(reads, q)
+    S.write_fasta(contigs, t)
+    api.ava(t, q, tmp_path / "g.paf", api.ava_opts_short())
+    OA.ava(t, q, tmp_path / "o.paf", OA.opts_short())
+    got, want = open(tmp_path / "g.paf").read(), open(tmp_path / "o.paf").read()
+    assert len(want.splitlines()) > 0.5 * len(reads)
+    assert got == want
+
+
 def test_short_vs_short_reports_both_directions(tmp_path):
     reads, _ = _short_reads_and_contigs(92, n_reads=400, genome_len=4000)
     fa = tmp_path / "s.fa"
