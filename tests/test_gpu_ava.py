@@ -145,6 +145,27 @@ def test_ava_noisy_reads(tmp_path, seed, errs):
     assert st["align_tasks_dp"] > 0.3 * st["align_tasks"]
 
 
+@pytest.mark.parametrize("changes", [
+    dict(mismatch=16, gap_open=20, gap_ext=2),           # scores too large for the 16-bit kernel: the 32-bit form by itself
+    dict(match=1, mismatch=1, gap_open=1, gap_ext=1),     # many ties: the traceback's tie rules decide every block
+    dict(k=15, w=8, bandwidth=300, max_gap=2000, min_chain_score=40),     # other seeds, byte-table gap costs
+    dict(bandwidth=3000),                                 # gap-cost table too small: costs computed in the chain DP
+])
+def test_ava_other_constants(tmp_path, changes):
+    """Constants other than the two presets go through the same kernels (or their fallback forms)."""
+    reads = _sim(37, 40, n_strains=2, genome_len=12000, err_sub=0.02, err_ins=0.01, err_del=0.01)
+    fa = _write(tmp_path, "r.fa", reads)
+    go, oo = api.ava_opts_long(), OA.opts_long()
+    for k, v in changes.items():
+        setattr(go, k, v)
+        setattr(oo, k, v)
+    api.ava(fa, fa, tmp_path / "g.paf", go)
+    OA.ava(fa, fa, tmp_path / "o.paf", oo)
+    want = open(tmp_path / "o.paf").read()
+    assert len(want.splitlines()) > 20
+    assert open(tmp_path / "g.paf").read() == want
+
+
 def test_ava_traceback_run_buffer_overflow(tmp_path, monkeypatch):
     """The traceback keeps a task's runs in LDS and walks once; a task with more runs than the buffer holds is
     walked a second time straight into the pool.  HLMI_RUN_BUF_CAP=3 sends nearly every DP task down that path."""
