@@ -64,6 +64,35 @@ def test_miniasm_against_compiled_reference(tmp_path, seed, n_reads, genome, fak
         assert open(out).read() == want and want.count("\nS\t") + want.startswith("S\t") >= 1
 
 
+def test_miniasm_reads_in_fastq_with_awkward_lines(golden, tmp_path):
+    """The unitig sequences come from a scan of the read file that copies only the reads on unitigs; the scan follows
+    kseq's record rules: wrapped sequence lines, CRLF, and FASTQ quality lines that begin with '@' or '>' must not be
+    taken for headers.  Same reads as fixture A in such a file -> the same GFA."""
+    fa = _plain(golden, "fxA_reads.fa", tmp_path)
+    recs = []
+    name = None
+    for line in open(fa):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            name = line[1:]
+        else:
+            recs.append((name, line))
+    fq = tmp_path / "reads.fq"
+    with open(fq, "w", newline="") as f:
+        for i, (n, seq) in enumerate(recs):
+            qual = ("@" if i % 3 == 0 else ">" if i % 3 == 1 else "I") + "I" * (len(seq) - 1)
+            if i % 2:                                  # wrapped sequence and quality, CRLF
+                w = 61
+                sl = "\r\n".join(seq[k:k + w] for k in range(0, len(seq), w))
+                ql = "\r\n".join(qual[k:k + w] for k in range(0, len(qual), w))
+                f.write(f"@{n} some comment\r\n{sl}\r\n+\r\n{ql}\r\n")
+            else:
+                f.write(f"@{n}\n{seq}\n+{n}\n{qual}\n")
+    out = tmp_path / "o.gfa"
+    api.miniasm(golden.path("fxA_stage_nsplit4.paf"), fq, out, bub_dist=10000, max_ext=1, outfmt="ug", **FLAGS["n1c1"])
+    assert open(out).read() == golden.text("fxA_miniasm_n1c1.gfa")
+
+
 def test_miniasm_empty_paf_gives_empty_gfa(tmp_path):
     p = tmp_path / "e.paf"
     p.write_text("")
