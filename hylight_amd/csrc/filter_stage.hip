@@ -338,8 +338,8 @@ __global__ __launch_bounds__(WG) void snp_count_kernel(const PafRec *recs, const
 
 __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
                                                        const uint8_t *sel, size_t n, int long_mode, const uint32_t *ev_off,
-                                                       const uint32_t *iv_off, const uint32_t *pseg_start, size_t n_pseg,
-                                                       const uint8_t *pair_live, int hb, int lb, uint64_t *ev_ck, uint32_t *ev_pair,
+                                                       const uint32_t *iv_off, const uint32_t *row_pair, int hb, int lb,
+                                                       uint64_t *ev_ck, uint32_t *ev_pair,
                                                        uint64_t *iv_sck, uint64_t *iv_eck) {
     // sort word of (chunk, read, position): chunk | read (hb bits) | position (lb bits) - numeric order = the
     // lexicographic order of the triple
@@ -355,15 +355,9 @@ __global__ __launch_bounds__(WG) void snp_fill_kernel(const PafRec *recs, const 
             if (r.ts < r.te) { iv_sck[w] = ck(r.chunk, r.tid, r.ts); iv_eck[w] = ck(r.chunk, r.tid, r.te); ++w; }
             if (long_mode && r.qs < r.qe) { iv_sck[w] = ck(r.chunk, r.qid, r.qs); iv_eck[w] = ck(r.chunk, r.qid, r.qe); }
         }
-        // the pair group of this row = the pair every event of the row counts for (read and partner are the row's
-        // two names): last group start <= i
-        uint32_t pg;
-        {
-            size_t lo = 0, hi = n_pseg;
-            while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (pseg_start[mid] <= i) lo = mid + 1; else hi = mid; }
-            pg = (uint32_t)(lo - 1);
-            if (!pair_live[pg]) pg = NO_PAIR;                      // nobody will read this pair's counter
-        }
+        // the pair group of this row = the pair every event of the row counts for (read and partner are the row's two
+        // names); NO_PAIR when nobody will read that pair's counter
+        const uint32_t pg = row_pair[i];
         const bool rev = r.flags & PF_REV;
         uint32_t p1 = rev ? r.qlen - r.qe : r.qs;   // slr2:334   (positions after the ops handled so far)
         uint32_t p2 = r.ts;                         // slr2:336
@@ -447,8 +441,10 @@ __global__ void snp_pair_count_kernel(const uint32_t *ev_pair_sorted, const uint
 // Pair groups whose supported-mutation count pass 2 can ever look at: some row passes the tests that do not depend on
 // the count (slr2:102-131).  With len_over near the read length that is a few per cent of the pairs; the events of the
 // others still take part in the support counting, but nobody reads their pair's counter.
+// row_pair[i] = the pair group of row i, or NO_PAIR for the rows of a group nobody will look at (the event kernel
+// reads it instead of searching the group starts)
 __global__ void pair_live_kernel(const PafRec *recs, const uint32_t *grows, const uint32_t *seg_start, size_t n_seg,
-                                 size_t n_rows, int len_over, int min_o, uint8_t *live) {
+                                 size_t n_rows, int len_over, int min_o, uint32_t *row_pair) {
     size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     size_t b = seg_start[s], e = (s + 1 < n_seg) ? seg_start[s + 1] : n_rows;
@@ -457,7 +453,7 @@ __global__ void pair_live_kernel(const PafRec *recs, const uint32_t *grows, cons
         const PafRec &r = recs[grows[i]];
         any = r.qid != r.tid && (int64_t)r.nmatch >= (int64_t)len_over && !is_internal(r, min_o);
     }
-    live[s] = any ? 1 : 0;
+    for (size_t i = b; i < e; ++i) row_pair[i] = any ? (uint32_t)s : 0xffffffffu;
 }
 
 __global__ void pass2_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
@@ -636,11 +632,11 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
         DBuf<uint32_t> ev_pair(E);
         DBuf<uint64_t> ev_ck(E), iv_sck(I ? I : 1), iv_eck(I ? I : 1);
     { KTimer kt("filter_event_fill");
-        DBuf<uint8_t> pair_live(n_pseg);
+        DBuf<uint32_t> row_pair(m);
         hipLaunchKernelGGL(pair_live_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, grows.p, pseg_start.p, n_pseg, m,
-                           cfg.len_over, cfg.min_o, pair_live.p);
+                           cfg.len_over, cfg.min_o, row_pair.p);
         hipLaunchKernelGGL(snp_fill_kernel, rows_grid, dim3(WG), 0, stream(), d_recs, d_ops, grows.p, sel.p, m, lm,
-                           ev_off.p, iv_off.p, pseg_start.p, n_pseg, pair_live.p, hb, lb, ev_ck.p, ev_pair.p, iv_sck.p, iv_eck.p);
+                           ev_off.p, iv_off.p, row_pair.p, hb, lb, ev_ck.p, ev_pair.p, iv_sck.p, iv_eck.p);
     }
     { KTimer kt("filter_event_sort");
         sort_pairs_u64_u32(ev_ck, ev_pair, E, 0, cb + hb + lb);      // the pair group rides along: no gather afterwards
