@@ -72,14 +72,25 @@ __global__ void index_occ_kernel(const uint32_t *run_start, size_t n_runs, size_
     size_t end = r + 1 < n_runs ? run_start[r + 1] : n;
     occ[e] = (uint32_t)(end - run_start[r]);
 }
-__global__ void index_hist_kernel(const uint32_t *run_start, size_t n_runs, size_t n, const uint64_t *y,
-                                  const uint32_t *chunk_of_t, uint32_t *hist) {
+// Most runs are one to a few entries long: those counts meet in a small LDS table per workgroup first (a few hundred
+// hot global counters took the whole kernel otherwise); chunks beyond the table and longer runs go straight to memory.
+constexpr int HIST_LDS_CHUNKS = 256, HIST_LDS_LEN = 8;
+__global__ __launch_bounds__(WG) void index_hist_kernel(const uint32_t *run_start, size_t n_runs, size_t n, const uint64_t *y,
+                                                         const uint32_t *chunk_of_t, uint32_t *hist) {
+    __shared__ uint32_t s_h[HIST_LDS_CHUNKS * HIST_LDS_LEN];
+    for (int i = threadIdx.x; i < HIST_LDS_CHUNKS * HIST_LDS_LEN; i += WG) s_h[i] = 0;
+    __syncthreads();
     size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (r >= n_runs) return;
-    size_t end = r + 1 < n_runs ? run_start[r + 1] : n;
-    uint32_t len = (uint32_t)(end - run_start[r]);
-    uint32_t c = chunk_of_t[y[run_start[r]] >> 32];
-    atomicAdd(&hist[(size_t)c * HB + (len < (uint32_t)HB - 1 ? len : (uint32_t)HB - 1)], 1u);
+    if (r < n_runs) {
+        size_t end = r + 1 < n_runs ? run_start[r + 1] : n;
+        uint32_t len = (uint32_t)(end - run_start[r]);
+        uint32_t c = chunk_of_t[y[run_start[r]] >> 32];
+        if (c < (uint32_t)HIST_LDS_CHUNKS && len < (uint32_t)HIST_LDS_LEN) atomicAdd(&s_h[c * HIST_LDS_LEN + len], 1u);
+        else atomicAdd(&hist[(size_t)c * HB + (len < (uint32_t)HB - 1 ? len : (uint32_t)HB - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_LDS_CHUNKS * HIST_LDS_LEN; i += WG)
+        if (s_h[i]) atomicAdd(&hist[(size_t)(i / HIST_LDS_LEN) * HB + (size_t)(i % HIST_LDS_LEN)], s_h[i]);
 }
 
 __global__ void index_rank_kernel(const uint64_t *y, const uint32_t *occ, const uint32_t *mid_occ, const uint32_t *chunk_of_t,
