@@ -3,8 +3,6 @@
 
 #include "common.h"
 
-#include <malloc.h>
-
 namespace hlmi {
 
 namespace {
@@ -35,14 +33,6 @@ void init_device(int device, int threads) {
         fail(HLMI_ENODEV, "no HIP device available (%s); libhylight_mi has no CPU fallback",
              e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     if (device >= n) fail(HLMI_EINVAL, "device %d out of range (have %d)", device, n);
-    // Every stage pass fills and drops host vectors of tens of MB (row order keys, kept records, text): above glibc's
-    // default mmap threshold each of them is mapped, page-faulted in and unmapped again.  Keep them on the heap.
-    static bool heap_tuned = false;
-    if (!heap_tuned) {
-        mallopt(M_MMAP_THRESHOLD, 512 << 20);
-        mallopt(M_TRIM_THRESHOLD, 1 << 30);
-        heap_tuned = true;
-    }
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
     if (!g_stream) HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     if (threads > 0) g_threads = threads;
