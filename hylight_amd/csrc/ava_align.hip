@@ -1230,12 +1230,12 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         const std::vector<uint32_t> hn = list_n.download(4);
         const size_t n1 = hn[0], n2 = hn[1], n3 = hn[2], n4 = hn[3];
         for (int which = 0; which < 2; ++which) {
-            uint32_t *lst = which ? list3.p : list1.p;
+            DBuf<uint32_t> &lst = which ? list3 : list1;
             const size_t nl = which ? n3 : n1;
             if (nl < 8) continue;
             DBuf<uint32_t> key(nl);
-            hipLaunchKernelGGL(task_rows_key_kernel, grid1(nl), dim3(WG), 0, stream(), tasks.p, lst, nl, key.p);
-            sort_pairs_u32_u32(key.p, lst, nl, 0, 7);
+            hipLaunchKernelGGL(task_rows_key_kernel, grid1(nl), dim3(WG), 0, stream(), tasks.p, lst.p, nl, key.p);
+            sort_pairs_u32_u32(key, lst, nl, 0, 7);
         }
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
         // packed form (two tasks per lane, 16-bit scores): block scores must stay within +-4096 of the bias

@@ -16,6 +16,7 @@ void sort_keys_u64(uint64_t *keys, size_t n, int begin_bit = 0, int end_bit = 64
 template <typename T> struct DBuf;
 void sort_keys_u64(DBuf<uint64_t> &keys, size_t n, int begin_bit = 0, int end_bit = 64);
 void sort_pairs_u64_u32(DBuf<uint64_t> &keys, DBuf<uint32_t> &vals, size_t n, int begin_bit = 0, int end_bit = 64);
+void sort_pairs_u32_u32(DBuf<uint32_t> &keys, DBuf<uint32_t> &vals, size_t n, int begin_bit = 0, int end_bit = 32);
 
 // out[i] = sum_{j<i} in[j]; returns nothing, total = out[n-1] + in[n-1] (use scan_total)
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n);

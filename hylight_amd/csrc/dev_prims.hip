@@ -71,6 +71,17 @@ void sort_pairs_u64_u64(uint64_t *keys, uint64_t *vals, size_t n, int b0, int b1
     if (dv.current() != vals) HIP_CHECK(hipMemcpyAsync(vals, dv.current(), n * 8, hipMemcpyDeviceToDevice, stream()));
 }
 void sort_pairs_u32_u32(uint32_t *k, uint32_t *v, size_t n, int b0, int b1) { sort_pairs_impl(k, v, n, b0, b1); }
+void sort_pairs_u32_u32(DBuf<uint32_t> &keys, DBuf<uint32_t> &vals, size_t n, int b0, int b1) {
+    if (n < 2) return;
+    DBuf<uint32_t> k2(keys.n), v2(vals.n);
+    rocprim::double_buffer<uint32_t> dk(keys.p, k2.p), dv(vals.p, v2.p);
+    size_t tmp_bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+    HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    if (dk.current() != keys.p) std::swap(keys, k2);
+    if (dv.current() != vals.p) std::swap(vals, v2);
+}
 
 void sort_keys_u64(uint64_t *keys, size_t n, int b0, int b1) {
     if (n < 2) return;
