@@ -1,0 +1,56 @@
+"""GPU: size-independent properties on a high-divergence read set in the spirit of BASELINE.json configs[4] (8 strains,
+2 % SNPs, strain indels, 1 % / 0.5 % / 0.5 % read errors, stage thresholds 1500 / 0.90): two thirds of the alignment
+tasks need a DP, so this is where the packed and 32-bit DP kernels, the traceback walks and the CIGAR run pool carry
+the load.  A pass is deterministic, forcing the fallback forms of the kernels changes nothing, and sharding over 3
+ranks + merging reproduces the unsharded file byte for byte."""
+import os
+
+import pytest
+
+from hylight_amd import api
+from hylight_amd import simulate as S
+
+pytestmark = pytest.mark.gpu
+
+LEN_OVER, MC, IDEN = 1500, 2, 0.90
+
+
+@pytest.fixture(scope="module")
+def div(tmp_path_factory):
+    d = tmp_path_factory.mktemp("divergent")
+    reads, _ = S.simulate_reads(seed=20241009, n_strains=8, genome_len=60_000, n_reads=1_500, mean_len=10_000,
+                                min_len=1_000, max_len=40_000, snp_rate=0.02, strain_indel_rate=0.001,
+                                err_sub=0.01, err_ins=0.005, err_del=0.005)
+    fa = d / "s1.fa"
+    S.write_fasta(reads, fa)
+    out = d / "s1_s1.paf"
+    api.split_reads2(fa, fa, 30, d, out, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    return d, fa, out
+
+
+def test_divergent_pass_is_deterministic_and_shardable(div):
+    d, fa, out = div
+    ref = open(out).read()
+    again = d / "again.paf"
+    api.split_reads2(fa, fa, 30, d, again, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    st = api.last_stats()
+    assert st["align_tasks_dp"] > 0.4 * st["align_tasks"] and st["rows_after_v4"] > 20_000
+    assert ref.count("\n") > 20               # (the mutation filter of pass 2 leaves few pairs of this mix)
+    assert open(again).read() == ref
+    parts = []
+    for rank in range(3):
+        p = d / f"part{rank}.paf"
+        api.split_reads2(fa, fa, 30, d, p, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True, rank=rank, world=3)
+        parts.append(p)
+    merged = d / "merged.paf"
+    api.merge_scored_paf(parts, merged)
+    assert open(merged).read() == ref
+
+
+@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_NO_RANK_WORD"])
+def test_divergent_fallback_forms_agree(div, monkeypatch, var):
+    d, fa, out = div
+    monkeypatch.setenv(var, "1")
+    alt = d / f"alt_{var}.paf"
+    api.split_reads2(fa, fa, 30, d, alt, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    assert open(alt).read() == open(out).read()
