@@ -68,3 +68,14 @@ def test_full_size_rows_satisfy_pass2_and_order(c2):
         prev = s
         n += 1
     assert n > 40_000
+
+
+@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_NO_RANK_WORD"])
+def test_full_size_fallback_forms_agree(c2, monkeypatch, var):
+    """The forms of the kernels that unusual inputs take (32-bit DP, two-register chain state, key + value anchors,
+    two-array index search) give the same file at full size."""
+    d, fa, out = c2
+    monkeypatch.setenv(var, "1")
+    alt = d / f"alt_{var}.paf"
+    api.split_reads2(fa, fa, 100, d, alt, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    assert open(alt).read() == open(out).read()
