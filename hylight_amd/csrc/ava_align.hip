@@ -416,10 +416,6 @@ __global__ void task_rows_key_kernel(const Task *tasks, const uint32_t *list, si
     if (i < n) key[i] = (uint32_t)tasks[list[i]].m >> 2;
 }
 
-__global__ void split_class_kernel(const uint8_t *cls, size_t n, uint8_t *f1, uint8_t *f2, uint8_t *f3, uint8_t *f4) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) { f1[i] = cls[i] == 1; f2[i] = cls[i] == 2; f3[i] = cls[i] == 3; f4[i] = cls[i] == 4; }
-}
 
 // ---- pass 2a: DP of near-diagonal blocks, FOUR tasks per wave (one per row of 16 lanes) --------------------------
 // Same recurrences and tie rules as align_kernel with W = 16; every cross-lane step is a DPP row operation, so
@@ -1207,26 +1203,22 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.run_buf_cap = 0xffffffffu;
         if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
         // pass 1: classify every task, finish the diagonal fast path right away
-        DBuf<uint8_t> cls(NT), f1(NT), f2(NT), f3(NT), f4(NT);
+        DBuf<uint8_t> cls(NT), f1(NT);
         DBuf<uint32_t> list1(NT), list2(NT), list3(NT), list4(NT);
         DBuf<uint32_t> list_n(4);
         {
             KTimer kt("align_classify");
             const unsigned nbc = (unsigned)std::min<size_t>(cdiv(NT, (size_t)WG), MAX_BLOCKS);
             astats.zero();
-            aa.defer_flag = f1.p;                 // (f1 .. f4 are filled by split_class_kernel afterwards)
+            aa.defer_flag = f1.p;
             aa.defer_list = list1.p; aa.defer_count = list_n.p;
             hipLaunchKernelGGL(classify_kernel<1>, dim3(nbc ? nbc : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
             select_flagged_indices_async(f1.p, list1.p, NT, list_n.p);
             const unsigned nb2 = std::max(1u, nbc / 4);
             hipLaunchKernelGGL(classify_kernel<2>, dim3(nb2), dim3(WG), 0, stream(), aa, cls.p, astats.p);
         }
-        hipLaunchKernelGGL(split_class_kernel, grid1(NT), dim3(WG), 0, stream(), cls.p, NT, f1.p, f2.p, f3.p, f4.p);
         HIP_CHECK(hipGetLastError());
-        select_flagged_indices_async(f1.p, list1.p, NT, list_n.p);
-        select_flagged_indices_async(f2.p, list2.p, NT, list_n.p + 1);
-        select_flagged_indices_async(f3.p, list3.p, NT, list_n.p + 2);
-        select_flagged_indices_async(f4.p, list4.p, NT, list_n.p + 3);
+        select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);      // the four DP task lists
         const std::vector<uint32_t> hn = list_n.download(4);
         const size_t n1 = hn[0], n2 = hn[1], n3 = hn[2], n4 = hn[3];
         for (int which = 0; which < 2; ++which) {

@@ -26,6 +26,10 @@ void exclusive_scan_u32_to_u64(const uint32_t *in, uint64_t *out, size_t n);
 size_t select_flagged_indices(const uint8_t *flags, uint32_t *out_idx, size_t n);
 // same, the count goes to *d_count (device): several selections can then share one trip to the host
 void select_flagged_indices_async(const uint8_t *flags, uint32_t *out_idx, size_t n, uint32_t *d_count);
+// four selections in one go: out_idx[c - 1] receives the indices with cls[i] == c (c = 1..4, ascending), their counts go
+// to d_counts[0..3] (device)
+void select_classes4_async(const uint8_t *cls, size_t n, uint32_t *out1, uint32_t *out2, uint32_t *out3, uint32_t *out4,
+                           uint32_t *d_counts);
 // indices i where key[i] >> shift starts a new run (keys grouped): the group boundaries of a sorted / grouped array
 size_t select_run_heads_u64(const uint64_t *key, size_t n, int shift, uint32_t *out_idx);
 // number of significant bits of the maximum key value helper

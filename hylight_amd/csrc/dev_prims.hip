@@ -194,6 +194,51 @@ void select_flagged_indices_async(const uint8_t *flags, uint32_t *out_idx, size_
     HIP_CHECK(hipGetLastError());
 }
 
+// class c - 1 owns cnt / mask / off entries [(c - 1) nw, c nw): one scan serves the four selections
+__global__ __launch_bounds__(WG) void class_count_kernel(const uint8_t *cls, size_t n, size_t nw, uint32_t *cnt, unsigned long long *mask) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const uint8_t c = i < n ? cls[i] : 0;
+    const size_t w = i >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long m = __ballot(c == k + 1);
+        if ((threadIdx.x & 63) == 0 && w < nw) { cnt[(size_t)k * nw + w] = (uint32_t)__popcll(m); mask[(size_t)k * nw + w] = m; }
+    }
+}
+struct Out4 { uint32_t *p[4]; };
+__global__ __launch_bounds__(WG) void class_scatter_kernel(const uint8_t *cls, size_t n, size_t nw, const uint32_t *cnt,
+                                                            const unsigned long long *mask, const uint32_t *off, Out4 out,
+                                                            uint32_t *d_counts) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < 4) {                                          // the four totals
+        const size_t k = i;
+        const uint32_t end = k < 3 ? off[(k + 1) * nw] : off[4 * nw - 1] + cnt[4 * nw - 1];
+        d_counts[k] = end - off[k * nw];
+    }
+    if (i >= n) return;
+    const uint8_t c = cls[i];
+    if (c < 1 || c > 4) return;
+    const size_t k = (size_t)c - 1, w = i >> 6;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long m = mask[k * nw + w];
+    out.p[k][off[k * nw + w] - off[k * nw] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+}
+
+void select_classes4_async(const uint8_t *cls, size_t n, uint32_t *out1, uint32_t *out2, uint32_t *out3, uint32_t *out4,
+                           uint32_t *d_counts) {
+    if (!n) { HIP_CHECK(hipMemsetAsync(d_counts, 0, 16, stream())); return; }
+    if (n >= (1ull << 32)) fail(HLMI_EINVAL, "select_classes4: more than 2^32 elements");
+    const size_t nw = (n + 63) / 64;
+    DBuf<uint32_t> cnt(4 * nw), off(4 * nw);
+    DBuf<unsigned long long> mask(4 * nw);
+    const dim3 grid(cdiv(n, WG));
+    hipLaunchKernelGGL(class_count_kernel, grid, dim3(WG), 0, stream(), cls, n, nw, cnt.p, mask.p);
+    exclusive_scan_u32(cnt.p, off.p, 4 * nw);
+    hipLaunchKernelGGL(class_scatter_kernel, grid, dim3(WG), 0, stream(), cls, n, nw, cnt.p, mask.p, off.p,
+                       Out4{{out1, out2, out3, out4}}, d_counts);
+    HIP_CHECK(hipGetLastError());
+}
+
 size_t select_flagged_indices(const uint8_t *flags, uint32_t *out_idx, size_t n) {
     if (!n) return 0;
     DBuf<uint32_t> total(1);
