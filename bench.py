@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """bench.py - long-read all-vs-all overlaps/sec of the hot path on synthetic reads (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload C3|C2|...]
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the split_reads2-equivalent stage (sketch -> index -> seed -> chain -> align ->
-v4 window filter -> SNP pile-up filter -> pass 2 -> score-sorted PAF on disk) over the workload, with
-the reads already resident in HBM when the timed region starts (hlmi_job_open uploads them).
-Workload at N=1 = BASELINE.json configs[1] (C2): 10 000 synthetic ONT reads, mean 8 kb, 5 strains of
-400 kb, --nsplit 100; the stage constants are those of the reference's main all-vs-all call
-(script/HyLight.py:130: len_over=6000, mc=2, iden=0.95).  With N>1 the --nsplit target chunks are
-sharded over the ranks (chunk i -> rank i % N), every rank sketches 1/N of the reads and the sketches
-are all-gathered over RCCL; the read set is fixed whatever N is, so scaling is "strong".
+Workload at N=1 = the configuration BASELINE.json's metric is quoted on (north_star: "synthetic 100k-long-read
+ava"): C3 = configs[2], 100 000 synthetic ONT reads, mean 10 kb, 20 strains x 1 Mb, --nsplit 200, with the stage
+constants of the reference's main all-vs-all call (script/HyLight.py:130: len_over=6000, mc=2, iden=0.95).  A full
+pass of C3 is ~8e10 anchors / ~1e8 aligned candidate rows; one STEP is one pass of the split_reads2-equivalent
+stage (index -> seed -> chain -> align -> v4 window filter -> SNP pile-up filter -> pass 2 -> score-sorted PAF on
+disk) over ONE BATCH of it: 1/8 of the --nsplit target chunks per GPU (chunk c belongs to slice c % 8) against ALL
+100 000 query reads - exactly the share one rank of an 8-rank job computes (hlmi_job_run(rank, 8)).  Steps walk
+through the slices, so 8 steps at N=1 (one step at N=8) are one complete pass; whenever a new pass begins the
+query sketch is recomputed and, with N>1, exchanged again (each rank sketches 1/N of the reads, RCCL all-gather)
+inside the timed region: nothing is carried over from one pass to the next.  The reads are resident in HBM when
+the timed region starts (hlmi_job_open uploads them; `value_e2e` adds parsing + upload).  Per-GPU work per step is
+the same for every N, so the line reports "scaling": "weak"; `value` = overlaps written by all ranks / time.
+`--workload C2` (configs[1], 10 000 reads) runs whole passes per step instead (`--slices 1`).
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+Prints ONE JSON line on rank 0 (fields: README.md / DESIGN.md section 7).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -27,51 +34,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {
-    # BASELINE.json configs[1]
-    "C2": dict(seed=20241008, n_strains=5, genome_len=400_000, n_reads=10_000, mean_len=8_000, min_len=1_000,
-               max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001, nsplit=100),
-    # small variant for quick checks (not a bench line)
-    "C2mini": dict(seed=20241008, n_strains=5, genome_len=40_000, n_reads=1_000, mean_len=8_000, min_len=1_000,
-                   max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001, nsplit=100),
-    # scale / robustness probes (not bench lines): 4x the reads of C2 at the same depth; a high-divergence mix in
-    # the spirit of BASELINE.json configs[4] (strain indels, 1 % / 0.5 % / 0.5 % read errors)
-    "C3s": dict(seed=20241008, n_strains=5, genome_len=1_600_000, n_reads=40_000, mean_len=8_000, min_len=1_000,
-                max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001, nsplit=200),
-    "C5s": dict(seed=20241008, n_strains=8, genome_len=200_000, n_reads=5_000, mean_len=10_000, min_len=1_000,
-                max_len=40_000, snp_rate=0.02, strain_indel_rate=0.001, err_sub=0.01, err_ins=0.005, err_del=0.005,
-                nsplit=100, stage=dict(len_over=1500, mc=2, iden=0.90)),
-}
-STAGE = dict(len_over=6000, mc=2, iden=0.95)     # script/HyLight.py:130
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+SLICES = {"C3": 8, "C5": 8, "C4": 64}            # slices of the --nsplit chunks a full pass is cut into (default 1)
 
-
-def make_workload(name, path):
-    from hylight_amd import simulate as S
-    w = dict(WORKLOADS[name])
-    w.pop("nsplit")
-    w.pop("stage", None)
-    reads, _ = S.simulate_reads(**w)
-    S.write_fasta(reads, path)
-    return sum(len(r.seq) for r in reads)
-
-
-KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_narrow_kernel", "align_wide": "hlmi::align_kernel",
+KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_narrow", "align_wide": "hlmi::align_kernel",
                    "align_classify": "hlmi::classify_kernel", "seed_fill": "hlmi::seed_kernel<true>",
-                   "seed_count": "hlmi::seed_kernel<false>", "anchor_sort": "rocprim::radix_sort_onesweep_config"}
+                   "seed_count": "hlmi::seed_kernel<false>", "anchor_sort": "hlmi::anchor_"}
+
+
+def _latest_profile(suffix, workload):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload.lower()}_{suffix}.json")))
+    return files[-1] if files else None
 
 
 def pmc_traffic(timer, workload):
-    """HBM bytes per launch of the kernel behind `timer`, from the committed rocprofv3 --pmc passes
-    (profiles/*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, see tools/summarize_pmc.py).  Those passes were run
-    on the C2 workload; any other workload reports null."""
-    if workload != "C2":
+    """HBM bytes per launch of the kernel behind `timer`, from the committed rocprofv3 --pmc passes of the SAME
+    workload and step definition (profiles/*_<workload>_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes for gfx950, tools/summarize_pmc.py); null when no such pass is committed."""
+    f = _latest_profile("pmc_traffic", workload)
+    if not f:
         return None
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
+    d = json.load(open(f))
     name = KERNEL_OF_TIMER.get(timer, "")
     k = next((v for n, v in d.items() if name and n.startswith(name)), None)      # template arguments follow the name
     return k["hbm_bytes_per_launch"] if k else None
@@ -79,69 +63,111 @@ def pmc_traffic(timer, workload):
 
 def pmc_valu(timer, workload):
     """What the kernel behind `timer` is really bound by (chain and banded DP are VALU work): the share
-    of the SIMDs' vector-issue cycles it uses, from the committed SQ counter pass (profiles/*_sq_counters.json,
-    tools/summarize_sq.py; SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)).  C2 only."""
-    if workload != "C2":
+    of the SIMDs' vector-issue cycles it uses, from the committed SQ counter pass (tools/summarize_sq.py;
+    SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    f = _latest_profile("sq_counters", workload)
+    if not f:
         return None
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
+    d = json.load(open(f))
     name = KERNEL_OF_TIMER.get(timer, "")
-    k = next((v for n, v in d.items() if n.startswith(name)), None)
+    k = next((v for n, v in d.items() if name and n.startswith(name)), None)
     if not k or not k.get("GRBM_GUI_ACTIVE"):
         return None
     busy = k["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0)
     return dict(valu_issue_frac=round(busy, 4), valu_insts_per_launch=k.get("SQ_INSTS_VALU", 0.0) / max(k.get("launches", 1), 1),
-                source=os.path.basename(files[-1]))
+                source=os.path.basename(f))
 
 
-def cpu_baseline(fa, nsplit, budget_s=25.0):
-    """Oracle (CPU port) timed on a bounded sample of the same workload: as many --nsplit target chunks
-    (each vs ALL query reads, exactly like one reference worker) as fit the budget, one process per
-    host core like the reference's `xargs -P`."""
+# ---- CPU baseline ------------------------------------------------------------------------------------------
+def cpu_baseline(fa, cfg, budget_s=25.0):
+    """The reference's CPU path timed beside the GPU number, on a bounded sample of the same workload.
+    (1) minimap2 on $PATH: the exact command line of script/filter_overlap_slr2.py:51 on sampled --nsplit chunks, one
+        process per chunk under a pool as wide as `xargs -P` (utils.py:65) -> kind "reference";
+    (2) otherwise the oracle (this repo's CPU restatement, kind "port"): sampled target reads of as many --nsplit
+        chunks as fit the budget, each against a fixed prefix of the query file, oracle overlapper + oracle filters,
+        one process per host core."""
     import multiprocessing as mp
     from oracle import filters as F
-    lines = open(fa).read().split("\n")[:-1]
-    # bounded sample: the first 16 target reads of every --nsplit chunk (a full chunk of ~100 reads against
-    # 10 k queries is ~1 core-minute in the scalar oracle)
-    ranges = [(lo, min(hi, lo + 32)) for lo, hi in F.chunk_ranges(len(lines), nsplit)]
+    stage = cfg["stage"]
+    n_lines = 2 * cfg["sim"]["n_reads"]
+    ranges = F.chunk_ranges(n_lines, cfg["nsplit"])
     cores = min(len(os.sched_getaffinity(0)), 32, len(ranges))
     tmp = tempfile.mkdtemp(prefix="hl_cpu_")
+    mm2 = shutil.which("minimap2")
+    # query sample: the first 10 000 reads (C2: all of them); target sample: the first 8 reads of a chunk
+    q_reads = min(cfg["sim"]["n_reads"], 10_000)
+    qfa = os.path.join(tmp, "q.fa")
+    with open(fa) as src, open(qfa, "w") as dst:
+        for _ in range(2 * q_reads):
+            dst.write(src.readline())
+    n_t = 8
+    want = {}
+    for i, (lo, hi) in enumerate(ranges):
+        for l in range(lo, min(hi, lo + 2 * n_t)):
+            want[l] = i
+    tl = [[] for _ in ranges]
+    with open(fa) as f:
+        for l, text in enumerate(f):
+            if l in want:
+                tl[want[l]].append(text.rstrip("\n"))
     t0 = time.time()
     done, rows = 0, 0
+    jobs = [(qfa, tl[i], os.path.join(tmp, f"c{i}"), stage, mm2) for i in range(len(ranges))]
     with mp.get_context("fork").Pool(cores) as pool:
         nxt = 0
-        while nxt < len(ranges) and (done == 0 or (time.time() - t0) * (1 + cores / max(done, 1)) < budget_s):
-            batch = [(fa, lines, ranges[i], os.path.join(tmp, f"c{i}")) for i in range(nxt, min(nxt + cores, len(ranges)))]
+        while nxt < len(jobs) and (done == 0 or (time.time() - t0) * (1 + cores / max(done, 1)) < budget_s):
+            batch = jobs[nxt:nxt + cores]
             rows += sum(pool.map(_cpu_chunk, batch))
             done += len(batch)
             nxt += len(batch)
     dt = time.time() - t0
-    return dict(value=rows / dt, unit="overlaps/s", cores=cores, kind="port",
-                sample=f"first 16 target reads of {done} of the {len(ranges)} --nsplit chunks x all queries, oracle overlapper "
-                       f"+ oracle filters, one process per core, {dt:.1f} s wall")
+    shutil.rmtree(tmp, ignore_errors=True)
+    what = ("minimap2 (the command of filter_overlap_slr2.py:51, -t 1 per process) + oracle filters for the count"
+            if mm2 else "oracle overlapper + oracle filters")
+    return dict(value=rows / dt, unit="overlaps/s", cores=cores, kind="reference" if mm2 else "port",
+                sample=f"first {n_t} target reads of {done} of the {len(ranges)} --nsplit chunks x first {q_reads} queries, {what}, "
+                       f"one process per core, {dt:.1f} s wall")
 
 
 def _cpu_chunk(args):
-    fa, lines, (lo, hi), base = args
-    from oracle import ava as OA
+    qfa, tlines, base, stage, mm2 = args
     from oracle import filters as F
     with open(base + ".fa", "w") as f:
-        f.write("\n".join(lines[lo:hi]) + "\n")
-    OA.ava(base + ".fa", fa, base + ".paf")
+        f.write("\n".join(tlines) + "\n")
+    if mm2:        # script/filter_overlap_slr2.py:51
+        with open(base + ".paf", "w") as out:
+            subprocess.run([mm2, "-N", "40", "-t", "1", "-L", "--eqx", "-cx", "ava-pb", "-Hk19", "-m100", "-g10000",
+                            "--max-chain-skip", "25", base + ".fa", qfa], stdout=out, stderr=subprocess.DEVNULL, check=True)
+    else:
+        from oracle import ava as OA
+        OA.ava(base + ".fa", qfa, base + ".paf")
     raw = open(base + ".paf").read().split("\n")[:-1]
-    return len(F.worker(raw, True, STAGE["len_over"], STAGE["mc"], STAGE["iden"]))
+    return len(F.worker(raw, True, stage["len_over"], stage["mc"], stage["iden"]))
+
+
+# ---- SURVEY.md 8d: algorithmic bytes of the whole stage from the counts of one step -------------------------------
+def stage_bytes(st):
+    B_t, B_q = st.get("bases_t", 0.0), st.get("bases_q", 0.0)
+    M_t, M_q = st.get("index_entries", 0.0), st.get("minimizers_q", 0.0)
+    A, E, P = st.get("anchors", 0.0), st.get("cigar_ops", 0.0), st.get("ava_rows", 0.0)
+    L = st.get("align_dp_bases", 0.0)                # sum of (Lq + Lt) over the alignment tasks
+    X, P2, Pout = st.get("snp_events", 0.0), st.get("rows_after_v4", 0.0), st.get("rows_out", 0.0)
+    ava = (B_t + B_q) + 16 * (M_t + M_q) + 32 * M_t + 16 * M_q + 8 * A + 16 * A + 32 * A + 16 * A + L + 4 * E + 64 * P
+    flt = 64 * P * 4 + 4 * E + 16 * X * 3 + 8 * 2 * 2 * P2 + 16 * X + 64 * P + 64 * Pout
+    return ava, flt
 
 
 def main():
+    from hylight_amd import workloads as W
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="C3", choices=sorted(W.CONFIGS))
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and genomes together (quick checks; not a bench line)")
+    ap.add_argument("--slices", type=int, default=0, help="slices of the --nsplit chunks per pass (0: workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +182,10 @@ def main():
     # one rank per GPU; HL_BENCH_BACKEND=gloo lets several ranks share a card (the 1-GPU rehearsal of the N > 1 flow:
     # RCCL wants one device per rank)
     backend = os.environ.get("HL_BENCH_BACKEND", "nccl")
-    dev_id = local % max(torch.cuda.device_count(), 1)
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > max(n_dev, 1):
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {n_dev}")
+    dev_id = local % max(n_dev, 1)
     torch.cuda.set_device(dev_id)
     api.init(dev_id, 0)
     if world > 1:
@@ -164,14 +193,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    wl = WORKLOADS[args.workload]
+    cfg = W.config(args.workload, args.scale)
+    slices = args.slices or SLICES.get(args.workload, 1)
+    if slices % world and slices > 1:
+        raise SystemExit(f"--slices {slices} must be a multiple of the rank count {world}")
+    shares = max(1, slices // world)                 # steps per complete pass
     work = os.environ.get("HL_BENCH_DIR") or tempfile.mkdtemp(prefix="hl_bench_")
-    fa = os.path.join(work, f"{args.workload}.fa")
+    fa = os.path.join(work, f"{cfg['name']}.fa")
     if rank == 0 and not os.path.exists(fa):
-        make_workload(args.workload, fa + ".tmp")
-        os.replace(fa + ".tmp", fa)
+        W.make_long(cfg, fa)
     if world > 1:
         obj = [fa]
         dist.broadcast_object_list(obj, src=0)
@@ -180,40 +213,60 @@ def main():
         dist.barrier()
 
     from hylight_amd.stage import StageRunner
-    runner = StageRunner(fa, fa, wl["nsplit"], long_mode=True, rank=rank, world=world)
+    t_open = time.time()
+    runner = StageRunner(fa, fa, cfg["nsplit"], long_mode=True, rank=rank, world=world)
+    torch.cuda.synchronize()
+    t_open = time.time() - t_open           # FASTA parse + name ranks + host-to-device upload of the reads
     out_paf = os.path.join(work, "out.paf")         # N > 1: ranks write out.paf.part<rank>, rank 0 merges into out.paf
+    stage = cfg["stage"]
+    t_prepare = []
 
-    def step():
-        return runner.run(out_paf, **wl.get("stage", STAGE))
+    def slice_paf(k):                       # every slice of a pass keeps its own file: together they are the stage output
+        return out_paf if shares == 1 else f"{out_paf}.slice{k}"
+
+    def step(i):
+        if i % shares == 0:                 # a new pass over the read set: sketch + exchange are part of it
+            t = time.time()
+            runner.prepare(force=True)
+            t_prepare.append(time.time() - t)
+        return runner.run(slice_paf(i % shares), share=(i % shares, shares), **stage)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    t_prepare.clear()
     fence()
     t0 = time.time()
     rows = 0
     stats = None
-    for _ in range(args.steps):
-        rows = step()
+    step_rows, step_s = [], []
+    for i in range(args.steps):
+        ts = time.time()
+        r = step(args.warmup + i)
+        step_s.append(time.time() - ts)
+        step_rows.append(r)
+        rows += r
         stats = api.last_stats()
     fence()
     dt = time.time() - t0
     if world > 1:
-        t = torch.tensor([dt, float(rows)], dtype=torch.float64, device=red_dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, rows = float(tmax[0]), int(t[1])
+        # every rank counts the rows of its own chunks
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        tot = torch.tensor([float(rows)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        rows = int(tot[0])
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
     ms = dt / args.steps * 1e3
-    value = rows / (dt / args.steps)
+    value = rows / dt
 
     # ---- roofline of the dominant kernel (HIP events on the library stream, last step) --------------
     kms = {k.split(".", 1)[1]: v for k, v in stats.items() if k.startswith("kernel_ms.")}
@@ -222,51 +275,76 @@ def main():
     # algorithmic bytes per kernel for the whole step (DESIGN.md "Algorithmic bytes")
     A, P = stats.get("anchors", 0.0), stats.get("pieces", 0.0)
     AB = stats.get("anchor_bytes", 16 * A)             # 8 B per anchor when a batch packs them into one word, else 16
-    M = stats.get("sketch_minimizers", 0.0)
+    M = stats.get("minimizers_q", 0.0)
     algo = {
         # every anchor read once, the alignment pieces (32 B) and their fixed points (8 B) written once; the DP's
-        # own arrays (f, p, best child, chain id, peak, member list: 36 B per anchor) are scratch, not counted
+        # own arrays are scratch, not counted
         "chain": AB + 32 * P + 8 * stats.get("fixed_points", 0.0),
         "align_narrow": stats.get("align_bases_narrow", 0.0) + 4 * stats.get("cigar_ops", 0.0) + 32 * stats.get("align_tasks_narrow", 0.0),
         "align_wide": stats.get("align_bases_wide", 0.0) + 32 * stats.get("align_tasks_wide", 0.0),
         "align_classify": stats.get("align_bases_classify", 0.0) + (32 + 24 + 1) * stats.get("align_tasks", 0.0),
         "anchor_sort": 2 * AB,                         # one read + one write per anchor
-        "seed_fill": 16 * M / 2 + 8 * A + AB,          # query minimizers, index occurrences (y), anchors out
-        "seed_count": 16 * M / 2 + 4 * A,              # query minimizers, rank/frequency word of every occurrence
-        "sketch_kmer_window": stats.get("sketch_bases", 0.0) * 1 + 16 * M,
+        "seed_fill": 16 * M + 8 * A + AB,              # query minimizers, index occurrences (y), anchors out
+        "seed_count": 16 * M + 4 * A,                  # query minimizers, rank/frequency word of every occurrence
     }
     launches = max(kn.get(dom, 1.0), 1.0)
     avg_ms = kms[dom] / launches
     bytes_per_launch = algo.get(dom, 0.0) / launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    b_ava, b_flt = stage_bytes(stats)
+    last_s = step_s[-1]
     roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                 traffic=pmc_traffic(dom, args.workload), algorithmic_bytes_per_launch=bytes_per_launch,
                 avg_launch_ms=avg_ms, launches_per_step=launches, valu=pmc_valu(dom, args.workload),
+                # whole stage: SURVEY.md 8d's bytes_ava + bytes_filter evaluated on the counts of the last step, over
+                # that step's wall time
+                stage=dict(bytes_ava=b_ava, bytes_filter=b_flt, step_s=last_s,
+                           achieved=(b_ava + b_flt) / last_s / 1e9, frac=(b_ava + b_flt) / last_s / 1e9 / HBM_PEAK_GBS),
                 kernel_ms_per_step={k: round(v, 3) for k, v in sorted(kms.items(), key=lambda kv: -kv[1])})
 
+    counts = {k: stats.get(k) for k in ("queries", "targets", "chunks_run", "bases_q", "bases_t", "minimizers_q", "index_entries",
+                                        "anchors", "anchor_bytes", "chain_groups", "pieces", "fixed_points", "align_tasks",
+                                        "align_tasks_dp", "align_tasks_fast", "align_dp_bases", "cigar_ops", "ava_rows",
+                                        "rows_after_v4", "snp_events", "pairs", "rows_out")}
+    pass_steps = shares
+    pass_s = (sum(step_s[-pass_steps:]) / min(pass_steps, len(step_s))) * pass_steps
+    pass_rows = (sum(step_rows[-pass_steps:]) / min(pass_steps, len(step_rows))) * pass_steps * (world if world > 1 else 1)
     line = dict(metric="long-read all-vs-all overlaps/sec", value=value, unit="overlaps/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
-                scaling="strong", vs_baseline=None, dtype="u8/int32", data="synthetic",
-                config=dict(workload=f"{args.workload}: {wl['n_reads']} synthetic ONT reads, mean {wl['mean_len']} bp, "
-                                     f"{wl['n_strains']} strains x {wl['genome_len']} bp, ava, --nsplit {wl['nsplit']}",
-                            nsplit=wl["nsplit"], parallelism=f"chunks%{world}", **wl.get("stage", STAGE),
-                            overlaps_out=rows, candidate_rows=stats.get("ava_rows"), anchors=A),
+                scaling="weak" if slices > 1 else "strong", vs_baseline=None, dtype="u8/int32", data="synthetic",
+                config=dict(workload=W.describe(cfg), nsplit=cfg["nsplit"],
+                            step=(f"slice {slices} of the --nsplit chunks per pass; one step = {world} slice(s) "
+                                  f"(chunk c: slice c % {slices}) x all queries; {shares} steps = one full pass"
+                                  if slices > 1 else "one full pass"),
+                            parallelism=f"chunks%{slices if slices > 1 else world}", **stage, overlaps_out=rows,
+                            last_step=counts),
                 roofline=roof,
+                # the drop-in call's view: FASTA parsing + upload of the reads + sketch/exchange + one full pass
+                value_e2e=pass_rows / (t_open + pass_s) if pass_s > 0 else None,
+                e2e=dict(open_parse_upload_s=round(t_open, 3), pass_s=round(pass_s, 3), pass_overlaps=int(pass_rows),
+                         sketch_exchange_s=[round(x, 4) for x in t_prepare]),
                 stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})
     # second half of the BASELINE metric: overlap-graph build seconds (PAF on disk -> GFA on disk), not part of `value`
-    try:
-        t_g = time.time()
-        api.miniasm(out_paf, fa, os.path.join(work, "contigs1.gfa"), bub_dist=10000, n_rounds_arg=1, max_ext=1, min_dp=1)
-        line["graph_build_s"] = round(time.time() - t_g, 4)
-        line["graph_unitigs"] = sum(1 for l in open(os.path.join(work, "contigs1.gfa")) if l.startswith("S\t"))
-    except Exception as e:                                    # the stage number stays valid without it
-        line["graph_build_s"] = None
-        line["graph_error"] = str(e)[:200]
+    if not args.no_graph:
+        try:
+            if shares > 1:                  # the pass's output = the merge of its slices (utils.py:69)
+                have = [slice_paf(k) for k in range(shares) if os.path.exists(slice_paf(k))]
+                api.merge_scored_paf(have, out_paf)
+                line["graph_input"] = f"{len(have)} of {shares} slices of the pass"
+            t_g = time.time()
+            api.miniasm(out_paf, fa, os.path.join(work, "contigs1.gfa"), bub_dist=10000, n_rounds_arg=1, max_ext=1, min_dp=1)
+            line["graph_build_s"] = round(time.time() - t_g, 4)
+            line["graph_rows_in"] = sum(1 for _ in open(out_paf))
+            line["graph_unitigs"] = sum(1 for l in open(os.path.join(work, "contigs1.gfa")) if l.startswith("S\t"))
+        except Exception as e:                                    # the stage number stays valid without it
+            line["graph_build_s"] = None
+            line["graph_error"] = str(e)[:200]
     if os.environ.get("HL_BENCH_STATS"):
         sys.stderr.write("STATS " + json.dumps({k: round(v, 4) for k, v in sorted(stats.items())}) + "\n")
     if not args.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_baseline(fa, wl["nsplit"])
+        line["cpu_baseline"] = cpu_baseline(fa, cfg)
     print(json.dumps(line), flush=True)
+    runner.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -67,6 +67,9 @@ struct AvaInput {
     // all-vs-all on one read set: local target t is query t_query[t], so its minimizers are already in d_qmz and
     // the target sketch is a gather instead of a second pass over the bases (empty: targets are sketched)
     std::vector<uint32_t> t_query;
+    // more anchors than this in the run: ava_device stops after the counting pass (AvaRows::refused_anchors is set) so
+    // that the caller can come back with fewer chunks (0: no limit; a run of a single chunk is never refused)
+    uint64_t max_anchors = 0;
 };
 
 struct AvaRows {            // overlapper output in stream order (chunk, query, target, strand, chain, piece)
@@ -74,6 +77,7 @@ struct AvaRows {            // overlapper output in stream order (chunk, query, 
     DBuf<PafRec> recs;
     DBuf<uint32_t> ops;
     std::vector<uint64_t> chunk_row_start;   // n_chunks+1
+    uint64_t refused_anchors = 0;            // != 0: nothing was computed, the run would have had this many anchors
 };
 void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out);
 

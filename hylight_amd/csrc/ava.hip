@@ -32,7 +32,8 @@ __global__ void gather_rows_kernel(const PafRec *src, const uint32_t *idx, PafRe
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     PafRec r = src[idx[i]];
-    r.tie = (uint32_t)i;    // stream position: last-resort order of rows the overlapper itself emitted
+    r.tie = (uint32_t)i;    // stream position (only identical lines fall back to it)
+    r.flags |= PF_GEN;      // whole-line order of these rows comes from their fields (filter_stage.hip: row_text_less)
     dst[i] = r;
 }
 __global__ void shift_cigar_kernel(PafRec *recs, size_t n, uint64_t base) {
@@ -138,7 +139,6 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         build_index(tsk, in.d_chunk_of_t, in.d_rank_t, in.n_chunks, in.n_ranks, o, ix);
         tsk.mz.release();
     }
-    stat_add("index_entries", (double)ix.n);
 
     // ---- query batches ----------------------------------------------------------------------------------
     std::vector<AlignOut> parts;
@@ -154,6 +154,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     // and no more queries than keep the anchor a single 64-bit word (seed_and_chain: "fits")
     uint64_t total_anchors = 0;
     for (size_t i = 0; i < nQ; ++i) total_anchors += plan.per_query[i];
+    if (in.max_anchors && total_anchors > in.max_anchors && in.n_chunks > 1) { out.refused_anchors = total_anchors; return; }
     const uint64_t n_batches = std::max<uint64_t>(1, (total_anchors + anchor_batch - 1) / anchor_batch);
     const uint64_t batch_target = (total_anchors + n_batches - 1) / n_batches;
     size_t q_cap = QUERY_BATCH;
@@ -191,6 +192,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         }
         q = hi;
     }
+    stat_add("index_entries", (double)ix.n);
     stat_add("anchors", (double)st.anchors);
     stat_add("chain_groups", (double)st.groups);
 

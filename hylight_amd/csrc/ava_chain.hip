@@ -312,7 +312,6 @@ struct ChainArgs {
     Piece *pieces;
     FixPt *fps;
     uint32_t cap_pieces, cap_fps;
-    int stop_after;                   // tuning aid (HLMI_CHAIN_STOP): 1 = leave a group after the DP, 2 = after the member lists
     uint32_t *counters;               // [0] pieces, [1] unused, [2] overflow flag, [3] fixed points written
 };
 
@@ -676,7 +675,6 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         }
         resolve((n - 1) & ~63, P1_f, P1_p, P2_f);
         __threadfence_block();
-        if (a.stop_after == 1) continue;
         int moff = 0;                                      // member lists of the group's chains are disjoint
         for (int s0 = 0; s0 < n; s0 += 64) {
             int pk_i = 0;
@@ -708,7 +706,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                     best_len += __popcll(mm);
                 }
                 moff += best_len;
-                if (best_len < a.min_cnt || a.stop_after == 2) continue;
+                if (best_len < a.min_cnt) continue;
                 __threadfence_block();
                 // fixed points of this chain: at most 2 per member, and the member lists of a batch are disjoint
                 // ranges of the anchor array - twice the list's own offset is a private range, no counter needed
@@ -927,14 +925,6 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     ca.sbase = sbase.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
-    if (const char *e = getenv("HLMI_CHAIN_STOP")) {
-        ca.stop_after = atoi(e);
-        static bool warned = false;
-        if (ca.stop_after && !warned) {
-            fprintf(stderr, "hylight-mi: HLMI_CHAIN_STOP=%d is a timing aid - the overlaps of this run are incomplete\n", ca.stop_after);
-            warned = true;
-        }
-    }
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
     ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);
     ca.cap_fps = (uint32_t)(2 * A + 1024);

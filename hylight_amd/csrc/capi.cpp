@@ -23,14 +23,18 @@ template <typename F>
 int guarded(F &&f) {
     try {
         f();
+        ktimer_flush();          // kernel timers of this call end here: none leaks into the next call's statistics
         return HLMI_OK;
     } catch (const Error &e) {
+        ktimer_discard();
         set_last_error(e.what());
         return e.code;
     } catch (const std::bad_alloc &) {
+        ktimer_discard();
         set_last_error("out of host memory");
         return HLMI_ENOMEM;
     } catch (const std::exception &e) {
+        ktimer_discard();
         set_last_error(e.what());
         return HLMI_EINVAL;
     }

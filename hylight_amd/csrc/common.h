@@ -111,6 +111,7 @@ struct KTimer {
     size_t slot;
 };
 void ktimer_flush();
+void ktimer_discard();           // drop pending timers without reading them (error paths)
 
 // Host wall-clock of a scope (stream drained at both ends) -> stats "host_s.<name>"; active only with HLMI_HOST_TIMERS set
 struct HostTimer {
@@ -160,6 +161,9 @@ enum : uint32_t {
     PF_REV = 1u,       // strand '-'
     PF_STAR = 2u,      // last field is "*" (no CIGAR)
     PF_BAD = 4u,       // row could not be parsed (kept only to preserve window positions)
+    PF_GEN = 8u,       // row emitted by the device overlapper: qid/tid are strcmp ranks of the names and the row's text
+                       // is a function of its fields, so the whole-line byte order (GNU sort's last resort) is computed
+                       // from the fields instead of `tie`
 };
 
 struct PafRec {

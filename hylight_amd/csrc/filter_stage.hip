@@ -255,16 +255,67 @@ __global__ void pair_keys_kernel(const PafRec *recs, const uint32_t *rows, size_
     key[i] = pair_key(r.qid, r.tid);
 }
 
+// ---- whole-line byte order of two rows the overlapper emitted (LC_ALL=C last resort of `sort -nk7 -k8 -k9 -k5`,
+// slr2:57).  The text of such a row is a function of its fields (ava.hip:format_ava_row): name, numbers in decimal,
+// strand, ..., NM:i:<blen - nmatch>, tp:A:S, cg:Z:<len><op>...  Two decimal numbers followed by the same terminator
+// compare like their digit strings, and where one is a prefix of the other the terminator decides: TAB sorts below
+// the digits, the CIGAR letters above them.
+__device__ __forceinline__ int dec_digits(uint32_t v, uint8_t *d) {      // most significant first
+    uint8_t t[10];
+    int n = 0;
+    do { t[n++] = (uint8_t)(v % 10u); v /= 10u; } while (v);
+    for (int i = 0; i < n; ++i) d[i] = t[n - 1 - i];
+    return n;
+}
+__device__ __forceinline__ int cmp_dec_text(uint32_t a, uint32_t b, bool term_high) {
+    if (a == b) return 0;
+    uint8_t da[10], db[10];
+    const int na = dec_digits(a, da), nb = dec_digits(b, db);
+    const int n = na < nb ? na : nb;
+    for (int i = 0; i < n; ++i)
+        if (da[i] != db[i]) return da[i] < db[i] ? -1 : 1;
+    // one is a proper prefix of the other: its terminator meets a digit
+    return ((na < nb) != term_high) ? -1 : 1;
+}
+__device__ __forceinline__ int op_char(uint32_t code) {      // '=' 'D' 'I' 'X'
+    return code == OP_EQ ? 0x3d : code == OP_D ? 0x44 : code == OP_I ? 0x49 : code == OP_X ? 0x58 : 0x3f;
+}
+__device__ bool row_text_less(const PafRec &a, const PafRec &b, const uint32_t *ops) {
+    int c;
+    if (a.qid != b.qid) return a.qid < b.qid;                 // name ranks = strcmp order
+    if ((c = cmp_dec_text(a.qlen, b.qlen, false))) return c < 0;
+    if ((c = cmp_dec_text(a.qs, b.qs, false))) return c < 0;
+    if ((c = cmp_dec_text(a.qe, b.qe, false))) return c < 0;
+    if ((a.flags ^ b.flags) & PF_REV) return !(a.flags & PF_REV);      // '+' (0x2b) < '-' (0x2d)
+    if (a.tid != b.tid) return a.tid < b.tid;
+    if ((c = cmp_dec_text(a.tlen, b.tlen, false))) return c < 0;
+    if ((c = cmp_dec_text(a.ts, b.ts, false))) return c < 0;
+    if ((c = cmp_dec_text(a.te, b.te, false))) return c < 0;
+    if ((c = cmp_dec_text(a.nmatch, b.nmatch, false))) return c < 0;
+    if ((c = cmp_dec_text(a.blen, b.blen, false))) return c < 0;
+    if ((c = cmp_dec_text(a.blen - a.nmatch, b.blen - b.nmatch, false))) return c < 0;
+    const uint32_t n = a.cig_n < b.cig_n ? a.cig_n : b.cig_n;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t x = ops[a.cig_off + i], y = ops[b.cig_off + i];
+        if (x == y) continue;
+        if ((c = cmp_dec_text(x >> 4, y >> 4, true))) return c < 0;
+        return op_char(x & 15u) < op_char(y & 15u);
+    }
+    if (a.cig_n != b.cig_n) return a.cig_n < b.cig_n;          // the shorter line is a prefix of the longer one
+    return a.tie < b.tie;                                      // identical lines
+}
+
 // the reference's intermediate order restricted to one chunk (slr2:57)
-__device__ __forceinline__ bool row_less(const PafRec &a, const PafRec &b) {
+__device__ __forceinline__ bool row_less(const PafRec &a, const PafRec &b, const uint32_t *ops) {
     if (a.tlen != b.tlen) return a.tlen < b.tlen;
     if (a.ts != b.ts) return a.ts < b.ts;
     if (a.te != b.te) return a.te < b.te;
+    if (a.flags & b.flags & PF_GEN) return row_text_less(a, b, ops);
     return a.tie < b.tie;
 }
 
 // one thread per pair group: order the group's rows, select the rows that feed the pile-up
-__global__ void pair_order_select_kernel(const PafRec *recs, uint32_t *grows /* rows, grouped */,
+__global__ void pair_order_select_kernel(const PafRec *recs, const uint32_t *ops, uint32_t *grows /* rows, grouped */,
                                          const uint32_t *seg_start, size_t n_seg, size_t n_rows, int long_mode,
                                          uint8_t *sel /* per grouped position */) {
     size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -273,7 +324,7 @@ __global__ void pair_order_select_kernel(const PafRec *recs, uint32_t *grows /* 
     for (size_t i = b + 1; i < e; ++i) {   // insertion sort, groups are tiny
         uint32_t x = grows[i];
         size_t j = i;
-        while (j > b && row_less(recs[x], recs[grows[j - 1]])) { grows[j] = grows[j - 1]; --j; }
+        while (j > b && row_less(recs[x], recs[grows[j - 1]], ops)) { grows[j] = grows[j - 1]; --j; }
         grows[j] = x;
     }
     bool taken = false;
@@ -606,7 +657,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     const size_t n_pseg = select_flagged_indices(head.p, pseg_start.p, m);
     out.n_pairs = n_pseg;
     DBuf<uint8_t> sel(m);
-    hipLaunchKernelGGL(pair_order_select_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, grows.p, pseg_start.p,
+    hipLaunchKernelGGL(pair_order_select_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, d_ops, grows.p, pseg_start.p,
                        n_pseg, m, lm, sel.p);
 
     ht.reset(); ht.reset(new HostTimer("filter_events"));

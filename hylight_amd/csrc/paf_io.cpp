@@ -49,17 +49,32 @@ void write_lines(const char *path, const std::vector<std::string> &lines) {
     write_lines(path, v);
 }
 void write_lines(const char *path, const std::vector<std::string_view> &lines) {
-    FILE *f = fopen(path, "wb");
+    // written next to the target and renamed on success: a short write (ENOSPC, quota) never leaves a truncated file
+    // under the final name for the next tool of the pipeline to read
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) fail(HLMI_EIO, "cannot write %s: %s", path, strerror(errno));
     std::string buf;                             // one buffer, few large writes
     buf.reserve(8u << 20);
+    bool ok = true;
+    auto flush = [&]() {
+        if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) ok = false;
+        buf.clear();
+    };
     for (auto &l : lines) {
         buf.append(l);
         buf.push_back('\n');
-        if (buf.size() > (7u << 20)) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+        if (buf.size() > (7u << 20)) flush();
     }
-    if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
-    if (fclose(f) != 0) fail(HLMI_EIO, "write error on %s", path);
+    flush();
+    if (ferror(f)) ok = false;
+    if (fclose(f) != 0) ok = false;
+    if (!ok) {
+        const int e = errno;
+        remove(tmp.c_str());
+        fail(HLMI_EIO, "write error on %s: %s", path, strerror(e));
+    }
+    if (rename(tmp.c_str(), path) != 0) fail(HLMI_EIO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(errno));
 }
 
 static bool parse_u32(std::string_view s, uint32_t &v) {

@@ -73,6 +73,7 @@ KTimer::KTimer(const char *name) {
 KTimer::~KTimer() { (void)hipEventRecord(g_krecs[slot].b, g_stream); }
 
 void ktimer_flush() {
+    if (g_krecs.empty()) return;
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     for (auto &r : g_krecs) {
         float ms = 0;
@@ -83,6 +84,13 @@ void ktimer_flush() {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
+    g_krecs.clear();
+}
+
+void ktimer_discard() {
+    if (g_krecs.empty()) return;
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (auto &r : g_krecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_krecs.clear();
 }
 

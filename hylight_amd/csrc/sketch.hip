@@ -255,6 +255,7 @@ static int64_t sketch_core(const DevReads &r, int k, int w, int hpc, uint32_t ri
     if (!r.n) return 0;
     if (!n) {
         HIP_CHECK(hipMemsetAsync(d_counts, 0, r.n * 4, stream()));
+        sync();                  // the caller reads the counts from another stream (torch) right after the call
         return 0;
     }
     DBuf<uint8_t> flag(n);

@@ -110,27 +110,53 @@ void Job::sketch_all_queries() {
 void Job::run(int rank, int world, int len_over, int mc, double iden, const char *out_paf) {
     Impl &m = *impl_;
     if (!m.d_qmz && m.Q.size()) fail(HLMI_ESTATE, "hlmi_job_run before a query sketch was installed");
+    ktimer_discard();            // timers of earlier calls (sketching) do not belong to this pass
     stat_reset();
     const double t0 = now_s();
     struct ExitStamp { double t0; ~ExitStamp() { stat_set("t_with_cleanup_s", now_s() - t0); } } exit_stamp{t0};   // runs after the locals are gone
-    // ---- this rank's chunks and targets ---------------------------------------------------------------
-    std::vector<uint32_t> tids, chunk_of_t;
-    uint32_t n_my = 0;
-    for (size_t c = 0; c < m.chunks.size(); ++c) {
-        if ((int)(c % (size_t)world) != rank) continue;
-        for (uint32_t t = m.chunks[c].first; t < m.chunks[c].second; ++t) { tids.push_back(t); chunk_of_t.push_back(n_my); }
-        ++n_my;
-    }
+    // ---- this rank's chunks, in sub-runs ----------------------------------------------------------------------
+    // The chunks are independent (the reference runs one worker per chunk), so the rank's share is processed in
+    // sub-runs of consecutive chunks: every structure of a sub-run (index, anchors, candidate rows with their CIGARs)
+    // lives in HBM only while the sub-run is worked on, and the hard limits of one overlapper run (2^21 targets, 2^32
+    // index entries) are never met whatever the size of the share.  The first sub-run is small; its anchors per target
+    // base set the size of the following ones (~SUBRUN_ANCHORS anchors: rows + CIGARs of a sub-run are ~2-4 B/anchor).
+    std::vector<uint32_t> my_chunks;
+    for (size_t c = 0; c < m.chunks.size(); ++c)
+        if ((int)(c % (size_t)world) == rank) my_chunks.push_back((uint32_t)c);
+    constexpr double SUBRUN_ANCHORS = 1.2e10;
+    constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
+    constexpr double SUBRUN_ANCHORS_MAX = 2.4e10;
+    uint64_t budget_bases = 96ull << 20;
+    if (const char *e = getenv("HLMI_SUBRUN_MBASES")) budget_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
+    const bool fixed_budget = getenv("HLMI_SUBRUN_MBASES") != nullptr;
     // the rows' text: every formatting thread appends to a buffer of its own, `lines` are views into those buffers
     std::vector<std::string_view> lines;
     std::vector<std::unique_ptr<std::string>> text;
-    if (!tids.empty() && m.Q.size()) {
+    std::vector<uint32_t> tids;
+    double t_ava = 0, t_flt = 0, t_fmt = 0;
+    size_t n_v4 = 0, n_ev = 0, n_pairs = 0, n_subruns = 0;
+    uint64_t done_bases = 0;
+    double done_anchors = 0;
+    for (size_t ci = 0; ci < my_chunks.size() && m.Q.size();) {
+        std::vector<uint32_t> sub_tids, chunk_of_t;
+        uint32_t n_my = 0;
+        uint64_t sub_bases = 0;
+        while (ci < my_chunks.size()) {
+            const auto &ch = m.chunks[my_chunks[ci]];
+            const uint64_t cb = m.T.off[ch.second] - m.T.off[ch.first];
+            if (n_my && (sub_bases + cb > budget_bases || sub_tids.size() + (ch.second - ch.first) > SUBRUN_MAX_TARGETS)) break;
+            for (uint32_t t = ch.first; t < ch.second; ++t) { sub_tids.push_back(t); chunk_of_t.push_back(n_my); }
+            sub_bases += cb;
+            ++n_my; ++ci;
+        }
+        if (sub_tids.empty()) continue;
+        const double ts0 = now_s();
         DevReads dT_sub;
-        const bool all_in_order = tids.size() == m.T.size();   // world == 1: every chunk, file order
-        if (!all_in_order) subset_reads_device(*m.dT, tids, dT_sub);
+        const bool all_in_order = sub_tids.size() == m.T.size();   // every chunk, file order
+        if (!all_in_order) subset_reads_device(*m.dT, sub_tids, dT_sub);
         DevReads &dT = all_in_order ? *m.dT : dT_sub;
-        std::vector<uint32_t> rt(tids.size());
-        for (size_t i = 0; i < tids.size(); ++i) rt[i] = m.rank_t[tids[i]];
+        std::vector<uint32_t> rt(sub_tids.size());
+        for (size_t i = 0; i < sub_tids.size(); ++i) rt[i] = m.rank_t[sub_tids[i]];
         DBuf<uint32_t> d_rt, d_ct;
         d_rt.upload(rt);
         d_ct.upload(chunk_of_t);
@@ -138,21 +164,33 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         in.T = &dT; in.Q = &m.dQ; in.d_rank_t = d_rt.p; in.d_rank_q = m.d_rank_q.p; in.d_chunk_of_t = d_ct.p;
         in.n_chunks = n_my; in.d_qmz = m.d_qmz; in.qmz_off = m.qmz_off;
         in.n_ranks = m.name_of_rank.size();
-        if (m.dT == &m.dQ) in.t_query = tids;         // reads vs themselves: the targets' minimizers are in the query sketch
+        if (m.dT == &m.dQ) in.t_query = sub_tids;     // reads vs themselves: the targets' minimizers are in the query sketch
+        in.max_anchors = (uint64_t)SUBRUN_ANCHORS_MAX;
         AvaRows rows;
+        const double a0 = stats()["anchors"];
         ava_device(in, m.opts, rows);
+        if (rows.refused_anchors) {           // deeper than the estimate: come back with fewer chunks
+            budget_bases = std::max<uint64_t>(1, (uint64_t)(0.8 * SUBRUN_ANCHORS * (double)sub_bases / (double)rows.refused_anchors));
+            ci -= n_my;
+            stat_add("subruns_refused", 1);
+            continue;
+        }
+        tids.insert(tids.end(), sub_tids.begin(), sub_tids.end());
+        ++n_subruns;
+        done_bases += sub_bases;
+        done_anchors += stats()["anchors"] - a0;
+        if (!fixed_budget && done_anchors > 0)
+            budget_bases = std::min<uint64_t>(SUBRUN_MAX_BASES, std::max<uint64_t>(16ull << 20, (uint64_t)(SUBRUN_ANCHORS * (double)done_bases / done_anchors)));
         const double t1 = now_s();
+        t_ava += t1 - ts0;
         FilterCfg cfg;
         cfg.len_over = len_over; cfg.mc = mc; cfg.long_mode = m.long_mode;
         cfg.chunk_id_bound = n_my;
         cfg.reference_order = false;          // the rows are sorted by (score, text) below: one total order
-        // The chunks are independent (the reference runs one worker per chunk); filter them in groups whose SNP
-        // events (<= 2 per X op) stay below the 32-bit offsets the event arrays use.
+        // filter the chunks in groups whose SNP events (<= 2 per X op) stay below the 32-bit offsets the event arrays use
         const std::vector<uint64_t> chunk_ops = ops_per_chunk(rows.recs.p, rows.n_rows, n_my);
         FilterOut fo;
-        std::string s;
-        size_t n_v4 = 0, n_ev = 0, n_pairs = 0;
-        double t_fmt = 0;
+        double t_fmt_sub = 0;
         for (uint32_t c0 = 0; c0 < n_my;) {
             uint32_t c1 = c0;
             uint64_t ops = 0;
@@ -190,18 +228,19 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
                         if (len[i]) lines.emplace_back(buf.data() + at[i], len[i]);
                 }
             }
-            t_fmt += now_s() - tf;
+            t_fmt_sub += now_s() - tf;
             c0 = c1;
         }
-        const double t2 = now_s() - t_fmt;
-        fo.n_after_v4 = n_v4; fo.n_events = n_ev; fo.n_pairs = n_pairs;
-        stat_set("rows_after_v4", (double)fo.n_after_v4);
-        stat_set("snp_events", (double)fo.n_events);
-        stat_set("pairs", (double)fo.n_pairs);
-        stat_set("t_ava_s", t1 - t0);
-        stat_set("t_filter_s", t2 - t1);
-        stat_set("t_rows_to_text_s", t_fmt);
+        t_fmt += t_fmt_sub;
+        t_flt += now_s() - t1 - t_fmt_sub;
     }
+    stat_set("subruns", (double)n_subruns);
+    stat_set("rows_after_v4", (double)n_v4);
+    stat_set("snp_events", (double)n_ev);
+    stat_set("pairs", (double)n_pairs);
+    stat_set("t_ava_s", t_ava);
+    stat_set("t_filter_s", t_flt);
+    stat_set("t_rows_to_text_s", t_fmt);
     const double t3 = now_s();
     sort_scored_lines(lines);     // per-chunk sort + merged sort of utils.py:54,69 collapse into one total order
     stat_set("t_final_sort_s", now_s() - t3);
@@ -211,7 +250,15 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     ktimer_flush();
     stat_set("t_total_s", now_s() - t0);
 
+    // the counts SURVEY.md 8d's byte formula is evaluated on (bench.py: roofline.stage)
     stat_set("bases_q", (double)m.Q.bases.size());
+    uint64_t bt = 0;
+    for (uint32_t t : tids) bt += m.T.len(t);
+    stat_set("bases_t", (double)bt);
+    stat_set("targets", (double)tids.size());
+    stat_set("queries", (double)m.Q.size());
+    stat_set("minimizers_q", m.qmz_off.empty() ? 0.0 : (double)m.qmz_off.back());
+    stat_set("chunks_run", (double)my_chunks.size());
 }
 
 }  // namespace hlmi

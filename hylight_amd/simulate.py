@@ -38,12 +38,15 @@ class Read:
 
 
 def make_strains(rng, n_strains, genome_len, snp_rate, indel_rate=0.0):
-    """Return list of strain sequences (uint8 arrays).  Strain 0 is the ancestor."""
+    """Return list of strain sequences (uint8 arrays).  Strain 0 is the ancestor.  `snp_rate` is one rate or a
+    (lo, hi) pair: every strain then draws its own divergence uniformly from that range ("ANI
+    98.5-99.5 % (per-strain uniform)")."""
     anc = _BASES[rng.integers(0, 4, size=genome_len)]
     strains = [anc]
     for _ in range(1, n_strains):
         s = anc.copy()
-        n_snp = rng.binomial(genome_len, snp_rate)
+        rate = float(rng.uniform(snp_rate[0], snp_rate[1])) if isinstance(snp_rate, (tuple, list)) else snp_rate
+        n_snp = rng.binomial(genome_len, rate)
         pos = rng.choice(genome_len, size=n_snp, replace=False)
         # substitute with a different base
         shift = rng.integers(1, 4, size=n_snp)
@@ -51,14 +54,11 @@ def make_strains(rng, n_strains, genome_len, snp_rate, indel_rate=0.0):
         s[pos] = _BASES[(code + shift) % 4]
         if indel_rate > 0:
             n_id = rng.binomial(genome_len, indel_rate)
-            ipos = np.sort(rng.choice(genome_len, size=n_id, replace=False))[::-1]
-            lst = s.tolist()
-            for p in ipos:
-                if rng.random() < 0.5:
-                    del lst[p]
-                else:
-                    lst.insert(p, int(_BASES[rng.integers(0, 4)]))
-            s = np.array(lst, dtype=np.uint8)
+            ipos = np.sort(rng.choice(genome_len, size=n_id, replace=False))
+            is_del = rng.random(n_id) < 0.5
+            s = np.insert(np.delete(s, ipos[is_del]),
+                          ipos[~is_del] - np.searchsorted(ipos[is_del], ipos[~is_del]),
+                          _BASES[rng.integers(0, 4, size=int((~is_del).sum()))])
         strains.append(s)
     return strains
 
@@ -269,3 +269,46 @@ def messy_graph_paf(seed, n_reads=260, genome=70_000, drop=0.12, trim=0.25, fake
                               str(ov), str(ov - 20), str(ov), "0"]))
     rnd.shuffle(out)
     return reads, out
+
+
+def simulate_short_pairs(seed, strains, n_pairs, read_len=250, insert_mean=450.0, insert_sd=27.0, err_sub=0.001,
+                         name_prefix="p"):
+    """Paired 2 x `read_len` reads, insert size N(mean, sd), substitution errors only ("10 M paired
+    2x250 bp (insert N(450,27)), short 0.1 % sub").  Interleaved: read 2i is the forward mate `<name>/1`, read 2i+1
+    the reverse-complemented mate `<name>/2` of the same fragment; fragments are drawn from the strains with the same
+    log-uniform abundances as the long reads.  Vectorised: the C4 share draws millions of pairs."""
+    rng = np.random.default_rng(seed)
+    ns = len(strains)
+    ab = 10.0 ** rng.uniform(0.0, 1.0, size=ns)
+    ab /= ab.sum()
+    strain_of = rng.choice(ns, size=n_pairs, p=ab)
+    ins = np.maximum(np.rint(rng.normal(insert_mean, insert_sd, size=n_pairs)).astype(np.int64), read_len)
+    glen = np.array([len(g) for g in strains], dtype=np.int64)
+    start = (rng.random(n_pairs) * (glen[strain_of] - ins + 1)).astype(np.int64)
+    flip = rng.random(n_pairs) < 0.5                     # which strand the fragment is read from
+    reads = []
+    idx = np.arange(read_len, dtype=np.int64)
+    for st in range(ns):
+        sel = np.nonzero(strain_of == st)[0]
+        if not len(sel):
+            continue
+        g = strains[st]
+        left = g[start[sel][:, None] + idx[None, :]]                                     # fragment's first bases
+        right = _COMP[g[(start[sel] + ins[sel])[:, None] - 1 - idx[None, :]]]             # revcomp of its last bases
+        for block in (left, right):
+            e = rng.random(block.shape) < err_sub
+            n_e = int(e.sum())
+            if n_e:
+                code = np.searchsorted(_BASES, block[e])
+                block[e] = _BASES[(code + rng.integers(1, 4, size=n_e)) % 4]
+        for k, i in enumerate(sel):
+            a, b = (right[k], left[k]) if flip[i] else (left[k], right[k])
+            s0, s1 = int(start[i]), int(start[i] + ins[i])
+            reads.append((int(i), Read(f"{name_prefix}{i}/1", a, None, st, s0, s1, bool(flip[i])),
+                          Read(f"{name_prefix}{i}/2", b, None, st, s0, s1, not flip[i])))
+    reads.sort(key=lambda x: x[0])
+    out = []
+    for _, r1, r2 in reads:
+        out.append(r1)
+        out.append(r2)
+    return out

@@ -2,10 +2,15 @@
 
 One process per GPU.  PyTorch is plumbing here: it owns the device buffers that cross the C ABI
 and provides torch.distributed (backend "nccl" = RCCL over xGMI) for the ONE exchange step of the
-path: every rank sketches 1/N of the reads, the 16-byte minimizers are all-gathered, then each
-rank overlaps + filters its share of the --nsplit target chunks (chunk i -> rank i % N) against
-ALL reads with no further communication.  Rank 0 merges the per-rank score-sorted PAFs
-(`sort -k12 -nr` of utils.py:69).
+path: every rank sketches 1/N of the reads, the 16-byte minimizers are all-gathered ONCE per read
+set (`prepare()`), then each rank overlaps + filters its share of the --nsplit target chunks
+(chunk i -> rank i % N) against ALL reads with no further communication.  Rank 0 merges the
+per-rank score-sorted PAFs (`sort -k12 -nr` of utils.py:69).
+
+The exchange is streamed: the complete sketch is allocated once at its final size and filled in
+rounds of at most SLAB entries per rank (one all_gather_into_tensor of equal slabs per round, then
+one device-to-device copy per rank into place), so the transient memory is N slabs whatever the
+sketch size (C4: 40 GB of minimizers).
 """
 from __future__ import annotations
 
@@ -13,21 +18,30 @@ import os
 
 from . import api
 
+SLAB = 32 << 20          # minimizers per rank and round (16 B each: 512 MiB per rank slot)
+
 
 class StageRunner:
     def __init__(self, reads_fa, ref_fa, nsplit, long_mode=True, rank=0, world=1, group=None, job=None,
-                 device="cuda"):
+                 device="cuda", slab=SLAB):
         """`job` / `device` exist for the CPU (gloo) tests of the exchange logic: the product always uses
         api.Job on "cuda"."""
         self.rank, self.world, self.group, self.device = rank, world, group, device
+        self.slab = max(1, int(slab))
         self.job = job if job is not None else api.Job(reads_fa, ref_fa, nsplit, long_mode)
         self._keep = None
+        self.exchange_rounds = 0
 
     def close(self):
         self.job.close()
+        self._keep = None
 
     # -- sketch exchange -------------------------------------------------------------------------
-    def _install_sketch(self):
+    def prepare(self, force=False):
+        """Sketch this rank's slice of the reads, exchange, install the complete sketch.  Once per read set:
+        later passes (`run`) reuse it unless `force`."""
+        if self._keep is not None and not force:
+            return
         import torch
         job, world, rank, dev = self.job, self.world, self.rank, self.device
         nq = job.num_queries
@@ -35,44 +49,69 @@ class StageRunner:
         cap = max(job.sketch_bound(lo, hi), 1)
         mz = torch.empty((cap, 2), dtype=torch.int64, device=dev)
         cnt = torch.zeros(max(hi - lo, 1), dtype=torch.int32, device=dev)
+        if dev == "cuda":
+            torch.cuda.current_stream().synchronize()      # the library works on its own stream: torch's fills first
         n = job.sketch(lo, hi, mz.data_ptr(), cap, cnt.data_ptr()) if hi > lo else 0
         if world == 1:
             all_mz, all_cnt, total = mz[:max(n, 1)], cnt, n
         else:
             import torch.distributed as dist
             # RCCL moves device buffers directly; a gloo group (tests: two ranks sharing one GPU) stages through the host
-            xdev = "cpu" if dev == "cuda" and dist.get_backend(self.group) == "gloo" else dev
+            staged = dev == "cuda" and dist.get_backend(self.group) == "gloo"
+            xdev = "cpu" if staged else dev
             sizes = torch.tensor([n, hi - lo], dtype=torch.int64, device=xdev)
             gathered = torch.empty(world * 2, dtype=torch.int64, device=xdev)     # flat: gloo and RCCL both take it
             dist.all_gather_into_tensor(gathered, sizes, group=self.group)
             g = gathered.view(world, 2).cpu().tolist()
-            max_n, max_q = max(max(x[0] for x in g), 1), max(max(x[1] for x in g), 1)
-            # all-gather of equally sized slabs (RCCL: ring over xGMI, (N-1)/N of the sketch per link)
-            send = torch.zeros((max_n, 2), dtype=torch.int64, device=xdev)
-            send[:n] = mz[:n].to(xdev)
-            recv = torch.empty(world * max_n * 2, dtype=torch.int64, device=xdev)
-            dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)
-            recv = recv.view(world * max_n, 2)
+            n_of, q_of = [int(x[0]) for x in g], [int(x[1]) for x in g]
+            total = sum(n_of)
+            all_mz = torch.empty((max(total, 1), 2), dtype=torch.int64, device=dev)
+            if total == 0:
+                all_mz.zero_()
+            base = [sum(n_of[:r]) for r in range(world)]
+            slab = min(self.slab, max(max(n_of), 1))
+            send = torch.zeros((slab, 2), dtype=torch.int64, device=xdev)
+            recv = torch.empty(world * slab * 2, dtype=torch.int64, device=xdev)
+            self.exchange_rounds = 0
+            for off in range(0, max(n_of), slab):
+                mine = max(0, min(slab, n - off))
+                if mine:
+                    send[:mine].copy_(mz[off:off + mine])
+                # all-gather of equally sized slabs (RCCL: ring over xGMI, (N-1)/N of the round per link)
+                dist.all_gather_into_tensor(recv, send.view(-1), group=self.group)
+                rv = recv.view(world, slab, 2)
+                for r in range(world):
+                    k = max(0, min(slab, n_of[r] - off))
+                    if k:
+                        all_mz[base[r] + off:base[r] + off + k].copy_(rv[r, :k])
+                self.exchange_rounds += 1
+            del send, recv, mz
+            max_q = max(max(q_of), 1)
             csend = torch.zeros(max_q, dtype=torch.int32, device=xdev)
-            csend[:hi - lo] = cnt[:hi - lo].to(xdev)
+            csend[:hi - lo].copy_(cnt[:hi - lo])
             crecv = torch.empty(world * max_q, dtype=torch.int32, device=xdev)
             dist.all_gather_into_tensor(crecv, csend, group=self.group)
-            all_mz = torch.cat([recv[r * max_n:r * max_n + g[r][0]] for r in range(world)]).contiguous().to(dev)
-            all_cnt = torch.cat([crecv[r * max_q:r * max_q + g[r][1]] for r in range(world)]).contiguous().to(dev)
-            total = int(sum(x[0] for x in g))
-            if all_mz.shape[0] == 0:
-                all_mz = torch.zeros((1, 2), dtype=torch.int64, device=dev)
+            all_cnt = torch.zeros(max(nq, 1), dtype=torch.int32, device=dev)
+            qbase = 0
+            for r in range(world):
+                if q_of[r]:
+                    all_cnt[qbase:qbase + q_of[r]].copy_(crecv[r * max_q:r * max_q + q_of[r]])
+                qbase += q_of[r]
         if dev == "cuda":
             torch.cuda.synchronize()
         self._keep = (all_mz, all_cnt)          # the library reads these buffers during run()
         job.set_query_sketch(all_mz.data_ptr(), total, all_cnt.data_ptr())
 
     # -- one pass ----------------------------------------------------------------------------------
-    def run(self, out_paf, len_over, mc, iden, merge=True):
-        """Returns the number of overlaps this rank wrote (rank 0 with merge: of the merged file)."""
-        self._install_sketch()
+    def run(self, out_paf, len_over, mc, iden, merge=True, share=None):
+        """One pass over this rank's chunks.  `share` = (i, n) restricts the pass to the i-th of n slices of
+        the --nsplit chunks (chunk c belongs to slice c % n; inside a slice the ranks take turns): bench.py's
+        unit of work on workloads whose full pass takes tens of seconds.  Returns the number of overlaps this
+        rank wrote (rank 0 with merge: of the merged file)."""
+        self.prepare()
+        si, sn = share if share is not None else (0, 1)
         part = out_paf if self.world == 1 else f"{out_paf}.part{self.rank}"
-        self.job.run(self.rank, self.world, len_over, mc, iden, part)
+        self.job.run(si * self.world + self.rank, sn * self.world, len_over, mc, iden, part)
         rows = int(self.job.rows_out()) if hasattr(self.job, "rows_out") else int(api.last_stats().get("rows_out", 0))
         if self.world > 1 and merge:
             import torch.distributed as dist

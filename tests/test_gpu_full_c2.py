@@ -7,7 +7,7 @@ import os
 import pytest
 
 from hylight_amd import api
-from hylight_amd import simulate as S
+from hylight_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
 
@@ -17,10 +17,8 @@ LEN_OVER, MC, IDEN = 6000, 2, 0.95     # script/HyLight.py:130
 @pytest.fixture(scope="module")
 def c2(tmp_path_factory):
     d = tmp_path_factory.mktemp("c2full")
-    reads, _ = S.simulate_reads(seed=20241008, n_strains=5, genome_len=400_000, n_reads=10_000, mean_len=8_000,
-                                min_len=1_000, max_len=40_000, snp_rate=0.01, err_sub=0.003, err_ins=0.001, err_del=0.001)
     fa = d / "s1.fa"
-    S.write_fasta(reads, fa)
+    W.make_long(W.config("C2"), str(fa))
     out = d / "s1_s1.paf"
     api.split_reads2(fa, fa, 100, d, out, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
     return d, fa, out

@@ -141,3 +141,14 @@ def test_overlapper_recall_against_simulator_truth(workload):
     short = [k for k in want if k in best and best[k] < 0.97 * want[k] - 30]
     assert not missing, missing[:5]
     assert len(short) <= 0.01 * len(want), (len(short), len(want))
+
+
+def test_subruns_do_not_change_the_result(workload, monkeypatch):
+    """A rank's chunks are processed in sub-runs sized by their anchor count (csrc/stage.cpp); forcing tiny sub-runs
+    (1 Mb of target bases each) must reproduce the single-run file: a chunk's rows do not depend on its neighbours."""
+    d, fa, reads, out = workload
+    monkeypatch.setenv("HLMI_SUBRUN_MBASES", "1")
+    alt = d / "subruns.paf"
+    api.split_reads2(fa, fa, 100, d, alt, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    assert api.last_stats()["subruns"] >= 4
+    assert open(alt).read() == open(out).read()
