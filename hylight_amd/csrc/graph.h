@@ -63,6 +63,7 @@ struct GraphState {
     std::vector<uint32_t> seq_len;      // string graph: per read length | deleted << 31
     std::vector<Arc> arc;               // sorted by ul, after a14
     bool have_graph = false;
+    bool symmetric = false;             // asg_symm has run (it does after a reduction that removed arcs, asg.c:187-190)
     std::string read_name(uint32_t id) const { return paf.substr(name[id].off, name[id].len); }
 };
 

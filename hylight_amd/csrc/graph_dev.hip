@@ -489,34 +489,17 @@ __global__ __launch_bounds__(64 * TR_WAVES) void reduce_kernel(const Arc *arc, c
         return;
     }
     uint32_t *key = s_key[wv], *val = s_val[wv];
-    for (int k = lane; k < TR_SLOTS; k += 64) key[k] = TR_EMPTY;
+    for (int k = lane; k < TR_SLOTS; k += 64) { key[k] = TR_EMPTY; val[k] = 1u << 30 | 0x3fffffffu; }     // mark 1, no arc yet
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    // insert in arc order, one arc at a time per lane round: duplicates keep the smaller arc index
-    for (uint32_t i0 = 0; i0 < nv; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        if (i < nv) {
-            const uint32_t w = av[i].v;
-            uint32_t h = tr_hash(w);
-            for (;;) {
-                const uint32_t old = atomicCAS(&key[h], TR_EMPTY, w);
-                if (old == TR_EMPTY || old == w) { atomicMin(&val[h], 1u << 30 | i); break; }
-                h = (h + 1) & (TR_SLOTS - 1);
-            }
-        }
-        // (val starts undefined: set it where this round created the slot)
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-    }
-    // the atomicMin above needs an initial value: do the insertion in two phases instead - keys first, then values
-    // (kept simple: clear values of occupied slots to "mark 1, no arc yet", then take the minimum arc index)
-    for (int k = lane; k < TR_SLOTS; k += 64) if (key[k] != TR_EMPTY) val[k] = 1u << 30 | 0x3fffffffu;
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < nv; i += 64) {
+    for (uint32_t i = lane; i < nv; i += 64) {         // duplicates of a neighbour share one slot: smallest arc index wins
         const uint32_t w = av[i].v;
         uint32_t h = tr_hash(w);
-        while (key[h] != w) h = (h + 1) & (TR_SLOTS - 1);
+        for (;;) {
+            const uint32_t old = atomicCAS(&key[h], TR_EMPTY, w);
+            if (old == TR_EMPTY || old == w) break;
+            h = (h + 1) & (TR_SLOTS - 1);
+        }
         atomicMin(&val[h], 1u << 30 | i);
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -674,7 +657,12 @@ struct DevGraph {
     }
 };
 
-// windows of all reads from the current overlaps (reads without overlaps keep {0, 0, alive})
+__global__ void q_run_head_kernel(const Ovl *ovl, size_t n, uint8_t *head) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || ovl[i].q != ovl[i - 1].q) ? 1 : 0;
+}
+
+// windows of all reads from the current overlaps (a read without overlaps keeps {0, 0, alive}: calloc in hit.c:115)
 void coverage_windows(const DBuf<Ovl> &ovl, size_t n, size_t n_reads, const GraphOpt &o, DBuf<ReadWin> &win) {
     win.alloc(n_reads ? n_reads : 1);
     win.zero();
@@ -682,11 +670,227 @@ void coverage_windows(const DBuf<Ovl> &ovl, size_t n, size_t n_reads, const Grap
     DBuf<uint64_t> ends(2 * n);
     hipLaunchKernelGGL(win_ends_kernel, grid1(n), dim3(WG), 0, stream(), ovl.p, n, o.min_iden, ends.p);
     sort_keys_u64(ends, 2 * n, 0, 64);
-    // the overlaps are grouped by query read: one run per read
-    DBuf<uint64_t> qkey(n);
-    hipLaunchKernelGGL(gather_q_kernel_placeholder, dim3(1), dim3(1), 0, stream());
-    (void)qkey;
+    DBuf<uint8_t> head(n);
+    hipLaunchKernelGGL(q_run_head_kernel, grid1(n), dim3(WG), 0, stream(), ovl.p, n, head.p);
+    DBuf<uint32_t> run_head(n);
+    const size_t n_runs = select_flagged_indices(head.p, run_head.p, n);
+    hipLaunchKernelGGL(win_sweep_kernel, dim3(cdiv(n_runs, (size_t)(WG / 64))), dim3(WG), 0, stream(), ovl.p, run_head.p, n_runs,
+                       ends.p, 2 * n, o.min_dp, win.p);
+    HIP_CHECK(hipGetLastError());
+}
+
+uint32_t scan_total(const DBuf<uint32_t> &in, const DBuf<uint32_t> &excl, size_t n) {
+    return n ? download_one(excl.p + (n - 1)) + download_one(in.p + (n - 1)) : 0u;
 }
 }  // namespace
+
+void graph_device(const char *paf_path, const GraphOpt &o, const std::string &until, GraphState &out) {
+    require_device();
+    out = GraphState();
+    out.paf = read_file(paf_path);
+    const size_t nb = out.paf.size();
+    if (!nb) return;
+    if (nb >= 0xfffffff0ull) fail(HLMI_EINVAL, "%s: PAF files of 4 GiB and more are not supported by the graph stage", paf_path);
+    KTimer kt_all("graph_device");
+    DBuf<uint8_t> txt;
+    txt.upload((const uint8_t *)out.paf.data(), nb);
+    // ---- a9: lines -> rows ----------------------------------------------------------------------------------------
+    DBuf<uint32_t> line_start(nb);
+    size_t n_lines;
+    {
+        DBuf<uint8_t> flag(nb);
+        hipLaunchKernelGGL(line_start_kernel, grid1(nb), dim3(WG), 0, stream(), txt.p, nb, flag.p);
+        n_lines = select_flagged_indices(flag.p, line_start.p, nb);
+    }
+    DBuf<PafRow> rows(n_lines);
+    DBuf<uint32_t> kept(n_lines);
+    size_t n_rows;
+    {
+        DBuf<uint8_t> ok(n_lines);
+        hipLaunchKernelGGL(parse_rows_kernel, grid1(n_lines), dim3(WG), 0, stream(), txt.p, nb, line_start.p, n_lines, o.min_span,
+                           o.min_match, rows.p, ok.p);
+        HIP_CHECK(hipGetLastError());
+        n_rows = select_flagged_indices(ok.p, kept.p, n_lines);
+    }
+    line_start.release();
+    stat_set("graph_rows", (double)n_lines);
+    stat_set("graph_rows_kept", (double)n_rows);
+    if (!n_rows) return;
+    if (n_rows >= (1ull << 30)) fail(HLMI_EINVAL, "overlap graph: more than 2^30 PAF rows");
+    // ---- a9: read ids ----------------------------------------------------------------------------------------------
+    const size_t n_occ = 2 * n_rows;
+    DBuf<uint32_t> id_of_occ(n_occ);
+    DBuf<uint64_t> ref_off;
+    DBuf<uint32_t> ref_len;
+    size_t n_reads = 0;
+    for (int attempt = 0;; ++attempt) {
+        DBuf<uint64_t> hash(n_occ);
+        DBuf<uint32_t> occ(n_occ);
+        hipLaunchKernelGGL(name_hash_kernel, grid1(n_occ), dim3(WG), 0, stream(), txt.p, rows.p, kept.p, n_occ,
+                           0x243f6a8885a308d3ull + 0x9e3779b97f4a7c15ull * (uint64_t)attempt, hash.p, occ.p);
+        sort_pairs_u64_u32(hash, occ, n_occ, 0, 64);
+        DBuf<uint8_t> head(n_occ), first(n_occ);
+        DBuf<uint32_t> collision(1);
+        collision.zero();
+        first.zero();
+        hipLaunchKernelGGL(name_group_kernel, grid1(n_occ), dim3(WG), 0, stream(), txt.p, rows.p, kept.p, hash.p, occ.p, n_occ, head.p,
+                           collision.p);
+        HIP_CHECK(hipGetLastError());
+        if (download_one(collision.p)) {
+            if (attempt == 3) fail(HLMI_EINVAL, "overlap graph: read names collide under four hash seeds");
+            continue;
+        }
+        DBuf<uint32_t> group_start(n_occ);
+        n_reads = select_flagged_indices(head.p, group_start.p, n_occ);
+        DBuf<uint32_t> head32(n_occ), group_of(n_occ), first32(n_occ), first_rank(n_occ);
+        hipLaunchKernelGGL(widen_u8_kernel, grid1(n_occ), dim3(WG), 0, stream(), head.p, head32.p, n_occ);
+        exclusive_scan_u32(head32.p, group_of.p, n_occ);
+        hipLaunchKernelGGL(inclusive_from_exclusive_kernel, grid1(n_occ), dim3(WG), 0, stream(), group_of.p, head32.p, group_of.p, n_occ);
+        hipLaunchKernelGGL(name_first_kernel, grid1(n_occ), dim3(WG), 0, stream(), occ.p, head.p, n_occ, first.p);
+        hipLaunchKernelGGL(widen_u8_kernel, grid1(n_occ), dim3(WG), 0, stream(), first.p, first32.p, n_occ);
+        exclusive_scan_u32(first32.p, first_rank.p, n_occ);
+        hipLaunchKernelGGL(name_assign_kernel, grid1(n_occ), dim3(WG), 0, stream(), occ.p, group_of.p, group_start.p, first_rank.p, n_occ,
+                           id_of_occ.p);
+        ref_off.alloc(n_reads);
+        ref_len.alloc(n_reads);
+        hipLaunchKernelGGL(name_ref_kernel, grid1(n_occ), dim3(WG), 0, stream(), rows.p, kept.p, first.p, first_rank.p, n_occ, ref_off.p,
+                           ref_len.p);
+        HIP_CHECK(hipGetLastError());
+        sync();
+        break;
+    }
+    // ---- a9: overlaps, each row from both sides, in the reference's order ---------------------------------------------
+    DBuf<Ovl> ovl;
+    size_t n_ovl;
+    {
+        DBuf<uint32_t> cnt(n_rows), at(n_rows);
+        hipLaunchKernelGGL(ovl_count_kernel, grid1(n_rows), dim3(WG), 0, stream(), id_of_occ.p, n_rows, cnt.p);
+        exclusive_scan_u32(cnt.p, at.p, n_rows);
+        n_ovl = scan_total(cnt, at, n_rows);
+        ovl.alloc(n_ovl);
+        DBuf<uint64_t> key(n_ovl);
+        hipLaunchKernelGGL(ovl_fill_kernel, grid1(n_rows), dim3(WG), 0, stream(), rows.p, kept.p, id_of_occ.p, at.p, n_rows, ovl.p, key.p);
+        HIP_CHECK(hipGetLastError());
+        reference_order(ovl, n_ovl, key);                 // hit.c:104: by (read, start)
+    }
+    rows.release(); kept.release(); id_of_occ.release(); txt.release();
+    stat_set("graph_reads", (double)n_reads);
+    stat_set("graph_overlaps", (double)n_ovl);
+    // ---- a10-a11: two rounds of read selection (main.c:119-142) ---------------------------------------------------------
+    DBuf<ReadWin> win;
+    DBuf<uint8_t> keep(n_ovl ? n_ovl : 1);
+    coverage_windows(ovl, n_ovl, n_reads, o, win);
+    hipLaunchKernelGGL(clip_kernel, grid1(n_ovl), dim3(WG), 0, stream(), ovl.p, n_ovl, win.p, o.min_span, keep.p);
+    compact(ovl, n_ovl, keep.p);
+    hipLaunchKernelGGL(crude_filter_kernel, grid1(n_ovl), dim3(WG), 0, stream(), ovl.p, n_ovl, win.p, (int)(o.max_hang * 1.5),
+                       (int)(o.min_ovlp * .5), keep.p);
+    compact(ovl, n_ovl, keep.p);
+    {
+        DBuf<ReadWin> win2;
+        coverage_windows(ovl, n_ovl, n_reads, o, win2);
+        hipLaunchKernelGGL(clip_kernel, grid1(n_ovl), dim3(WG), 0, stream(), ovl.p, n_ovl, win2.p, o.min_span, keep.p);
+        compact(ovl, n_ovl, keep.p);
+        hipLaunchKernelGGL(win_merge_kernel, grid1(n_reads), dim3(WG), 0, stream(), win.p, win2.p, n_reads);
+    }
+    // ---- a12: containment, unused reads, renumbering (hit.c:225-256) -------------------------------------------------------
+    {
+        DBuf<uint32_t> used(n_reads), alive(n_reads), new_id(n_reads);
+        used.zero();
+        if (n_ovl) hipLaunchKernelGGL(contained_kernel, grid1(n_ovl), dim3(WG), 0, stream(), ovl.p, n_ovl, win.p, o, used.p);
+        hipLaunchKernelGGL(read_alive_kernel, grid1(n_reads), dim3(WG), 0, stream(), win.p, used.p, n_reads, alive.p);
+        exclusive_scan_u32(alive.p, new_id.p, n_reads);
+        const size_t n_left = scan_total(alive, new_id, n_reads);
+        DBuf<ReadWin> win2(n_left ? n_left : 1);
+        DBuf<uint64_t> off2(n_left ? n_left : 1);
+        DBuf<uint32_t> len2(n_left ? n_left : 1);
+        hipLaunchKernelGGL(squeeze_reads_kernel, grid1(n_reads), dim3(WG), 0, stream(), win.p, ref_off.p, ref_len.p, alive.p, new_id.p,
+                           n_reads, win2.p, off2.p, len2.p);
+        if (n_ovl) hipLaunchKernelGGL(renumber_kernel, grid1(n_ovl), dim3(WG), 0, stream(), ovl.p, n_ovl, alive.p, new_id.p, keep.p);
+        HIP_CHECK(hipGetLastError());
+        compact(ovl, n_ovl, keep.p);
+        win = std::move(win2); ref_off = std::move(off2); ref_len = std::move(len2);
+        n_reads = n_left;
+    }
+    stat_set("graph_reads_selected", (double)n_reads);
+    stat_set("graph_overlaps_selected", (double)n_ovl);
+    out.win = win.download(n_reads);
+    {
+        const std::vector<uint64_t> off = ref_off.download(n_reads);
+        const std::vector<uint32_t> len = ref_len.download(n_reads);
+        out.name.resize(n_reads);
+        for (size_t i = 0; i < n_reads; ++i) out.name[i] = NameRef{off[i], len[i]};
+    }
+    if (until == "paf") out.ovl = ovl.download(n_ovl);
+    if (until == "bed" || until == "paf") return;
+    // ---- a13: string graph (asm.c:9-39, asg.c:57-80) ----------------------------------------------------------------------
+    DevGraph g;
+    g.n_seq = n_reads;
+    g.seq.alloc(n_reads ? n_reads : 1);
+    hipLaunchKernelGGL(seq_init_kernel, grid1(n_reads), dim3(WG), 0, stream(), win.p, n_reads, g.seq.p);
+    g.arc.alloc(n_ovl ? n_ovl : 1);
+    g.n_arc = n_ovl;
+    if (n_ovl) {
+        hipLaunchKernelGGL(make_arcs_kernel, grid1(n_ovl), dim3(WG), 0, stream(), ovl.p, n_ovl, win.p, o, g.arc.p, keep.p, g.seq.p);
+        HIP_CHECK(hipGetLastError());
+        compact(g.arc, g.n_arc, keep.p);
+    }
+    ovl.release();
+    if (g.n_arc) {          // arcs of reads deleted while the arcs were made go first, then the order-defining sort
+        DBuf<uint8_t> live(g.n_arc);
+        hipLaunchKernelGGL(arc_live_kernel, grid1(g.n_arc), dim3(WG), 0, stream(), g.arc.p, g.n_arc, g.seq.p, live.p);
+        compact(g.arc, g.n_arc, live.p);
+    }
+    if (g.n_arc) {
+        DBuf<uint64_t> key(g.n_arc);
+        hipLaunchKernelGGL(arc_key_kernel, grid1(g.n_arc), dim3(WG), 0, stream(), g.arc.p, g.n_arc, key.p);
+        reference_order(g.arc, g.n_arc, key);             // asg.c:27-42: by (vertex, arc length)
+    }
+    g.index();
+    stat_set("graph_arcs", (double)g.n_arc);
+    // ---- a14: transitive reduction, then duplicate and unpaired arcs (asg.c:104-193) ----------------------------------------
+    const uint32_t n_vtx = (uint32_t)(2 * n_reads);
+    uint32_t n_reduced = 0;
+    if (g.n_arc) {
+        DBuf<uint8_t> del(g.n_arc);
+        DBuf<uint32_t> counters(2), big(n_vtx ? n_vtx : 1);
+        del.zero();
+        counters.zero();
+        {
+            KTimer kt("graph_reduce");
+            hipLaunchKernelGGL(reduce_kernel, dim3(cdiv(n_vtx, (size_t)TR_WAVES)), dim3(64 * TR_WAVES), 0, stream(), g.arc.p, g.seq.p,
+                               g.idx.p, n_vtx, (uint32_t)o.gap_fuzz, del.p, counters.p, big.p, counters.p + 1);
+        }
+        HIP_CHECK(hipGetLastError());
+        const uint32_t n_big = download_one(counters.p + 1);
+        if (n_big) {
+            DBuf<uint8_t> state(g.n_arc);
+            hipLaunchKernelGGL(reduce_big_kernel, grid1(n_big), dim3(WG), 0, stream(), g.arc.p, g.idx.p, big.p, n_big,
+                               (uint32_t)o.gap_fuzz, state.p, del.p, counters.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        n_reduced = download_one(counters.p);
+        stat_set("graph_arcs_reduced", (double)n_reduced);
+        stat_set("graph_big_vertices", (double)n_big);
+        if (n_reduced) {
+            hipLaunchKernelGGL(apply_del_kernel, grid1(g.n_arc), dim3(WG), 0, stream(), g.arc.p, del.p, g.n_arc);
+            g.cleanup();
+            for (int pass = 0; pass < 2 && g.n_arc; ++pass) {     // asg_symm: duplicates, then arcs without their reverse
+                DBuf<uint8_t> d2(g.n_arc);
+                counters.zero();
+                if (pass == 0) hipLaunchKernelGGL(dup_arcs_kernel, grid1(g.n_arc), dim3(WG), 0, stream(), g.arc.p, g.idx.p, g.n_arc, d2.p, counters.p);
+                else hipLaunchKernelGGL(unpaired_arcs_kernel, grid1(g.n_arc), dim3(WG), 0, stream(), g.arc.p, g.idx.p, g.n_arc, d2.p, counters.p);
+                HIP_CHECK(hipGetLastError());
+                if (download_one(counters.p)) {
+                    hipLaunchKernelGGL(apply_del_kernel, grid1(g.n_arc), dim3(WG), 0, stream(), g.arc.p, d2.p, g.n_arc);
+                    g.cleanup();
+                }
+            }
+        }
+    }
+    out.arc = g.arc.download(g.n_arc);
+    out.seq_len = g.seq.download(n_reads);
+    out.have_graph = true;
+    out.symmetric = n_reduced != 0;
+}
 
 }  // namespace hlmi
