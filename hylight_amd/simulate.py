@@ -312,3 +312,51 @@ def simulate_short_pairs(seed, strains, n_pairs, read_len=250, insert_mean=450.0
         out.append(r1)
         out.append(r2)
     return out
+
+
+def layout_paf(seed, n_reads=20_000, genome=2_000_000, mean_len=10_000, min_ovl=2_500, jitter=30, dup_frac=0.01,
+               fake_frac=0.002, drop=0.05, name_prefix="L"):
+    """A large tag-less PAF straight from a read layout (no alignment is computed): every pair of reads whose genome
+    intervals share >= min_ovl bases gives one row with the overlap's coordinates on both reads (both strands occur),
+    ends jittered by a few bases, a fraction of the rows dropped, some pairs reported twice with shifted coordinates
+    and a few false suffix-prefix overlaps between unrelated reads.  Millions of rows in seconds: the scale test of
+    the overlap-graph stage (tests/test_gpu_graph_scale.py).  Returns (read_lengths, lines)."""
+    rng = np.random.default_rng(seed)
+    length = np.clip(rng.gamma(4.0, mean_len / 4.0, size=n_reads).astype(np.int64), 3_000, 40_000)
+    start = np.sort(rng.integers(0, genome - 3_000, size=n_reads))
+    length = np.minimum(length, genome - start)
+    end = start + length
+    rev = rng.random(n_reads) < 0.5
+    # partners of read i: the reads j > i (by start) that begin at least min_ovl before i ends
+    last = np.searchsorted(start, end - min_ovl, side="right")
+    cnt = np.maximum(last - (np.arange(n_reads) + 1), 0)
+    a = np.repeat(np.arange(n_reads), cnt)
+    b = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt) + a + 1
+    keep = rng.random(len(a)) >= drop
+    a, b = a[keep], b[keep]
+    dup = rng.random(len(a)) < dup_frac
+    a, b = np.concatenate([a, a[dup]]), np.concatenate([b, b[dup]])
+    s = np.maximum(start[a], start[b]) + rng.integers(0, jitter + 1, size=len(a))
+    e = np.minimum(end[a], end[b]) - rng.integers(0, jitter + 1, size=len(a))
+    ok = e - s >= 2_000
+    a, b, s, e = a[ok], b[ok], s[ok], e[ok]
+
+    def on_read(r, s, e):
+        return np.where(rev[r], end[r] - e, s - start[r]), np.where(rev[r], end[r] - s, e - start[r])
+    qs, qe = on_read(a, s, e)
+    ts, te = on_read(b, s, e)
+    strand = np.where(rev[a] == rev[b], "+", "-")
+    ml = (e - s) - rng.integers(0, 40, size=len(a))
+    rows = [f"{name_prefix}{x}\t{length[x]}\t{q0}\t{q1}\t{z}\t{name_prefix}{y}\t{length[y]}\t{t0}\t{t1}\t{m}\t{bl}\t255"
+            for x, y, q0, q1, z, t0, t1, m, bl in zip(a.tolist(), b.tolist(), qs.tolist(), qe.tolist(), strand.tolist(),
+                                                      ts.tolist(), te.tolist(), ml.tolist(), (e - s).tolist())]
+    n_fake = int(len(rows) * fake_frac)
+    fa, fb = rng.integers(0, n_reads, size=n_fake), rng.integers(0, n_reads, size=n_fake)
+    for x, y in zip(fa.tolist(), fb.tolist()):
+        if x == y:
+            continue
+        ov = int(min(length[x], length[y], 2_100 + int(rng.integers(0, 1_500))))
+        rows.append(f"{name_prefix}{x}\t{length[x]}\t{length[x] - ov}\t{length[x]}\t+\t{name_prefix}{y}\t{length[y]}\t0\t{ov}\t"
+                    f"{ov - 20}\t{ov}\t255")
+    order = rng.permutation(len(rows))
+    return length, [rows[i] for i in order.tolist()]
