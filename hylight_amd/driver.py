@@ -6,8 +6,12 @@ Keeps script/HyLight.py's CLI flags and defaults (HyLight.py:25-52), stage order
 B3 = miniasm.  External tools the reference shells out to (bfc, ropebwt2, fmlrc2, racon) are still
 external; unlike the reference (whose `execute()` swallows most failures) a missing or
 failing tool stops the run with a message.  The two short-read overlap calls of the path (HyLight.py:200,207)
-run in the library's short mode; short-read clustering, POLYTE and stage b are out of scope: the driver stops
-after them.  The text passes (filter_non_atcg, gfa2fa, pick_up) are the library's native ones.
+run in the library's short mode.  `extend_con` (HyLight.py:282-326) is wired up to the SAVAGE overlap file: contigs ->
+contigs_b.fastq -> self-overlaps (the `minimap2 --sr -X ... -r 0` call as hlmi_ava) -> v3 window filter with -sfo ->
+sfo2overlaps; the consumers of that file - short-read clustering, POLYTE and the stage-b contig merge
+(pipeline_per_stage.py / ViralQuasispecies) - are outside this implementation (SURVEY.md sections 2 and 8f): the run
+says so on stderr and exits 0 with everything up to tmp/stageb/sfoverlap.out.savage in place.  The text passes
+(filter_non_atcg, gfa2fa, pick_up) are the library's native ones.
 """
 from __future__ import annotations
 
@@ -70,6 +74,57 @@ def _run(cmd, cwd=None):
         raise SystemExit(1)
 
 
+def contig_ava_opts():
+    """minimap2 -t T --sr -X -c -k 21 -w 11 -s 60 -m 30 -n 2 -r 0 -A 4 -B 2 --end-bonus=100 (HyLight.py:309-310): the
+    short-read constants, each pair once and never a contig against itself (-X), chaining bandwidth 0 (-r 0)."""
+    o = api.ava_opts_short()
+    o.pair_once = 1
+    o.bandwidth = 0
+    return o
+
+
+def extend_con(input_con, outdir1, out_file, threads=30, len_c=50000000, stageb_cmd=None):
+    """HyLight.extend_con (script/HyLight.py:282-326) up to the SAVAGE overlap file.  Returns the number of contigs
+    written to contigs_b.fastq.  `stageb_cmd`: command prefix of the reference's stage-b script
+    (`python .../pipeline_per_stage.py`) for installations that have it; without it the merge itself is skipped."""
+    conb = os.path.join(outdir1, "contigs_b.fastq")
+    if os.path.exists(conb):
+        os.remove(conb)
+    n = 0
+    if os.path.exists(input_con):                              # HyLight.py:289-305: every sequence LINE longer than 150
+        with open(input_con) as f, open(conb, "a") as w:
+            for line in f:
+                line = line.strip()
+                if line.startswith(">"):
+                    continue
+                if len(line) > 150:
+                    n += 1
+                    w.write(f"@{n}\n{line}\n+\n{'=' * len(line)}\n")
+    sb = os.path.join(outdir1, "stageb")
+    os.makedirs(os.path.join(sb, "fastq"), exist_ok=True)
+    raw, sfo, savage = os.path.join(sb, "contigs_ava.paf"), os.path.join(sb, "sfoverlaps.out"), os.path.join(sb, "sfoverlap.out.savage")
+    if n:
+        api.ava(conb, conb, raw, contig_ava_opts())
+        api.paf_window_filter(3, raw, sfo, min_len=90, min_iden=0.99, min_o=2, sfo=True)      # HyLight.py:310-311
+        api.sfo2overlaps(sfo, savage, num_singles=n, num_pairs=0)                              # HyLight.py:315-317
+        shutil.copyfile(conb, os.path.join(sb, "fastq", "singles.fastq"))
+    else:
+        for p in (raw, sfo, savage):
+            open(p, "w").close()
+    if stageb_cmd and n:                                       # HyLight.py:320-324
+        _run(f"{stageb_cmd} --no_error_correction --remove_branches true --stage b --min_overlap_len 300 "
+             f"--min_overlap_perc 0 --edge_threshold 1 --overlaps ./sfoverlap.out.savage --fastq ./fastq --max_tip_len 1000 "
+             f"--len_c {len_c} --num_threads {threads}", cwd=sb)
+        singles = os.path.join(sb, "singles.fastq")
+        with open(singles) as f, open(out_file, "w") as o:     # fastq2fasta.py
+            for k, line in enumerate(f):
+                if k % 4 == 0:
+                    o.write(">" + line[1:])
+                elif k % 4 == 1:
+                    o.write(line)
+    return n
+
+
 def build_parser():
     p = argparse.ArgumentParser(prog="python -m hylight_amd.driver",
                                 description="Haplotype-aware de novo assembly of metagenome from hybrid sequencing data "
@@ -92,6 +147,10 @@ def build_parser():
     p.add_argument("--stop_after", choices=["overlap", "contigs1", "polish"], default=None,
                    help="(extension) stop after the named long-read stage")
     p.add_argument("--device", type=int, default=0, help="(extension) GPU index")
+    p.add_argument("--short_contigs", default=None,
+                   help="(extension) contigs of the short-read branch (POLYTE, run elsewhere) to merge with the long-read contigs")
+    p.add_argument("--stageb_cmd", default=None,
+                   help="(extension) command prefix of the reference's pipeline_per_stage.py, if installed")
     return p
 
 
@@ -174,7 +233,8 @@ def main(argv=None):
     if args.stop_after == "polish":
         return 0
     if not args.short_reads:
-        raise SystemExit("long-read path finished (tmp/long_con_polished.fa); no --short_reads given")
+        sys.stderr.write("hylight-mi: long-read path finished (tmp/long_con_polished.fa); no --short_reads given\n")
+        return 0
     short_reads = os.path.abspath(args.short_reads) if args.corrected else os.path.join(tmp, "cor_short_reads.fq")
     # the two short-read calls of the same path (HyLight.py:200,207: len_over 70, mc 3, short mode)
     ov_short = stage(short_reads, long_con2, nsplit, tmp + "shortr1.paf", 70, 3, iden, long=False)
@@ -183,9 +243,22 @@ def main(argv=None):
     remain_short = pick_up(ov_short, tmp, short_reads)
     if os.path.exists(remain_short) and os.path.getsize(remain_short):
         stage(short_reads, remain_short, nsplit, tmp + "shortr2.paf", 70, 3, iden, long=False)
-    raise SystemExit("overlap path finished (tmp/shortr1.paf, tmp/shortr2.paf, long_con_polished.fa).  Short-read "
-                     "clustering, POLYTE and stage b (HyLight.py:211-280) are outside this implementation's scope "
-                     "(SURVEY.md section 2).")
+    # HyLight.py:211-262 (read clustering, POLYTE per cluster) is the short-read branch: not part of this path.  Its
+    # contigs can be handed in; the contig-overlap half of extend_con runs either way (HyLight.py:264-280).
+    sys.stderr.write("hylight-mi: short-read clustering and POLYTE (HyLight.py:211-262) are outside this implementation"
+                     + (": using --short_contigs\n" if args.short_contigs else "; continuing with the long-read contigs only\n"))
+    all_con = os.path.join(outdir, "all_contigs.fa")
+    with open(all_con, "w") as o:
+        for p in ([args.short_contigs] if args.short_contigs else []) + [long_con3]:
+            with open(p) as f:
+                shutil.copyfileobj(f, o)
+    final = os.path.join(outdir, "final_contigs.fa")
+    n_con = extend_con(all_con, tmp, final, threads=30, stageb_cmd=args.stageb_cmd)
+    if not args.stageb_cmd:
+        sys.stderr.write(f"hylight-mi: {n_con} contigs, their overlaps are in tmp/stageb/sfoverlap.out.savage; the stage-b merge "
+                         "(pipeline_per_stage.py / ViralQuasispecies, HyLight.py:320-324) is not built here, so "
+                         "final_contigs.fa was not written (pass --stageb_cmd to run the reference's)\n")
+    return 0
 
 
 if __name__ == "__main__":

@@ -63,3 +63,61 @@ def test_miniasm_launcher_is_argv_compatible(tmp_path, golden):
             assert gc[0:2] == wc[0:2] and gc[2] == "*" and gc[3] == wc[3]
         else:
             assert g == w
+
+
+def test_driver_reproduces_the_reference_drivers_files(tmp_path, golden):
+    """Goldens captured from the reference's own HyLight.py run (tests/golden/make_goldens_driver.py: `--corrected
+    --nsplit 3 -t 4`, oracle overlapper behind the minimap2 name): s1.fa, s1_s1.paf, contigs1.gfa, contigs1.fa."""
+    import gzip
+    fq = tmp_path / "fxF_long.fq"
+    with gzip.open(golden.path("fxF_long.fq"), "rb") as f:
+        fq.write_bytes(f.read())
+    out = tmp_path / "OUT"
+    assert driver.main(["-l", str(fq), "-o", str(out), "--corrected", "--nsplit", "3", "-t", "4", "--stop_after", "contigs1"]) == 0
+    assert (out / "1.split_fastx" / "s1.fa").read_text() == golden.text("fxF_s1.fa")
+    assert (out / "2.overlap" / "s1_s1.paf").read_text() == golden.text("fxF_s1_s1.paf")
+    assert (out / "tmp" / "contigs1.gfa").read_text() == golden.text("fxF_contigs1.gfa")
+    assert (out / "tmp" / "contigs1.fa").read_text() == golden.text("fxF_contigs1.fa")
+    assert golden.text("fxF_s1_s1.paf").count("\n") > 100 and golden.text("fxF_contigs1.fa").count(">") >= 1
+
+
+def _contigs(seed, n=14, genome=60_000):
+    """Overlapping pieces of two strains, a few substitutions apart: what extend_con sees (polished contigs)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    _, strains = S.simulate_reads(seed=seed, n_strains=2, genome_len=genome, n_reads=1, snp_rate=0.004)
+    recs = []
+    for k in range(n):
+        g = strains[k % 2]
+        a = int(rng.integers(0, genome - 9000))
+        b = a + int(rng.integers(4000, 9000))
+        seq = g[a:b].copy()
+        if k % 3 == 0:
+            seq = S.revcomp(seq)
+        recs.append((f"longr_con_{k}", seq.tobytes().decode()))
+    recs.append(("tiny", "ACGT" * 30))                    # <= 150 bases: dropped (HyLight.py:297)
+    return recs
+
+
+def test_extend_con_files_match_the_oracle_chain(tmp_path):
+    """HyLight.extend_con (HyLight.py:282-318): contigs_b.fastq, then `minimap2 --sr -X ... -r 0` | v3 filter -sfo |
+    sfo2overlaps - every file against the oracle overlapper + the (reference-pinned) oracle filters."""
+    recs = _contigs(7)
+    fa = tmp_path / "all_contigs.fa"
+    fa.write_text("".join(f">{n}\n{s}\n" for n, s in recs))
+    tmp = tmp_path / "tmp"
+    tmp.mkdir()
+    n = driver.extend_con(str(fa), str(tmp), str(tmp_path / "final_contigs.fa"))
+    assert n == len(recs) - 1
+    fq = (tmp / "contigs_b.fastq").read_text().split("\n")[:-1]
+    assert fq[0::4] == [f"@{k + 1}" for k in range(n)] and fq[1::4] == [s for _, s in recs[:-1]]
+    assert all(q == "=" * len(s) for q, s in zip(fq[3::4], fq[1::4])) and set(fq[2::4]) == {"+"}
+    assert (tmp / "stageb" / "fastq" / "singles.fastq").read_text() == (tmp / "contigs_b.fastq").read_text()
+    o = OA.opts_short()
+    o.pair_once, o.bandwidth = 1, 0
+    OA.ava(tmp / "contigs_b.fastq", tmp / "contigs_b.fastq", tmp_path / "o.paf", o)
+    raw = open(tmp_path / "o.paf").read()
+    assert (tmp / "stageb" / "contigs_ava.paf").read_text() == raw and raw.count("\n") >= 10
+    sfo = F.window_filter(raw.split("\n")[:-1], variant=3, min_len=90, min_iden=0.99, min_o=2, sfo=True)
+    assert (tmp / "stageb" / "sfoverlaps.out").read_text().split("\n")[:-1] == sfo and len(sfo) >= 5
+    assert (tmp / "stageb" / "sfoverlap.out.savage").read_text().split("\n")[:-1] == F.sfo2overlaps(sfo)

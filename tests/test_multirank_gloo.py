@@ -78,20 +78,24 @@ class OracleJob:
         pass
 
 
-def _worker(rank, world, port, fa, out, nsplit):
+def _worker(rank, world, port, fa, out, nsplit, slab):
     import torch.distributed as dist
     from hylight_amd.stage import StageRunner
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    r = StageRunner(fa, fa, nsplit, rank=rank, world=world, job=OracleJob(fa, nsplit), device="cpu")
+    r = StageRunner(fa, fa, nsplit, rank=rank, world=world, job=OracleJob(fa, nsplit), device="cpu", slab=slab)
     n = r.run(out, len_over=1000, mc=2, iden=0.95)
+    with open(f"{out}.rounds{rank}", "w") as f:
+        f.write(str(r.exchange_rounds))
     with open(f"{out}.n{rank}", "w") as f:
         f.write(str(n))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nsplit", [(2, 5)])
-def test_two_ranks_reproduce_the_single_process_stage(tmp_path, world, nsplit):
+@pytest.mark.parametrize("world,nsplit,slab", [(2, 5, 1 << 20), (2, 5, 700), (3, 7, 257)])
+def test_ranks_reproduce_the_single_process_stage(tmp_path, world, nsplit, slab):
+    """slab = minimizers per rank and exchange round: the small values force the streamed exchange through many rounds
+    with a ragged last one (the C4 sketch is 40 GB: SURVEY.md 8e asks for query batches)."""
     from hylight_amd import simulate as S
     from oracle import ava as OA
     from oracle import filters as F
@@ -103,7 +107,7 @@ def test_two_ranks_reproduce_the_single_process_stage(tmp_path, world, nsplit):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, fa, out, nsplit), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, fa, out, nsplit, slab), nprocs=world, join=True)
     # single-process oracle stage
     lines = open(fa).read().split("\n")[:-1]
     chunks = []
@@ -118,3 +122,5 @@ def test_two_ranks_reproduce_the_single_process_stage(tmp_path, world, nsplit):
     per_rank = [int(open(f"{out}.n{r}").read()) for r in range(world)]
     assert sum(per_rank) == len(want) and all(n > 0 for n in per_rank)
     assert not any(os.path.exists(f"{out}.part{r}") for r in range(world))
+    rounds = [int(open(f"{out}.rounds{r}").read()) for r in range(world)]
+    assert len(set(rounds)) == 1 and (rounds[0] > 3 if slab < 1000 else rounds[0] == 1)
