@@ -70,14 +70,21 @@ struct AvaInput {
     // more anchors than this in the run: ava_device stops after the counting pass (AvaRows::refused_anchors is set) so
     // that the caller can come back with fewer chunks (0: no limit; a run of a single chunk is never refused)
     uint64_t max_anchors = 0;
+    // same for the run's output: after the first query batch the rows + CIGARs of the whole run are projected from that
+    // batch's bytes per anchor (divergent read sets carry five times the CIGAR ops per anchor of clean ones)
+    uint64_t max_out_bytes = 0;
 };
+// HBM a run's output occupies until the caller has filtered it: CIGAR ops twice (per batch, then concatenated), the
+// 64-byte records three times (per batch, concatenated, stream-ordered) plus their order keys
+inline uint64_t ava_out_bytes(uint64_t rows, uint64_t ops) { return 8 * ops + 216 * rows; }
 
 struct AvaRows {            // overlapper output in stream order (chunk, query, target, strand, chain, piece)
     size_t n_rows = 0, n_ops = 0;
     DBuf<PafRec> recs;
     DBuf<uint32_t> ops;
     std::vector<uint64_t> chunk_row_start;   // n_chunks+1
-    uint64_t refused_anchors = 0;            // != 0: nothing was computed, the run would have had this many anchors
+    uint64_t refused_anchors = 0;            // != 0: the run was given up, it would have had this many anchors ...
+    double refused_shrink = 1.0;             // ... and fits when the targets shrink by this factor
 };
 void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out);
 

@@ -154,7 +154,11 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     // and no more queries than keep the anchor a single 64-bit word (seed_and_chain: "fits")
     uint64_t total_anchors = 0;
     for (size_t i = 0; i < nQ; ++i) total_anchors += plan.per_query[i];
-    if (in.max_anchors && total_anchors > in.max_anchors && in.n_chunks > 1) { out.refused_anchors = total_anchors; return; }
+    if (in.max_anchors && total_anchors > in.max_anchors && in.n_chunks > 1) {
+        out.refused_anchors = total_anchors;
+        out.refused_shrink = 0.5 * (double)in.max_anchors / (double)total_anchors;
+        return;
+    }
     const uint64_t n_batches = std::max<uint64_t>(1, (total_anchors + anchor_batch - 1) / anchor_batch);
     const uint64_t batch_target = (total_anchors + n_batches - 1) / n_batches;
     size_t q_cap = QUERY_BATCH;
@@ -188,6 +192,14 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
             AlignOut ao;
             HostTimer ht("align_pieces");
             align_pieces(in, o, qlen.p, tlen.p, ch, ao);
+            if (in.max_out_bytes && in.n_chunks > 1 && parts.empty() && acc) {     // first batch with output: project the run
+                const double projected = (double)ava_out_bytes(ao.n_rows, ao.n_ops) / (double)acc * (double)total_anchors;
+                if (projected > (double)in.max_out_bytes) {
+                    out.refused_anchors = total_anchors;
+                    out.refused_shrink = 0.8 * (double)in.max_out_bytes / projected;
+                    return;
+                }
+            }
             if (ao.n_rows) parts.push_back(std::move(ao));
         }
         q = hi;

@@ -93,6 +93,15 @@ __global__ __launch_bounds__(WG) void index_hist_kernel(const uint32_t *run_star
         if (s_h[i]) atomicAdd(&hist[(size_t)(i / HIST_LDS_LEN) * HB + (size_t)(i % HIST_LDS_LEN)], s_h[i]);
 }
 
+// chunk << 32 | run length of every run: sorted, the exact occurrence quantile of a chunk can be read off (used only
+// for chunks whose quantile lies beyond the histogram: extremely repetitive input)
+__global__ void run_len_key_kernel(const uint32_t *run_start, size_t n_runs, size_t n, const uint64_t *y, const uint32_t *chunk_of_t,
+                                   uint64_t *key) {
+    size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    const size_t end = r + 1 < n_runs ? run_start[r + 1] : n;
+    key[r] = (uint64_t)chunk_of_t[y[run_start[r]] >> 32] << 32 | (uint32_t)(end - run_start[r]);
+}
 __global__ void index_rank_kernel(const uint64_t *y, const uint32_t *occ, const uint32_t *mid_occ, const uint32_t *chunk_of_t,
                                   const uint32_t *rank_t, size_t n, uint32_t *rk) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -751,6 +760,7 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint3
                            d_chunk_of_t, hist.p);
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> h = hist.download();
+        DBuf<uint64_t> exact_keys;
         for (uint32_t c = 0; c < n_chunks && o.mid_occ_frac > 0; ++c) {   // frac <= 0: fixed cut-off (-f INT)
             uint64_t nd = 0;
             for (int v = 0; v < HB; ++v) nd += h[(size_t)c * HB + v];
@@ -760,8 +770,19 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint3
             uint64_t cum = 0;
             int v = 0;
             for (; v < HB; ++v) { cum += h[(size_t)c * HB + v]; if (cum > q) break; }
-            if (v >= HB - 1)
-                fail(HLMI_EINVAL, "chunk %u: minimizer occurrence quantile beyond %d (extremely repetitive input)", c, HB - 2);
+            if (v >= HB - 1) {     // beyond the histogram (minimap2 only clamps its cut-off, it never gives up): exact quantile
+                if (!exact_keys.n) {
+                    exact_keys.alloc(n_runs);
+                    hipLaunchKernelGGL(run_len_key_kernel, grid1(n_runs), dim3(WG), 0, stream(), run_start.p, n_runs, n, ix.y.p,
+                                       d_chunk_of_t, exact_keys.p);
+                    sort_keys_u64(exact_keys, n_runs, 0, 64);
+                    HIP_CHECK(hipGetLastError());
+                }
+                uint64_t before = 0;               // runs of the chunks ahead of c
+                for (uint32_t c2 = 0; c2 < c; ++c2) for (int b = 0; b < HB; ++b) before += h[(size_t)c2 * HB + b];
+                v = (int)std::min<uint64_t>((uint32_t)download_one(exact_keys.p + before + q), (uint64_t)MAX_MID_OCC);
+                stat_add("index_exact_quantiles", 1);
+            }
             int t = v + 1;
             if (t > (int)mid[c]) mid[c] = (uint32_t)t;
             if (mid[c] > (uint32_t)MAX_MID_OCC) mid[c] = MAX_MID_OCC;

@@ -123,7 +123,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     std::vector<uint32_t> my_chunks;
     for (size_t c = 0; c < m.chunks.size(); ++c)
         if ((int)(c % (size_t)world) == rank) my_chunks.push_back((uint32_t)c);
-    constexpr double SUBRUN_ANCHORS = 1.2e10;
+    constexpr double SUBRUN_ANCHORS = 1.2e10, SUBRUN_OUT_BYTES = 64e9;
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
     constexpr double SUBRUN_ANCHORS_MAX = 2.4e10;
     uint64_t budget_bases = 96ull << 20;
@@ -136,7 +136,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     double t_ava = 0, t_flt = 0, t_fmt = 0;
     size_t n_v4 = 0, n_ev = 0, n_pairs = 0, n_subruns = 0;
     uint64_t done_bases = 0;
-    double done_anchors = 0;
+    double done_anchors = 0, done_out_bytes = 0;
     for (size_t ci = 0; ci < my_chunks.size() && m.Q.size();) {
         std::vector<uint32_t> sub_tids, chunk_of_t;
         uint32_t n_my = 0;
@@ -166,11 +166,12 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         in.n_ranks = m.name_of_rank.size();
         if (m.dT == &m.dQ) in.t_query = sub_tids;     // reads vs themselves: the targets' minimizers are in the query sketch
         in.max_anchors = (uint64_t)SUBRUN_ANCHORS_MAX;
+        in.max_out_bytes = (uint64_t)(1.5 * SUBRUN_OUT_BYTES);
         AvaRows rows;
         const double a0 = stats()["anchors"];
         ava_device(in, m.opts, rows);
         if (rows.refused_anchors) {           // deeper than the estimate: come back with fewer chunks
-            budget_bases = std::max<uint64_t>(1, (uint64_t)(0.8 * SUBRUN_ANCHORS * (double)sub_bases / (double)rows.refused_anchors));
+            budget_bases = std::max<uint64_t>(1, (uint64_t)(rows.refused_shrink * (double)sub_bases));
             ci -= n_my;
             stat_add("subruns_refused", 1);
             continue;
@@ -179,8 +180,12 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         ++n_subruns;
         done_bases += sub_bases;
         done_anchors += stats()["anchors"] - a0;
-        if (!fixed_budget && done_anchors > 0)
-            budget_bases = std::min<uint64_t>(SUBRUN_MAX_BASES, std::max<uint64_t>(16ull << 20, (uint64_t)(SUBRUN_ANCHORS * (double)done_bases / done_anchors)));
+        done_out_bytes += (double)ava_out_bytes(rows.n_rows, rows.n_ops);
+        if (!fixed_budget && done_anchors > 0) {        // next sub-run: as many target bases as give ~SUBRUN_ANCHORS anchors and
+            const double by_anchors = SUBRUN_ANCHORS * (double)done_bases / done_anchors;      // ~SUBRUN_OUT_BYTES of output
+            const double by_bytes = done_out_bytes > 0 ? SUBRUN_OUT_BYTES * (double)done_bases / done_out_bytes : by_anchors;
+            budget_bases = std::min<uint64_t>(SUBRUN_MAX_BASES, std::max<uint64_t>(4ull << 20, (uint64_t)std::min(by_anchors, by_bytes)));
+        }
         const double t1 = now_s();
         t_ava += t1 - ts0;
         FilterCfg cfg;

@@ -3,7 +3,7 @@
 import os
 
 
-def check_rows(path, len_over, iden, min_rows):
+def check_rows(path, len_over, iden, min_rows, pair_once=True):
     """14 columns + trailing TAB, one row per unordered pair, overhang rule, scores as printed, sort -k12 -nr."""
     seen = set()
     prev = None
@@ -15,8 +15,8 @@ def check_rows(path, len_over, iden, min_rows):
             int(c[7]), int(c[8]), int(c[9]), int(c[10])
         assert q != t and mc >= len_over                           # slr2:101-105 (column 10 against min_ovlp_len)
         key = (q, t) if q < t else (t, q)
-        assert key not in seen                                     # slr2:133-136
-        seen.add(key)
+        assert key not in seen or not pair_once                    # slr2:133-136 (per chunk: with both directions reported,
+        seen.add(key)                                              #  a pair may come back from another chunk)
         if strand == "-":
             ts, te = tl - te, tl - ts
         assert min(qs, ts) + min(ql - qe, tl - te) <= min(4, max(qe - qs, te - ts) * 0.8)      # slr2:116-131

@@ -227,3 +227,22 @@ def test_split_reads2_matches_oracle_pipeline(tmp_path):
     assert got == want
     st = api.last_stats()
     assert st["rows_out"] == len(want)
+
+
+def test_ava_extremely_repetitive_chunk(tmp_path):
+    """1030 copies of one 160-base read in a chunk: the occurrence count at the (1 - 2e-4) quantile of the chunk's
+    distinct minimizers lies beyond the 1024-bin histogram the index keeps per chunk; the cut-off then comes from the
+    exact quantile (minimap2 would only clamp its mid_occ and carry on) and the run completes like the oracle's."""
+    rng = np.random.default_rng(3)
+    unit = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=160)]
+    reads = [S.Read(f"rep{i:04d}", unit.copy(), None, 0, 0, 0, False) for i in range(1030)]
+    more, _ = S.simulate_reads(seed=4, n_strains=1, genome_len=20000, n_reads=20, mean_len=4000, min_len=2000, max_len=6000,
+                               name_prefix="u")
+    fa = tmp_path / "rep.fa"
+    S.write_fasta(reads + more, fa)
+    api.ava(fa, fa, tmp_path / "g.paf")
+    assert api.last_stats().get("index_exact_quantiles", 0) >= 1
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    got, want = open(tmp_path / "g.paf").read(), open(tmp_path / "o.paf").read()
+    assert want.count("\n") > 500_000
+    assert got == want

@@ -1,0 +1,67 @@
+"""GPU: BASELINE.json configs[4] (C5: 50 strains, ANI 95-99 %, 1 % / 0.5 % / 0.5 % read errors, --min_identity 0.90
+--min_ovlp_len 1500) with its REAL recipe at the largest size a pass of which stays under a minute on one card:
+scale 0.06 = 30 000 reads on 50 x 120 kb genomes, i.e. the configured 2 500x pooled depth and divergence with fewer
+reads (the full 500 000 reads are ~280 passes of this size; a pass of 50 000 reads takes 79 s, of 100 000 reads 128 s).
+Four fifths of the alignment tasks need a DP here and most of those are 64-diagonal end extensions of short chain
+fragments: the stress the config names ("banded-DP LDS occupancy").  CIGAR ops per anchor are five times those of C3,
+which is what sizes the sub-runs (csrc/stage.cpp).  Checks: row predicates and order, slices merge to the unsharded
+pass (= determinism across different batchings), the fallback DP forms agree on a slice."""
+import os
+
+import pytest
+
+from fullsize import check_rows, same_file
+from hylight_amd import api
+from hylight_amd import workloads as W
+from hylight_amd.stage import StageRunner
+
+pytestmark = pytest.mark.gpu
+SCALE = 0.06
+
+
+@pytest.fixture(scope="module")
+def c5(tmp_path_factory):
+    d = tmp_path_factory.mktemp("c5")
+    cfg = W.config("C5", SCALE)
+    fa = str(d / "s1.fa")
+    n, bases, _ = W.make_long(cfg, fa)
+    assert n == 30_000
+    r = StageRunner(fa, fa, cfg["nsplit"], long_mode=True)
+    out = str(d / "s1_s1.paf")
+    rows = r.run(out, **cfg["stage"])
+    st = api.last_stats()
+    yield d, cfg, r, out, rows, st
+    r.close()
+
+
+def test_c5_is_dp_bound_and_rows_are_valid(c5):
+    d, cfg, r, out, rows, st = c5
+    assert st["align_tasks_dp"] > 0.6 * st["align_tasks"] and st["anchors"] > 5e9 and st["subruns"] >= 2
+    assert st["cigar_ops"] > 3 * st["anchors"]            # five times C3's ops per anchor
+    check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 500)
+    assert rows == sum(1 for _ in open(out))
+
+
+def test_c5_slices_merge_to_the_full_pass(c5):
+    d, cfg, r, out, rows, st = c5
+    parts = []
+    for k in range(4):
+        p = str(d / f"slice{k}.paf")
+        r.run(p, share=(k, 4), **cfg["stage"])
+        parts.append(p)
+    merged = str(d / "merged.paf")
+    api.merge_scored_paf(parts, merged)
+    assert same_file(merged, out)
+
+
+@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_CHAIN_UNPACKED"])
+def test_c5_fallback_forms_agree_on_a_slice(c5, monkeypatch, var):
+    d, cfg, r, out, rows, st = c5
+    monkeypatch.setenv(var, "1")
+    alt = str(d / f"alt_{var}.paf")
+    r.run(alt, share=(7, 12), **cfg["stage"])
+    monkeypatch.delenv(var)
+    ref = str(d / "ref_slice.paf")
+    if not os.path.exists(ref):
+        r.run(ref, share=(7, 12), **cfg["stage"])
+    assert same_file(alt, ref)
