@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "dev_prims.h"
+#include "wave_ops.h"
 
 namespace hlmi {
 
@@ -349,12 +350,8 @@ __global__ void pair_order_select_kernel(const PafRec *recs, const uint32_t *ops
 // wave prefix sums, every 'X' lane writes its own events.
 constexpr uint32_t NO_PAIR = 0xffffffffu;
 __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)v, o, 64);
-        if (lane >= o) v += u;
-    }
-    return v;
+    (void)lane;
+    return wave_prefix_sum_incl_dpp(v);
 }
 
 // maxv[0] / maxv[1]: largest read id / read length among the selected rows (they size the event sort key)
@@ -484,6 +481,320 @@ __global__ void snp_pair_count_kernel(const uint32_t *ev_pair_sorted, const uint
         const uint32_t pg = ev_pair_sorted[i];
         if (pg != NO_PAIR) atomicAdd(&pair_mut[pg], 1u);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// a5 + a6 without materialised events: one workgroup per (chunk, read)
+// ---------------------------------------------------------------------------------------
+// A SNP key is (chunk, read, position) and everything the reference asks about it - how many selected rows put an X
+// there (v), how many of the read's intervals span it (con) - is local to one read of one chunk.  So the selected rows
+// are listed once under their target read and (long mode) once under their query read, the list is sorted by
+// (chunk, read), and a workgroup takes one read: two 16-bit arrays over the read's positions in LDS hold first the
+// interval starts / ends (prefix-summed into the coverage), then the X counts; a second walk over the same CIGARs
+// bumps the pair counter of every event whose key is supported (slr2:370-405).  Nothing per event ever goes to memory:
+// the sort of 2.7e9 16-byte events per C3 slice is replaced by a sort of 2.4e7 row references.
+constexpr int PILE_TILE = 15360;             // positions per pass (2 x 16-bit x 15360 = 60 KiB of LDS); longer reads: several passes
+constexpr int PILE_WG_HEAVY = 1024;          // reads with many rows in the chunk: one wave walks one row at a time
+constexpr int PILE_LIGHT_ROWS = 16;          // reads with at most this many rows take snp_pileup_light_kernel
+constexpr int PILE_EV_SLOTS = 4096;           // the event statistic is summed over this many counters (one word would
+                                             // serialise millions of atomics)
+constexpr uint32_t PILE_MAX_ROWS = 60000;    // rows per (chunk, read): the counters are 16 bit
+
+// entry of row i (position in the grouped row list) under one of its reads: key = chunk << 32 | read, val = i << 1 | side
+// (side 0: the read is the row's target, 1: its query).  Unselected rows get the sentinel key.
+__global__ void pile_entries_kernel(const PafRec *recs, const uint32_t *grows, const uint8_t *sel, size_t m, int long_mode,
+                                    uint64_t *key, uint32_t *val) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint64_t kt = ~0ull, kq = ~0ull;
+    if (sel[i]) {
+        const PafRec &r = recs[grows[i]];
+        kt = (uint64_t)r.chunk << 32 | r.tid;
+        if (long_mode) kq = (uint64_t)r.chunk << 32 | r.qid;
+    }
+    key[2 * i] = kt; val[2 * i] = (uint32_t)(i << 1);
+    key[2 * i + 1] = kq; val[2 * i + 1] = (uint32_t)(i << 1 | 1u);
+}
+__global__ void pile_entry_rows_kernel(const uint32_t *ent_val, const uint32_t *grows, size_t n, uint32_t *ent_rec) {
+    size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (k < n) ent_rec[k] = grows[ent_val[k] >> 1];
+}
+__global__ void add_one_u8_kernel(const uint8_t *in, uint8_t *out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + 1;
+}
+__global__ void pile_seg_size_kernel(const uint32_t *seg_start, size_t n_seg, size_t n_ent, uint32_t *max_rows) {
+    size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const uint32_t n = (uint32_t)((s + 1 < n_seg ? seg_start[s + 1] : n_ent) - seg_start[s]);
+    if (n > __hip_atomic_load(max_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_rows, n);
+}
+
+// counters of 8 or 16 bits packed into 32-bit LDS words (LDS atomics are 32 bit wide; a counter never overflows into its
+// neighbour: it counts rows of the segment, and the segment's class bounds those)
+template <typename CT> __device__ __forceinline__ void lds_inc(uint32_t *a, uint32_t idx) {
+    constexpr uint32_t per = 4 / sizeof(CT);
+    atomicAdd(&a[idx / per], 1u << (8 * sizeof(CT) * (idx % per)));
+}
+template <typename CT> __device__ __forceinline__ uint32_t lds_get(const uint32_t *a, uint32_t idx) { return ((const CT *)a)[idx]; }
+
+// class of every segment: 0 = fewer than 2 mc rows (no key can be supported), 1 = light, 2 = heavy
+__global__ void pile_seg_class_kernel(const uint32_t *seg_start, size_t n_seg, size_t n_ent, int mc, uint8_t *cls) {
+    size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const uint32_t n = (uint32_t)((s + 1 < n_seg ? seg_start[s + 1] : n_ent) - seg_start[s]);
+    cls[s] = (long long)n < 2ll * mc ? 0 : (n <= (uint32_t)PILE_LIGHT_ROWS ? 1 : 2);
+}
+// X events of the rows under segments nobody piles (statistics only): one wave per entry
+__global__ __launch_bounds__(WG) void pile_tiny_events_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *grows,
+                                                               const uint32_t *ent_val, const uint32_t *seg_start, const uint32_t *list,
+                                                               size_t n_list, size_t n_seg, size_t n_ent, unsigned long long *n_events) {
+    const int lane = threadIdx.x & 63;
+    const size_t w = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    if (w >= n_list) return;
+    const size_t seg = list[w];
+    const size_t b = seg_start[seg], e = seg + 1 < n_seg ? seg_start[seg + 1] : n_ent;
+    unsigned long long ev = 0;
+    for (size_t k = b; k < e; ++k) {
+        const PafRec &r = recs[grows[ent_val[k] >> 1]];
+        const uint32_t *o = ops + r.cig_off;
+        for (uint32_t k0 = 0; k0 < r.cig_n; k0 += 64)
+            ev += (unsigned long long)__popcll(__ballot(k0 + lane < r.cig_n && (o[k0 + lane] & 15u) == OP_X));
+    }
+    if (lane == 0 && ev) atomicAdd(&n_events[w & (PILE_EV_SLOTS - 1)], ev);
+}
+
+template <int PILE_WG, typename CT>
+__global__ __launch_bounds__(PILE_WG) void snp_pileup_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *ent_rec,
+                                                              const uint32_t *row_pair, const uint64_t *ent_key, const uint32_t *ent_val,
+                                                              const uint32_t *seg_start, const uint32_t *list, size_t n_seg, size_t n_ent,
+                                                              int long_mode, int mc, uint32_t *pair_mut, unsigned long long *n_events) {
+    constexpr uint32_t PER = 4 / sizeof(CT);                          // counters per LDS word
+    __shared__ uint32_t sA[PILE_TILE / PER], sB[PILE_TILE / PER];
+    __shared__ uint32_t s_part[2][PILE_WG / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t seg = list[blockIdx.x];
+    const size_t b = seg_start[seg], e = seg + 1 < n_seg ? seg_start[seg + 1] : n_ent;
+    // the read's length as its rows state it (a PAF file may disagree with itself: take the largest claim)
+    __shared__ uint32_t s_len;
+    if (tid == 0) s_len = 0;
+    __syncthreads();
+    {
+        uint32_t l = 0;
+        for (size_t k = b + (size_t)tid; k < e; k += PILE_WG) {
+            const uint32_t v = ent_val[k];
+            const PafRec &r = recs[ent_rec[k]];
+            l = max(l, (v & 1u) ? r.qlen : r.tlen);
+        }
+        if (l) atomicMax(&s_len, l);
+    }
+    __syncthreads();
+    const uint32_t read_len = s_len;
+    // the X events of one row, one wave: f(position on this read, lane has an event).  Only the walked side's
+    // positions are tracked (one wave scan per 64 ops): query side = ops that consume query bases (= X I), target side
+    // = ops that consume target bases (= X D)   (slr2:334-365)
+    auto walk = [&](const PafRec &r, bool qside, auto &&f) {
+        const bool rev = r.flags & PF_REV;
+        uint32_t p = qside ? (rev ? r.qlen - r.qe : r.qs) : r.ts;
+        const uint32_t skip = qside ? OP_D : OP_I;
+        const uint32_t *o = ops + r.cig_off;
+        // four loads of 64 ops in flight (a row of C3 has ~280 ops: one round trip to memory instead of five)
+        for (uint32_t k0 = 0; k0 < r.cig_n; k0 += 256) {
+            uint32_t opv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t idx = k0 + 64u * u + lane; opv[u] = idx < r.cig_n ? o[idx] : skip; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + 64u * u >= r.cig_n) break;
+                const uint32_t len = opv[u] >> 4, code = opv[u] & 15u;
+                const bool isx = code == OP_X;
+                const uint32_t sc = wave_prefix_sum_incl_dpp(code == skip ? 0u : len);
+                const uint32_t after = p + sc;                           // position after this op
+                f(qside && rev ? r.qlen - after + 1 : after, isx);        // slr2:357 / :361
+                p += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+            }
+        }
+    };
+    unsigned long long ev = 0;
+    for (uint32_t t0 = 0; t0 < read_len + 2; t0 += PILE_TILE) {
+        const uint32_t n_pos = min((uint32_t)PILE_TILE, read_len + 2 - t0), n_words = (n_pos + PER - 1) / PER;
+        for (uint32_t w = tid; w < n_words; w += PILE_WG) { sA[w] = 0; sB[w] = 0; }
+        __syncthreads();
+        // intervals: A counts starts at s + 1, B counts ends at e (con = #(s < pos) - #(e <= pos), strict on both sides)
+        for (size_t k = b + (size_t)tid; k < e; k += PILE_WG) {
+            const uint32_t v = ent_val[k];
+            const PafRec &r = recs[ent_rec[k]];
+            const uint32_t s0 = (v & 1u) ? r.qs : r.ts, e0 = (v & 1u) ? r.qe : r.te;
+            if (s0 < e0) {
+                const uint32_t ia = max(s0 + 1, t0) - t0, ib = max(e0, t0) - t0;
+                if (ia < n_pos) lds_inc<CT>(sA, ia);
+                if (ib < n_pos) lds_inc<CT>(sB, ib);
+            }
+        }
+        __syncthreads();
+        {   // prefix sums of both arrays, coverage = A - B into A, B cleared: every thread owns a contiguous stretch
+            const uint32_t per = (n_pos + PILE_WG - 1) / PILE_WG, lo = min(n_pos, (uint32_t)tid * per), hi = min(n_pos, lo + per);
+            uint32_t ta = 0, tb = 0;
+            for (uint32_t i = lo; i < hi; ++i) { ta += lds_get<CT>(sA, i); tb += lds_get<CT>(sB, i); }
+            // exclusive offsets of the stretches: wave scan, then the totals of the waves before
+            const uint32_t ia = wave_prefix_sum_incl_dpp(ta), ib = wave_prefix_sum_incl_dpp(tb);
+            if (lane == 63) { s_part[0][wave] = ia; s_part[1][wave] = ib; }
+            __syncthreads();                               // (also: every stretch total has been read before the arrays change)
+            uint32_t oa = ia - ta, ob = ib - tb;
+            for (int w = 0; w < wave; ++w) { oa += s_part[0][w]; ob += s_part[1][w]; }
+            // stretches share words at odd boundaries: write 16-bit halves with atomics-free read-modify-write of OWN halves only
+            CT *ca = (CT *)sA, *cb = (CT *)sB;
+            for (uint32_t i = lo; i < hi; ++i) {
+                oa += ca[i]; ob += cb[i];
+                ca[i] = (CT)(oa - ob);
+                cb[i] = 0;
+            }
+        }
+        __syncthreads();
+        // X counts
+        for (size_t k = b + (size_t)wave; k < e; k += PILE_WG / 64) {
+            const uint32_t v = ent_val[k];
+            const PafRec r = recs[ent_rec[k]];
+            walk(r, (v & 1u) != 0, [&](uint32_t pos, bool isx) {
+                if (isx && pos >= t0 && pos - t0 < n_pos) lds_inc<CT>(sB, pos - t0);
+                if (t0 == 0) ev += (unsigned long long)__popcll(__ballot(isx));
+            });
+        }
+        __syncthreads();
+        // supported keys -> their rows' pair counters
+        for (size_t k = b + (size_t)wave; k < e; k += PILE_WG / 64) {
+            const uint32_t v = ent_val[k];
+            const uint32_t pg = row_pair[v >> 1];
+            if (pg == NO_PAIR) continue;                   // nobody reads this pair's counter (uniform across the wave)
+            const PafRec r = recs[ent_rec[k]];
+            uint32_t hits = 0;
+            walk(r, (v & 1u) != 0, [&](uint32_t pos, bool isx) {
+                if (isx && pos >= t0 && pos - t0 < n_pos) {
+                    const int cnt = (int)lds_get<CT>(sB, pos - t0), cov = (int)lds_get<CT>(sA, pos - t0);
+                    if (cnt >= mc && cov - cnt >= mc) ++hits;
+                }
+            });
+            hits = wave_incl_sum_u32(hits, lane);
+            if (lane == 63 && hits) atomicAdd(&pair_mut[pg], hits);
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && ev) atomicAdd(&n_events[(blockIdx.x * 16u + (uint32_t)wave) & (PILE_EV_SLOTS - 1)], ev);
+}
+
+// Reads with at most PILE_LIGHT_ROWS rows in the chunk (nearly every (chunk, query) pair: a chunk holds ~500 of the
+// 100 000 reads a query could overlap): eight waves, every wave walks at most two rows ONCE and keeps the event
+// positions in registers; one 8-bit array of X counts over the read's positions in LDS; the coverage of the few
+// positions that reach mc is counted directly from the segment's interval list.  One trip to memory per row, 15 KiB
+// of LDS per workgroup.
+constexpr int PILE_LIGHT_WG = 512, PILE_LIGHT_IT = 6;      // 6 x 64 CIGAR ops per row are cached
+__global__ __launch_bounds__(PILE_LIGHT_WG) void snp_pileup_light_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *ent_rec,
+                                                                          const uint32_t *row_pair, const uint32_t *ent_val,
+                                                                          const uint32_t *seg_start, const uint32_t *list, size_t n_seg,
+                                                                          size_t n_ent, int mc, uint32_t *pair_mut,
+                                                                          unsigned long long *n_events) {
+    __shared__ uint32_t sV[PILE_TILE / 4];                            // four 8-bit counters per word
+    __shared__ uint32_t s_is[PILE_LIGHT_ROWS], s_ie[PILE_LIGHT_ROWS], s_len;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t seg = list[blockIdx.x];
+    const size_t b = seg_start[seg], e = seg + 1 < n_seg ? seg_start[seg + 1] : n_ent;
+    const int n_rows = (int)(e - b);
+    if (tid == 0) s_len = 0;
+    __syncthreads();
+    // ---- every wave: its (at most two) rows, walked once ---------------------------------------------------------------
+    uint32_t pos[2][PILE_LIGHT_IT];
+    uint32_t xm[2] = {0, 0}, pg[2] = {NO_PAIR, NO_PAIR};
+    bool spill[2] = {false, false};                                    // row longer than the cache: walked again per phase
+    PafRec rr[2];
+    bool side[2] = {false, false};
+    unsigned long long ev = 0;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int k = wave + 8 * sl;
+        if (k >= n_rows) continue;
+        const uint32_t v = ent_val[b + k];
+        const PafRec r = recs[ent_rec[b + k]];
+        rr[sl] = r; side[sl] = (v & 1u) != 0;
+        pg[sl] = row_pair[v >> 1];
+        const bool qside = side[sl], rev = r.flags & PF_REV;
+        if (lane == 0) {
+            const uint32_t s0 = qside ? r.qs : r.ts, e0 = qside ? r.qe : r.te;
+            s_is[k] = s0 < e0 ? s0 : 0; s_ie[k] = s0 < e0 ? e0 : 0;
+            atomicMax(&s_len, qside ? r.qlen : r.tlen);
+        }
+        spill[sl] = r.cig_n > 64u * PILE_LIGHT_IT;
+        uint32_t p = qside ? (rev ? r.qlen - r.qe : r.qs) : r.ts;
+        const uint32_t skip = qside ? OP_D : OP_I;
+        const uint32_t *o = ops + r.cig_off;
+        uint32_t opv[PILE_LIGHT_IT];
+#pragma unroll
+        for (int u = 0; u < PILE_LIGHT_IT; ++u) { const uint32_t idx = 64u * u + lane; opv[u] = idx < r.cig_n ? o[idx] : skip; }
+#pragma unroll
+        for (int u = 0; u < PILE_LIGHT_IT; ++u) {
+            const uint32_t len = opv[u] >> 4, code = opv[u] & 15u;
+            const uint32_t sc = wave_prefix_sum_incl_dpp(code == skip ? 0u : len);
+            const uint32_t after = p + sc;
+            pos[sl][u] = qside && rev ? r.qlen - after + 1 : after;
+            if (code == OP_X) xm[sl] |= 1u << u;
+            p += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+        }
+        // events of the row (statistics): all its ops, cached or not
+        for (uint32_t k0 = 0; k0 < r.cig_n; k0 += 64)
+            ev += (unsigned long long)__popcll(__ballot(k0 + lane < r.cig_n && (k0 < 64u * PILE_LIGHT_IT ? ((xm[sl] >> (k0 >> 6)) & 1u) != 0
+                                                                                 : (o[k0 + lane] & 15u) == OP_X)));
+    }
+    __syncthreads();
+    const uint32_t read_len = s_len;
+    // the uncached tail of a long row: f(position, is X) for the ops from 64 * PILE_LIGHT_IT on
+    auto tail = [&](int sl, auto &&f) {
+        const PafRec &r = rr[sl];
+        const bool qside = side[sl], rev = r.flags & PF_REV;
+        const uint32_t skip = qside ? OP_D : OP_I;
+        const uint32_t *o = ops + r.cig_off;
+        uint32_t p = qside ? (rev ? r.qlen - r.qe : r.qs) : r.ts;
+        for (uint32_t k0 = 0; k0 < r.cig_n; k0 += 64) {
+            uint32_t len = 0, code = skip;
+            if (k0 + lane < r.cig_n) { const uint32_t op = o[k0 + lane]; len = op >> 4; code = op & 15u; }
+            const uint32_t sc = wave_prefix_sum_incl_dpp(code == skip ? 0u : len);
+            const uint32_t after = p + sc;
+            if (k0 >= 64u * PILE_LIGHT_IT) f(qside && rev ? r.qlen - after + 1 : after, code == OP_X);
+            p += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+        }
+    };
+    for (uint32_t t0 = 0; t0 < read_len + 2; t0 += PILE_TILE) {
+        const uint32_t n_pos = min((uint32_t)PILE_TILE, read_len + 2 - t0);
+        for (uint32_t w = tid; w < (n_pos + 3) / 4; w += PILE_LIGHT_WG) sV[w] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (wave + 8 * sl >= n_rows) continue;
+#pragma unroll
+            for (int u = 0; u < PILE_LIGHT_IT; ++u)
+                if (((xm[sl] >> u) & 1u) && pos[sl][u] >= t0 && pos[sl][u] - t0 < n_pos) lds_inc<uint8_t>(sV, pos[sl][u] - t0);
+            if (spill[sl]) tail(sl, [&](uint32_t q, bool isx) { if (isx && q >= t0 && q - t0 < n_pos) lds_inc<uint8_t>(sV, q - t0); });
+        }
+        __syncthreads();
+        auto supported = [&](uint32_t q) {
+            const int cnt = (int)lds_get<uint8_t>(sV, q - t0);
+            if (cnt < mc) return false;
+            int cov = 0;                                              // slr2:383-392: intervals with start < q < end
+            for (int i = 0; i < n_rows; ++i) cov += (s_is[i] < q && q < s_ie[i]) ? 1 : 0;
+            return cov - cnt >= mc;
+        };
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (wave + 8 * sl >= n_rows || pg[sl] == NO_PAIR) continue;
+            uint32_t hits = 0;
+#pragma unroll
+            for (int u = 0; u < PILE_LIGHT_IT; ++u)
+                if (((xm[sl] >> u) & 1u) && pos[sl][u] >= t0 && pos[sl][u] - t0 < n_pos && supported(pos[sl][u])) ++hits;
+            if (spill[sl]) tail(sl, [&](uint32_t q, bool isx) { if (isx && q >= t0 && q - t0 < n_pos && supported(q)) ++hits; });
+            hits = wave_prefix_sum_incl_dpp(hits);
+            if (lane == 63 && hits) atomicAdd(&pair_mut[pg[sl]], hits);
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && ev) atomicAdd(&n_events[(blockIdx.x * 16u + (uint32_t)wave) & (PILE_EV_SLOTS - 1)], ev);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -661,6 +972,66 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
                        n_pseg, m, lm, sel.p);
 
     ht.reset(); ht.reset(new HostTimer("filter_events"));
+    DBuf<uint32_t> pair_mut(n_pseg);
+    pair_mut.zero();
+    // ---- a5 + a6: per-read pile-up in LDS (the sort-based form below stays as the form very deep reads take) ---------
+    bool piled = false;
+    if (!getenv("HLMI_SNP_SORT")) {
+        DBuf<uint64_t> ekey(2 * m);
+        DBuf<uint32_t> eval(2 * m);
+        hipLaunchKernelGGL(pile_entries_kernel, grid1(m), dim3(WG), 0, stream(), d_recs, grows.p, sel.p, m, lm, ekey.p, eval.p);
+        sort_pairs_u64_u32(ekey, eval, 2 * m, 0, 32 + bits_for(n_chunks > 1 ? n_chunks - 1 : 1));
+        DBuf<uint32_t> eseg(2 * m);
+        // (the sentinel keys of unselected rows form the last run: it is not a segment)
+        size_t n_eseg = select_run_heads_u64(ekey.p, 2 * m, 0, eseg.p);
+        size_t n_ent = 2 * m;
+        if (n_eseg && download_one(ekey.p + (2 * m - 1)) == ~0ull) { --n_eseg; n_ent = download_one(eseg.p + n_eseg); }
+        DBuf<uint32_t> max_rows(1);
+        max_rows.zero();
+        if (n_eseg) hipLaunchKernelGGL(pile_seg_size_kernel, grid1(n_eseg), dim3(WG), 0, stream(), eseg.p, n_eseg, n_ent, max_rows.p);
+        if (!n_eseg || download_one(max_rows.p) <= PILE_MAX_ROWS) {
+            DBuf<uint32_t> row_pair(m);
+            DBuf<unsigned long long> n_ev_d(PILE_EV_SLOTS);
+            n_ev_d.zero();
+            hipLaunchKernelGGL(pair_live_kernel, grid1(n_pseg), dim3(WG), 0, stream(), d_recs, grows.p, pseg_start.p, n_pseg, m,
+                               cfg.len_over, cfg.min_o, row_pair.p);
+            if (n_eseg) {
+                // a key needs v >= mc rows with an X and mc further spanning rows: reads with fewer than 2 mc rows in the
+                // chunk cannot carry one (their events only count for the statistics); the others are piled, reads
+                // with many rows by large workgroups (one wave walks one row at a time)
+                DBuf<uint32_t> erec(n_ent);
+                hipLaunchKernelGGL(pile_entry_rows_kernel, grid1(n_ent), dim3(WG), 0, stream(), eval.p, grows.p, n_ent, erec.p);
+                DBuf<uint8_t> cls(n_eseg);
+                hipLaunchKernelGGL(pile_seg_class_kernel, grid1(n_eseg), dim3(WG), 0, stream(), eseg.p, n_eseg, n_ent, cfg.mc, cls.p);
+                DBuf<uint32_t> l0(n_eseg), l1(n_eseg), l2(n_eseg), l3(1), cnt4(4);
+                DBuf<uint8_t> cls1(n_eseg);
+                hipLaunchKernelGGL(add_one_u8_kernel, grid1(n_eseg), dim3(WG), 0, stream(), cls.p, cls1.p, n_eseg);
+                select_classes4_async(cls1.p, n_eseg, l0.p, l1.p, l2.p, l3.p, cnt4.p);
+                const std::vector<uint32_t> nc = cnt4.download(4);
+                if (nc[0]) hipLaunchKernelGGL(pile_tiny_events_kernel, dim3(cdiv(nc[0], (size_t)(WG / 64))), dim3(WG), 0, stream(), d_recs,
+                                              d_ops, grows.p, eval.p, eseg.p, l0.p, (size_t)nc[0], n_eseg, n_ent, n_ev_d.p);
+                if (nc[1]) {
+                    KTimer kt("filter_pileup_light");
+                    hipLaunchKernelGGL(snp_pileup_light_kernel, dim3(nc[1]), dim3(PILE_LIGHT_WG), 0, stream(), d_recs, d_ops, erec.p,
+                                       row_pair.p, eval.p, eseg.p, l1.p, n_eseg, n_ent, cfg.mc, pair_mut.p, n_ev_d.p);
+                }
+                if (nc[2]) {
+                    KTimer kt("filter_pileup_heavy");
+                    hipLaunchKernelGGL((snp_pileup_kernel<PILE_WG_HEAVY, uint16_t>), dim3(nc[2]), dim3(PILE_WG_HEAVY), 0, stream(), d_recs, d_ops, erec.p,
+                                       row_pair.p, ekey.p, eval.p, eseg.p, l2.p, n_eseg, n_ent, lm, cfg.mc, pair_mut.p, n_ev_d.p);
+                }
+            }
+            HIP_CHECK(hipGetLastError());
+            {
+                const std::vector<unsigned long long> evs = n_ev_d.download(PILE_EV_SLOTS);
+                unsigned long long tot = 0;
+                for (unsigned long long v : evs) tot += v;
+                out.n_events = (size_t)tot;
+            }
+            piled = true;
+        }
+    }
+    if (!piled) {
     // ---- a5: events + intervals -------------------------------------------------------------------
     DBuf<uint32_t> n_ev(m), n_iv(m), ev_off(m), iv_off(m);
     const dim3 rows_grid((unsigned)std::min<size_t>(cdiv(m ? m : 1, WG / 64), 65536));    // one wave per row, grid-stride
@@ -673,8 +1044,6 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     const size_t E = (size_t)download_one(ev_off.p + (m - 1)) + download_one(n_ev.p + (m - 1));
     const size_t I = (size_t)download_one(iv_off.p + (m - 1)) + download_one(n_iv.p + (m - 1));
     out.n_events = E;
-    DBuf<uint32_t> pair_mut(n_pseg);
-    pair_mut.zero();
     if (E) {
         // one sort word per event / interval end: chunk | read | position, as wide as this call's ids and lengths need
         const std::vector<uint32_t> mx = maxv.download(2);
@@ -709,6 +1078,8 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     }
         HIP_CHECK(hipGetLastError());
         sync();
+    }
+
     }
 
     ht.reset(); ht.reset(new HostTimer("filter_pass2_order"));

@@ -126,7 +126,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     constexpr double SUBRUN_ANCHORS = 1.2e10, SUBRUN_OUT_BYTES = 64e9;
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
     constexpr double SUBRUN_ANCHORS_MAX = 2.4e10;
-    uint64_t budget_bases = 96ull << 20;
+    uint64_t budget_bases = 128ull << 20;
     if (const char *e = getenv("HLMI_SUBRUN_MBASES")) budget_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
     const bool fixed_budget = getenv("HLMI_SUBRUN_MBASES") != nullptr;
     // the rows' text: every formatting thread appends to a buffer of its own, `lines` are views into those buffers

@@ -60,6 +60,19 @@ __device__ __forceinline__ int wave_prefix_max_incl_dpp(int x) {
     return x;
 }
 
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside every row of 16, then the row totals travel down
+// (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); lanes without a source add 0
+__device__ __forceinline__ uint32_t wave_prefix_sum_incl_dpp(uint32_t v) {
+    int x = (int)v;
+    x += dpp_i32<0x111>(0, x);
+    x += dpp_i32<0x112>(0, x);
+    x += dpp_i32<0x114>(0, x);
+    x += dpp_i32<0x118>(0, x);
+    x += dpp_i32<0x142, 0xa>(0, x);
+    x += dpp_i32<0x143, 0xc>(0, x);
+    return (uint32_t)x;
+}
+
 // ---- the same inside rows of 16 lanes (four independent 16-lane groups per wave) -------------------
 // lane l <- lane l+1 of its row (l == 15 keeps `last`)
 __device__ __forceinline__ int row_shl1(int x, int last) { return dpp_i32<0x101>(last, x); }
