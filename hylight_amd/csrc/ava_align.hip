@@ -118,6 +118,9 @@ struct AlignArgs {
     int match, mismatch, go, ge, ambi;
     int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
+    int kgap1;              // 1: blocks with |n - m| = 1 and one substitution finish in the classifier (fifth certificate)
+    int kshift;             // 1: a square block with kmax + 1 substitutions also finishes here when the one-base shift
+                            // that could avoid them all does not match (fourth certificate, see classify_kernel)
     TaskOut *out;
     uint32_t *runs;
     uint32_t cap_runs;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
         bool ambig = false;
         if (try_fast) {
             const bool rev = (tk.kind & TASK_REV) != 0;
-            for (int x = 0; x < m && k <= a.kmax && !ambig; x += 8) {
+            for (int x = 0; x < m && k <= a.kmax + a.kshift && !ambig; x += 8) {
                 const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
                 const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
                 const int left = m - x;                        // bases of this step inside the block (>= 1)
@@ -273,6 +276,29 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
             }
         }
         bool fast = try_fast && !ambig && k <= a.kmax;
+        // Fourth certificate, square blocks with exactly kmax + 1 substitutions at p1 < .. < pk.  A gapped path scores at
+        // most match (m - 1 - x) - mismatch x - 2 (open + ext) with x mismatching diagonal moves, and by the choice of
+        // kmax it beats the diagonal only with x = 0, one inserted and one deleted base (the host checks that longer or
+        // further gaps cannot make up their cost): it follows the main diagonal without a mismatch up to p1 at the
+        // latest, runs one diagonal higher or lower past pk with every pair matching, and comes back.  The least
+        // constrained such path leaves at p1 and returns after pk: if neither (q[i + 1], t[i]) nor (q[i], t[i + 1])
+        // match for all i in [p1, pk), no gapped path ties or beats the diagonal - it is the unique optimum.
+        if (try_fast && !ambig && a.kshift && k == a.kmax + 1) {
+            const bool rev = (tk.kind & TASK_REV) != 0;
+            const int p1 = mpos[0], len = mpos[k - 1] - mpos[0];
+            bool up = true, down = true;                              // the two shifted segments match so far
+            for (int x = 0; x < len && (up || down); x += 8) {
+                const uint64_t q0 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, p1 + x);
+                const uint64_t q1 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, p1 + x + 1);
+                const uint64_t t0 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, p1 + x);
+                const uint64_t t1 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, p1 + x + 1);
+                const int left = len - x;
+                const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
+                up = up && ((q1 ^ t0) & keep) == 0;
+                down = down && ((q0 ^ t1) & keep) == 0;
+            }
+            fast = !up && !down;
+        }
         uint32_t runs[7];
         uint32_t nr = 0;
         int fast_score = a.match * (m - k) - a.mismatch * k;
@@ -308,42 +334,74 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
             }
         } else if (PASS == 2 && live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
             const bool rev = (tk.kind & TASK_REV) != 0;
-            const int mn = m < n ? m : n;
-            int lcp = 0, lcs = 0;
-            bool amb = false, open = true;
-            for (int x = 0; x < mn && open; x += 8) {                       // common prefix, elements x..x+7
+            const int mn = m < n ? m : n, gap = n > m ? n - m : m - n;
+            const bool del = n > m;                                       // the gap consumes target bases
+            // Both certificates come from two scans: from the block's start along the start diagonal, from its end along
+            // the end diagonal, each up to its first substitution (second certificate) or, for a one-base gap, its
+            // second (fifth certificate).  a1 < a2: first substitutions of the start diagonal (mn: none), b1 > b2: last
+            // ones of the end diagonal (-1: none).  "prefix [0,p) + gap + suffix [p,mn)" has
+            // s(p) = #(a < p) + #(b >= p) substitutions.
+            //   second certificate, s* = 0 (b1 < a1): no alignment of an m x n block beats match * min(m,n) - open -
+            //     ext * |n - m| (fewer columns or more gap cost); the traceback prefers the diagonal on ties, i.e. it
+            //     leaves the end diagonal as late as it can: the gap sits at the leftmost admissible place b1 + 1.
+            //   fifth certificate, |n - m| = 1 and s* = 1: any alignment that is not of this form needs a further
+            //     inserted + deleted base - at least open + 2 ext more gap cost and one diagonal move fewer, which
+            //     avoiding ONE substitution cannot pay for (checked on the host) - so the optimal alignments are the
+            //     placements with s(p) = 1: p in (b2, a1] with the substitution at b1, or p in (b1, a2] with it at a1;
+            //     the first range lies left of the second and the traceback takes the leftmost p, as above.
+            const int want = a.kgap1 && gap == 1 ? 2 : 1;
+            int found_a = 0, found_b = 0, a1 = mn, a2 = mn, b1 = -1, b2 = -1;
+            bool amb = false;
+            for (int x = 0; x < mn && found_a < want; x += 8) {
                 const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
                 const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
                 const int left = mn - x;
                 const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
-                const uint64_t d = (q8 ^ t8) & keep;
-                const int same = d ? (__ffsll((long long)d) - 1) >> 3 : (left < 8 ? left : 8);
-                const uint64_t seen = same >= 8 ? ~0ull : (1ull << (8 * same)) - 1ull;
-                amb |= ((q8 | t8) & seen & 0x0404040404040404ull) != 0;
-                lcp = x + same;
-                open = d == 0;
+                amb |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
+                uint64_t d = (q8 ^ t8) & keep;
+                d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
+                while (d && found_a < want) {
+                    const int y = (__ffsll((long long)d) - 1) >> 3;
+                    d &= d - 1;
+                    if (found_a++ == 0) a1 = x + y; else a2 = x + y;
+                }
             }
-            open = true;
-            for (int y = 0; y < mn && open; y += 8) {                       // common suffix (all of it: it decides where
-                                                                              // the gap goes), elements end-8-y..end-1-y
-                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, m - 8 - y);
-                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, n - 8 - y);
+            const int sq = m > n ? m - n : 0, st_ = n > m ? n - m : 0;   // shift of the end diagonal in q / t
+            for (int y = 0; y < mn && found_b < want; y += 8) {           // end diagonal, elements mn-8-y .. mn-1-y
+                const int e0 = mn - 8 - y;
+                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, e0 + sq);
+                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, e0 + st_);
                 const int left = mn - y;
                 const uint64_t keep = left >= 8 ? ~0ull : ~0ull << (8 * (8 - left));
-                const uint64_t d = (q8 ^ t8) & keep;
-                const int same = d ? __clzll((long long)d) >> 3 : (left < 8 ? left : 8);
-                const uint64_t seen = same >= 8 ? ~0ull : (same ? ~0ull << (8 * (8 - same)) : 0ull);
-                amb |= ((q8 | t8) & seen & 0x0404040404040404ull) != 0;
-                lcs = y + same;
-                open = d == 0;
+                amb |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
+                uint64_t d = (q8 ^ t8) & keep;
+                d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
+                while (d && found_b < want) {
+                    const int z = 7 - (__clzll((long long)d) >> 3);      // highest set byte
+                    d &= ~(0xffull << (8 * z));
+                    if (found_b++ == 0) b1 = e0 + z; else b2 = e0 + z;
+                }
             }
-            if (!amb && lcp + lcs >= mn) {
-                const int gap = n > m ? n - m : m - n;
-                const int p0 = mn - lcs > 0 ? mn - lcs : 0;                   // leftmost place the suffix allows (<= lcp)
-                if (p0 > 0) runs[nr++] = (uint32_t)p0 << 4 | OP_EQ;
-                runs[nr++] = (uint32_t)gap << 4 | (n > m ? OP_D : OP_I);
-                if (mn - p0 > 0) runs[nr++] = (uint32_t)(mn - p0) << 4 | OP_EQ;
-                fast_score = a.match * mn - a.go - a.ge * gap;
+            int p_star = -1, xpos = -1;
+            bool in_prefix = false;
+            if (!amb) {
+                if (b1 < a1) p_star = b1 + 1;                                             // s* = 0
+                else if (want == 2 && b2 < a1) { p_star = b2 + 1; xpos = b1; }            // s* = 1, substitution in the suffix
+                else if (want == 2 && b1 < a2) { p_star = b1 + 1; xpos = a1; in_prefix = true; }   // ... in the prefix
+            }
+            if (p_star >= 0) {
+                auto seg = [&](int from, int to) {            // [from, to) of one diagonal, with the substitution if it lies inside
+                    if (xpos >= from && xpos < to) {
+                        if (xpos > from) runs[nr++] = (uint32_t)(xpos - from) << 4 | OP_EQ;
+                        runs[nr++] = 1u << 4 | OP_X;
+                        if (to > xpos + 1) runs[nr++] = (uint32_t)(to - xpos - 1) << 4 | OP_EQ;
+                    } else if (to > from) runs[nr++] = (uint32_t)(to - from) << 4 | OP_EQ;
+                };
+                seg(0, p_star);
+                runs[nr++] = (uint32_t)gap << 4 | (del ? OP_D : OP_I);
+                seg(p_star, mn);
+                const int subs = xpos >= 0 ? 1 : 0;
+                fast_score = a.match * (mn - subs) - a.mismatch * subs - a.go - a.ge * gap;
                 fast = true;
                 c = 0;
             }
@@ -1198,6 +1256,14 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             const int den = o.match + o.mismatch, num = o.match + 2 * (o.gap_open + o.gap_ext);
             aa.kmax = den > 0 && num > 0 ? std::min(3, (num - 1) / den) : 0;
             if (o.match <= 0 || o.gap_open < 0 || o.gap_ext <= 0) aa.kmax = -1;   // proof needs sane scores
+            // fourth certificate: with k = kmax + 1 substitutions the only gapped paths that reach the diagonal's score
+            // have one inserted + one deleted base and no mismatch; paths with a further gap base pair lose another
+            // match + 2 ext, paths with a further gap another open + ext + match (three positions fit the run buffer)
+            const int k = aa.kmax + 1, U = den, T = num;
+            // fifth certificate: one substitution gains less than a further inserted + deleted base costs
+            aa.kgap1 = aa.kmax >= 0 && U < o.gap_open + 2 * o.gap_ext + o.match && !getenv("HLMI_NO_GAP1_CERT") ? 1 : 0;
+            aa.kshift = aa.kmax >= 0 && k <= 3 && k * U > T && k * U < T + o.match + std::min(2 * o.gap_ext, o.gap_open + o.gap_ext) &&
+                        !getenv("HLMI_NO_SHIFT_CERT") ? 1 : 0;
         }
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         aa.run_buf_cap = 0xffffffffu;

@@ -651,31 +651,52 @@ __global__ __launch_bounds__(PILE_WG) void snp_pileup_kernel(const PafRec *recs,
             }
         }
         __syncthreads();
-        // X counts
-        for (size_t k = b + (size_t)wave; k < e; k += PILE_WG / 64) {
-            const uint32_t v = ent_val[k];
-            const PafRec r = recs[ent_rec[k]];
-            walk(r, (v & 1u) != 0, [&](uint32_t pos, bool isx) {
-                if (isx && pos >= t0 && pos - t0 < n_pos) lds_inc<CT>(sB, pos - t0);
-                if (t0 == 0) ev += (unsigned long long)__popcll(__ballot(isx));
-            });
+        // X counts.  The record of a wave's next row is requested before the current row is walked: the chain
+        // entry -> record -> CIGAR is three trips to memory that would otherwise line up behind every walk.
+        {
+            size_t k = b + (size_t)wave;
+            uint32_t v = 0;
+            PafRec r{};
+            if (k < e) { v = ent_val[k]; r = recs[ent_rec[k]]; }
+            while (k < e) {
+                const size_t kn = k + PILE_WG / 64;
+                uint32_t vn = 0;
+                PafRec rn{};
+                if (kn < e) { vn = ent_val[kn]; rn = recs[ent_rec[kn]]; }
+                walk(r, (v & 1u) != 0, [&](uint32_t pos, bool isx) {
+                    if (isx && pos >= t0 && pos - t0 < n_pos) lds_inc<CT>(sB, pos - t0);
+                    if (t0 == 0) ev += (unsigned long long)__popcll(__ballot(isx));
+                });
+                k = kn; v = vn; r = rn;
+            }
         }
         __syncthreads();
-        // supported keys -> their rows' pair counters
-        for (size_t k = b + (size_t)wave; k < e; k += PILE_WG / 64) {
-            const uint32_t v = ent_val[k];
-            const uint32_t pg = row_pair[v >> 1];
-            if (pg == NO_PAIR) continue;                   // nobody reads this pair's counter (uniform across the wave)
-            const PafRec r = recs[ent_rec[k]];
-            uint32_t hits = 0;
-            walk(r, (v & 1u) != 0, [&](uint32_t pos, bool isx) {
-                if (isx && pos >= t0 && pos - t0 < n_pos) {
-                    const int cnt = (int)lds_get<CT>(sB, pos - t0), cov = (int)lds_get<CT>(sA, pos - t0);
-                    if (cnt >= mc && cov - cnt >= mc) ++hits;
-                }
-            });
-            hits = wave_incl_sum_u32(hits, lane);
-            if (lane == 63 && hits) atomicAdd(&pair_mut[pg], hits);
+        // supported keys -> their rows' pair counters (rows of pairs nobody reads are skipped before their record is fetched)
+        {
+            auto next_live = [&](size_t k) {               // first entry of this wave from k on whose pair counter is read
+                while (k < e && row_pair[ent_val[k] >> 1] == NO_PAIR) k += PILE_WG / 64;
+                return k;
+            };
+            size_t k = next_live(b + (size_t)wave);
+            uint32_t v = 0;
+            PafRec r{};
+            if (k < e) { v = ent_val[k]; r = recs[ent_rec[k]]; }
+            while (k < e) {
+                const size_t kn = next_live(k + PILE_WG / 64);
+                uint32_t vn = 0;
+                PafRec rn{};
+                if (kn < e) { vn = ent_val[kn]; rn = recs[ent_rec[kn]]; }
+                uint32_t hits = 0;
+                walk(r, (v & 1u) != 0, [&](uint32_t pos, bool isx) {
+                    if (isx && pos >= t0 && pos - t0 < n_pos) {
+                        const int cnt = (int)lds_get<CT>(sB, pos - t0), cov = (int)lds_get<CT>(sA, pos - t0);
+                        if (cnt >= mc && cov - cnt >= mc) ++hits;
+                    }
+                });
+                hits = wave_incl_sum_u32(hits, lane);
+                if (lane == 63 && hits) atomicAdd(&pair_mut[row_pair[v >> 1]], hits);
+                k = kn; v = vn; r = rn;
+            }
         }
         __syncthreads();
     }
