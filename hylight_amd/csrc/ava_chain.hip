@@ -265,9 +265,9 @@ __global__ void gather_u32_at_kernel(const uint32_t *src, const uint32_t *idx, u
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
-__global__ void mark_groups_kernel(const uint32_t *list, size_t n, uint8_t *flag) {
+__global__ void mark_proven_kernel(const uint32_t *gorder, const uint8_t *verdict, size_t n, uint8_t *flag) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) flag[list[i]] = 1;
+    if (i < n && verdict[i] == 1) flag[gorder[i]] = 1;
 }
 __global__ void plus_one_u8_kernel(const uint8_t *in, uint8_t *out, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -322,7 +322,7 @@ struct ChainArgs {
     const uint32_t *gorder;           // groups, largest first (the order the workgroups take them in)
     size_t n_list;                    // groups in gorder (this launch's share of the n_groups groups)
     size_t n_groups, n_anchors;
-    const uint32_t *fp;               // PRE form: score << 5 | distance to the predecessor (0: none) of every anchor, from chain_dp16_kernel
+    uint32_t *fp;                     // MODE 2: score << 5 | distance to the predecessor (0: none) of every anchor, from chain_dp16_kernel
     uint32_t *sbase;                  // per chain start: f(parent of the start) | has a child << 31
     int *mem;                         // member lists of the chains that score enough (scratch, one slot per anchor)
     int *root;                        // chain id of every anchor (index of the chain's start inside the group)
@@ -491,8 +491,170 @@ constexpr int CHAIN_WAVES = 4;      // waves per workgroup sharing one gap-cost 
 //      3 = packed DP state (score << 8 | predecessor stamp, see below) with a 32-bit table of -(cost << 8)
 constexpr int PK_NONE = 255;         // stamp of "no predecessor"
 constexpr int PK_NEG = -(1 << 30);   // candidate that loses against every state (scores stay below 2^22)
-template <int TAB, bool PRE = false>
+// ---------------------------------------------------------------------------------------------
+// chains, first pass: the DP over the 16 nearest predecessors, four groups per wave
+// ---------------------------------------------------------------------------------------------
+// On read sets the anchors of a (query, target, strand) group lie along one diagonal and f grows by about a k-mer per
+// anchor: the best predecessor is then one of the nearest few, and most of the 64 candidates the specification asks for
+// only cost instructions.  This kernel runs the same push-form recurrence with a window of 16 - a DPP row of 16 lanes
+// holds one group, a wave four of them, the sender's state reaches its row through row_newbcast - and PROVES per
+// anchor that the other 48 predecessors cannot change the result: a predecessor j scores at most f(j) + span_i, so
+//     max { f(j) : i - 64 <= j <= i - 17 } + span_i <= f16(i)
+// means no far predecessor beats the near maximum (on a tie the spec takes the later predecessor, which is the near
+// one).  By induction over the group f16 = f and the predecessors agree.  A group with one anchor that fails the test
+// is handed to the 64-predecessor kernel instead (repeats, off-diagonal seeds).  Output: score << 5 | distance to the
+// predecessor per anchor (4 bytes; chain_kernel<3, true> reads them), one verdict per group.
+constexpr int D16_WAVES = 4;
+// lane J of the own row of 16, to every lane of it: v_mov_b32_dpp row_newbcast.  The empty asm keeps the move a move:
+// folded into an arithmetic instruction as its DPP operand (v_subrev_u32_dpp ... row_newbcast:J) the result was wrong on
+// gfx950 (measured; the same code with ds_bpermute or with the unfolded move agrees with the CPU).
+template <int J> __device__ __forceinline__ int row_lane(int x) {
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xf, 0xf, true);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ int row_max_u_incl_prefix(int x) {               // unsigned max over lanes <= l of the row (identity 0)
+    auto mx = [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); };
+    x = mx(x, dpp_i32<0x111>(0, x)); x = mx(x, dpp_i32<0x112>(0, x)); x = mx(x, dpp_i32<0x114>(0, x)); x = mx(x, dpp_i32<0x118>(0, x));
+    return x;
+}
+__device__ __forceinline__ int row_max_u_incl_suffix(int x) {               // ... over lanes >= l (row_shl)
+    auto mx = [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); };
+    x = mx(x, dpp_i32<0x101>(0, x)); x = mx(x, dpp_i32<0x102>(0, x)); x = mx(x, dpp_i32<0x104>(0, x)); x = mx(x, dpp_i32<0x108>(0, x));
+    return x;
+}
+
+struct Dp16State {
+    int M_t, M_q, M_s, M_pk, N_t, N_q, N_s, N_pk, O_pk, w;
+};
+// the anchor held by lane J of every row becomes the sender: its position goes to the row, the lane itself moves on to
+// its next anchor (16 further), and every lane gets the part of the candidate that does not depend on the sender's score
+template <int J>
+__device__ __forceinline__ void dp16_prepare(Dp16State &z, const int *pen_tab, uint32_t lim4, uint32_t bw4) {
+    constexpr unsigned long long me = 0x0001000100010001ull << J;
+    const int tj = row_lane<J>(z.M_t), qj = row_lane<J>(z.M_q);
+    z.M_t = select_by_mask(me, z.N_t, z.M_t); z.M_q = select_by_mask(me, z.N_q, z.M_q); z.M_s = select_by_mask(me, z.N_s, z.M_s);
+    const uint32_t dr = (uint32_t)(z.M_t - tj), dq = (uint32_t)(z.M_q - qj);          // 4 x gap; a negative gap is huge
+    const uint32_t lo = dr < dq ? dr : dq, hi = dr < dq ? dq : dr;
+    uint32_t di = sad_u32(dr, dq, 0u);
+    di = di < bw4 ? di : bw4;
+    const int pen = *(const int *)((const char *)pen_tab + di);
+    const uint32_t mn = lo < (uint32_t)z.M_s ? lo : (uint32_t)z.M_s;
+    z.w = (lo >= 4u) & (hi <= lim4) ? (int)(mn << 6) + pen : PK_NEG;
+}
+// steps J .. 15 of a block: finish the sender, push it, prepare the next one
+template <int J>
+__device__ __forceinline__ void dp16_steps(Dp16State &z, const int *pen_tab, uint32_t lim4, uint32_t bw4) {
+    constexpr unsigned long long me = 0x0001000100010001ull << J;
+    const int sb = row_lane<J>(z.M_pk);
+    z.O_pk = select_by_mask(me, sb, z.O_pk);
+    z.M_pk = select_by_mask(me, z.N_pk, z.M_pk);
+    const int cand = ((sb & ~255) + (16 + J - 256)) + z.w;    // the table holds (1 - cost) << 8
+    z.M_pk = cand > z.M_pk ? cand : z.M_pk;
+    if constexpr (J < 15) {
+        dp16_prepare<J + 1>(z, pen_tab, lim4, bw4);
+        dp16_steps<J + 1>(z, pen_tab, lim4, bw4);
+    }
+}
+
+// the wave's four groups gorder[gi0 .. gi0 + 3], one per row of 16 lanes; pen_tab = the packed DP's table ((1 - cost) << 8,
+// entry bw + 1 rejecting).  Returns the row's verdict (the same in its 16 lanes).
+__device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, uint32_t *fp) {
+    const int lane = threadIdx.x & 63, rl = lane & 15, row = lane >> 4;
+    const size_t gi = gi0 + (size_t)row;
+    // geometry of the row's group (uniform inside the row)
+    size_t g = 0, g_first = 0;
+    long long g_step = 1;
+    int n = 0;
+    if (gi < a.n_list) {
+        g = a.gorder[gi];
+        const size_t b = a.gstart[g], e = g + 1 < a.n_groups ? (size_t)a.gstart[g + 1] : a.n_anchors;
+        n = (int)(e - b);
+        if (n < a.min_cnt) n = 0;                                  // nobody chains it
+        const uint32_t strand = (uint32_t)(a.key[b] >> (a.vb + a.pb)) & 1u;
+        g_first = strand ? b + (size_t)(e - b) - 1 : b;
+        g_step = strand ? -1 : 1;
+    }
+    int n_max = __builtin_amdgcn_readlane(n, 0);
+    n_max = max(n_max, __builtin_amdgcn_readlane(n, 16));
+    n_max = max(n_max, __builtin_amdgcn_readlane(n, 32));
+    n_max = max(n_max, __builtin_amdgcn_readlane(n, 48));
+    if (!n_max) return 2;
+    constexpr int DEAD_Q = -(1 << 30);
+    auto load_block = [&](int i0, int &t, int &q, int &sp) {       // positions x 4 (byte offsets into the table), span x 4
+        t = 0; q = DEAD_Q; sp = 0;
+        if (i0 + rl < n) {
+            anchor_fields(a, (size_t)((long long)g_first + g_step * (i0 + rl)), t, q, sp);
+            t <<= 2; q <<= 2; sp <<= 2;
+        }
+    };
+    Dp16State z;
+    int P_t, P_q, P_s;
+    load_block(0, z.M_t, z.M_q, z.M_s);
+    load_block(16, z.N_t, z.N_q, z.N_s);
+    z.M_pk = (z.M_s << 6) | PK_NONE;
+    const uint32_t lim4 = 4u * (uint32_t)a.max_gap, bw4 = 4u * (uint32_t)(a.bw + 1);
+    int F1 = 0, F2 = 0, F3 = 0, F4 = 0, R1 = 0, R2 = 0, R3 = 0;    // scores of the four blocks before / their row maxima
+    int gmax = 0;                                                  // largest score of the group
+    unsigned long long bad = 0;
+    for (int i0 = 0; i0 < n_max; i0 += 16) {
+        // every lane l holds anchor i0 + l here; N = the block after it, P = the one after that
+        load_block(i0 + 32, P_t, P_q, P_s);                        // in flight during the block
+        const int cur_span = z.M_s >> 2;                           // the bound below needs the spans of this block's anchors
+        z.N_pk = (z.N_s << 6) | PK_NONE;
+        z.O_pk = PK_NONE;
+        dp16_prepare<0>(z, pen_tab, lim4, bw4);
+        dp16_steps<0>(z, pen_tab, lim4, bw4);
+        // every lane holds an anchor of the next block now: stamps of this block's senders become "previous block"
+        z.M_pk -= (z.M_pk & 255) != PK_NONE ? 16 : 0;
+        const bool live = i0 + rl < n;
+        const int O_f = live ? z.O_pk >> 8 : 0, O_st = z.O_pk & 255;
+        if (live) {
+            const uint32_t off = O_st == PK_NONE ? 0u : (uint32_t)(rl + 16 - O_st);
+            fp[(size_t)((long long)g_first + g_step * (i0 + rl))] = (uint32_t)O_f << 5 | off;
+        }
+        // far predecessors of lane l: block -4 lanes >= l, blocks -3 and -2, block -1 lanes < l
+        {
+            const int far4 = row_max_u_incl_suffix(F4);
+            const int pre1 = dpp_i32<0x111>(0, row_max_u_incl_prefix(F1));       // exclusive
+            int far = far4 > R3 ? far4 : R3;
+            far = far > R2 ? far : R2;
+            far = far > pre1 ? far : pre1;
+            bad |= __ballot(live && far + cur_span > O_f);
+            F4 = F3; F3 = F2; F2 = F1; F1 = O_f;
+            R3 = R2; R2 = R1; R1 = row_lane<15>(row_max_u_incl_prefix(O_f));
+            gmax = gmax > R1 ? gmax : R1;
+        }
+        // the block after next moves up
+        z.N_t = P_t; z.N_q = P_q; z.N_s = P_s;
+    }
+    const unsigned long long mine = (bad >> (16 * row)) & 0xffffull;
+    // 1: proven.  2: proven, and no chain of the group can reach the minimum score (a chain scores at most its largest
+    // f): nobody needs to look at it again.  0: the full DP decides.
+    return mine ? 0 : (gmax < a.min_score || n == 0 ? 2 : 1);
+}
+
+
+// the pass on its own (self-check mode: its output is compared with the 64-predecessor DP of every group)
+__global__ __launch_bounds__(64 * D16_WAVES) void chain_dp16_kernel(ChainArgs a, uint32_t *fp, uint8_t *gok) {
+    __shared__ int pen_tab[PEN_TAB];
+    for (int d = threadIdx.x; d < a.bw + 2; d += 64 * D16_WAVES) {
+        const int pen = d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0;
+        pen_tab[d] = d <= a.bw ? (1 - pen) * 256 : PK_NEG;
+    }
+    __syncthreads();
+    const size_t gi0 = ((size_t)blockIdx.x * D16_WAVES + (threadIdx.x >> 6)) * 4;
+    const int verdict = dp16_groups(a, pen_tab, gi0, fp);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 0 && gi0 + (size_t)(lane >> 4) < a.n_list) gok[gi0 + (size_t)(lane >> 4)] = (uint8_t)verdict;
+}
+
+// MODE 0: the 64-predecessor DP for every group.  MODE 2 (packed form only): the wave first runs the 16-predecessor DP
+// over its four groups (dp16_groups); a group with the proof only needs the chain bookkeeping, read from fp, a group
+// without it takes the 64-predecessor DP as before, a group that cannot reach the minimum score is dropped.
+template <int TAB, int MODE = 0>
 __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
+    static_assert(MODE == 0 || TAB == 3, "the 16-predecessor pass uses the packed table");
     typedef typename std::conditional<TAB == 1, uint8_t, typename std::conditional<TAB == 3, int, uint16_t>::type>::type pen_t;
     __shared__ pen_t pen_tab[TAB ? PEN_TAB : 1];
     __shared__ unsigned long long s_bc[CHAIN_WAVES][BC_RING];      // best child of the anchors of the last few blocks
@@ -512,7 +674,25 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
     const size_t g_hi = g_lo + CHAIN_GROUPS < a.n_list ? g_lo + CHAIN_GROUPS : a.n_list;
     uint32_t wave_fps = 0;                                 // fixed points actually written by this wave (statistics)
+    int verdict16 = 0;
+    if constexpr (MODE == 2) {
+        static_assert(CHAIN_GROUPS == 4, "one group per row of 16 lanes");
+        verdict16 = g_lo < a.n_list ? dp16_groups(a, (const int *)pen_tab, g_lo, a.fp) : 2;
+        __builtin_amdgcn_s_waitcnt(0);                     // fp is read back by this wave below
+        __threadfence_block();
+        if (lane == 0) {
+            uint32_t n_full = 0;
+            for (int r = 0; r < 4; ++r) n_full += g_lo + (size_t)r < g_hi && __builtin_amdgcn_readlane(verdict16, 16 * r) == 0 ? 1u : 0u;
+            if (n_full) atomicAdd(&a.counters[1], n_full);
+        }
+    }
     for (size_t gi = g_lo; gi < g_hi; ++gi) {
+        bool use_pre = false;
+        if constexpr (MODE == 2) {
+            const int vd = __builtin_amdgcn_readlane(verdict16, 16 * (int)(gi - g_lo));
+            if (vd == 2) continue;
+            use_pre = vd == 1;
+        }
         const size_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gorder[gi]);
         const size_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g]);
         const size_t e = g + 1 < a.n_groups ? (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g + 1]) : a.n_anchors;
@@ -540,7 +720,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             if (i0 + lane < n) anchor_fields(a, (size_t)((long long)g_first + g_step * (i0 + lane)), t, q, sp);
         };
         int M_t = 0, M_q = 0, M_s = 0, N_t = 0, N_q = 0, N_s = 0, P_t, P_q, P_s;
-        if constexpr (!PRE) {
+        if (!use_pre) {
             load_block(0, M_t, M_q, M_s);
             load_block(64, N_t, N_q, N_s);
         }
@@ -614,8 +794,8 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             // three ahead (this block's own are still read when the next one is resolved)
             bc[(i - 64) & (BC_RING - 1)] = 0;
         };
-        if constexpr (PRE) {
-            // scores and predecessors come from chain_dp16_kernel (the 16-predecessor DP, verified equal to the
+        if (MODE == 2 && use_pre) {
+            // scores and predecessors come from dp16_groups (the 16-predecessor DP, verified equal to the
             // 64-predecessor one for this group): only the chain bookkeeping runs here
             auto load_fp = [&](int i0) { return i0 + lane < n ? a.fp[(size_t)((long long)g_first + g_step * (i0 + lane))] : 0u; };
             uint32_t v_next = load_fp(0);
@@ -796,156 +976,6 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     __builtin_amdgcn_wave_barrier();
     flush_pieces(a, lane, pbuf, n_pbuf);
     if (lane == 0 && wave_fps) atomicAdd(&a.counters[3], wave_fps);
-}
-
-// ---------------------------------------------------------------------------------------------
-// chains, first pass: the DP over the 16 nearest predecessors, four groups per wave
-// ---------------------------------------------------------------------------------------------
-// On read sets the anchors of a (query, target, strand) group lie along one diagonal and f grows by about a k-mer per
-// anchor: the best predecessor is then one of the nearest few, and most of the 64 candidates the specification asks for
-// only cost instructions.  This kernel runs the same push-form recurrence with a window of 16 - a DPP row of 16 lanes
-// holds one group, a wave four of them, the sender's state reaches its row through row_newbcast - and PROVES per
-// anchor that the other 48 predecessors cannot change the result: a predecessor j scores at most f(j) + span_i, so
-//     max { f(j) : i - 64 <= j <= i - 17 } + span_i <= f16(i)
-// means no far predecessor beats the near maximum (on a tie the spec takes the later predecessor, which is the near
-// one).  By induction over the group f16 = f and the predecessors agree.  A group with one anchor that fails the test
-// is handed to the 64-predecessor kernel instead (repeats, off-diagonal seeds).  Output: score << 5 | distance to the
-// predecessor per anchor (4 bytes; chain_kernel<3, true> reads them), one verdict per group.
-constexpr int D16_WAVES = 4;
-// lane J of the own row of 16, to every lane of it: v_mov_b32_dpp row_newbcast.  The empty asm keeps the move a move:
-// folded into an arithmetic instruction as its DPP operand (v_subrev_u32_dpp ... row_newbcast:J) the result was wrong on
-// gfx950 (measured; the same code with ds_bpermute or with the unfolded move agrees with the CPU).
-template <int J> __device__ __forceinline__ int row_lane(int x) {
-    int r = __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xf, 0xf, true);
-    asm volatile("" : "+v"(r));
-    return r;
-}
-__device__ __forceinline__ int row_max_u_incl_prefix(int x) {               // unsigned max over lanes <= l of the row (identity 0)
-    auto mx = [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); };
-    x = mx(x, dpp_i32<0x111>(0, x)); x = mx(x, dpp_i32<0x112>(0, x)); x = mx(x, dpp_i32<0x114>(0, x)); x = mx(x, dpp_i32<0x118>(0, x));
-    return x;
-}
-__device__ __forceinline__ int row_max_u_incl_suffix(int x) {               // ... over lanes >= l (row_shl)
-    auto mx = [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); };
-    x = mx(x, dpp_i32<0x101>(0, x)); x = mx(x, dpp_i32<0x102>(0, x)); x = mx(x, dpp_i32<0x104>(0, x)); x = mx(x, dpp_i32<0x108>(0, x));
-    return x;
-}
-
-struct Dp16State {
-    int M_t, M_q, M_s, M_pk, N_t, N_q, N_s, N_pk, O_pk, w;
-};
-// the anchor held by lane J of every row becomes the sender: its position goes to the row, the lane itself moves on to
-// its next anchor (16 further), and every lane gets the part of the candidate that does not depend on the sender's score
-template <int J>
-__device__ __forceinline__ void dp16_prepare(Dp16State &z, const int *pen_tab, uint32_t lim4, uint32_t bw4) {
-    constexpr unsigned long long me = 0x0001000100010001ull << J;
-    const int tj = row_lane<J>(z.M_t), qj = row_lane<J>(z.M_q);
-    z.M_t = select_by_mask(me, z.N_t, z.M_t); z.M_q = select_by_mask(me, z.N_q, z.M_q); z.M_s = select_by_mask(me, z.N_s, z.M_s);
-    const uint32_t dr = (uint32_t)(z.M_t - tj), dq = (uint32_t)(z.M_q - qj);          // 4 x gap; a negative gap is huge
-    const uint32_t lo = dr < dq ? dr : dq, hi = dr < dq ? dq : dr;
-    uint32_t di = sad_u32(dr, dq, 0u);
-    di = di < bw4 ? di : bw4;
-    const int pen = *(const int *)((const char *)pen_tab + di);
-    const uint32_t mn = lo < (uint32_t)z.M_s ? lo : (uint32_t)z.M_s;
-    z.w = (lo >= 4u) & (hi <= lim4) ? (int)(mn << 6) + pen : PK_NEG;
-}
-// steps J .. 15 of a block: finish the sender, push it, prepare the next one
-template <int J>
-__device__ __forceinline__ void dp16_steps(Dp16State &z, const int *pen_tab, uint32_t lim4, uint32_t bw4) {
-    constexpr unsigned long long me = 0x0001000100010001ull << J;
-    const int sb = row_lane<J>(z.M_pk);
-    z.O_pk = select_by_mask(me, sb, z.O_pk);
-    z.M_pk = select_by_mask(me, z.N_pk, z.M_pk);
-    const int cand = ((sb & ~255) + 16 + J) + z.w;
-    z.M_pk = cand > z.M_pk ? cand : z.M_pk;
-    if constexpr (J < 15) {
-        dp16_prepare<J + 1>(z, pen_tab, lim4, bw4);
-        dp16_steps<J + 1>(z, pen_tab, lim4, bw4);
-    }
-}
-
-__global__ __launch_bounds__(64 * D16_WAVES) void chain_dp16_kernel(ChainArgs a, uint32_t *fp, uint8_t *gok, unsigned long long *n_far) {
-    __shared__ int pen_tab[PEN_TAB];
-    for (int d = threadIdx.x; d < a.bw + 2; d += 64 * D16_WAVES) {
-        const int pen = d && d <= a.bw ? (d * a.k) / 100 + (ilog2_u32((uint32_t)d) >> 1) : 0;
-        pen_tab[d] = d <= a.bw ? -pen * 256 : PK_NEG;          // entry bw + 1 rejects
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, rl = lane & 15, row = lane >> 4;
-    const size_t gi = ((size_t)blockIdx.x * D16_WAVES + (threadIdx.x >> 6)) * 4 + (size_t)row;
-    // geometry of the row's group (uniform inside the row)
-    size_t g = 0, g_first = 0;
-    long long g_step = 1;
-    int n = 0;
-    if (gi < a.n_list) {
-        g = a.gorder[gi];
-        const size_t b = a.gstart[g], e = g + 1 < a.n_groups ? (size_t)a.gstart[g + 1] : a.n_anchors;
-        n = (int)(e - b);
-        if (n < a.min_cnt) n = 0;                                  // nobody chains it
-        const uint32_t strand = (uint32_t)(a.key[b] >> (a.vb + a.pb)) & 1u;
-        g_first = strand ? b + (size_t)(e - b) - 1 : b;
-        g_step = strand ? -1 : 1;
-    }
-    int n_max = __builtin_amdgcn_readlane(n, 0);
-    n_max = max(n_max, __builtin_amdgcn_readlane(n, 16));
-    n_max = max(n_max, __builtin_amdgcn_readlane(n, 32));
-    n_max = max(n_max, __builtin_amdgcn_readlane(n, 48));
-    if (!n_max) return;
-    constexpr int DEAD_Q = -(1 << 30);
-    auto load_block = [&](int i0, int &t, int &q, int &sp) {       // positions x 4 (byte offsets into the table), span x 4
-        t = 0; q = DEAD_Q; sp = 0;
-        if (i0 + rl < n) {
-            anchor_fields(a, (size_t)((long long)g_first + g_step * (i0 + rl)), t, q, sp);
-            t <<= 2; q <<= 2; sp <<= 2;
-        }
-    };
-    Dp16State z;
-    int P_t, P_q, P_s;
-    load_block(0, z.M_t, z.M_q, z.M_s);
-    load_block(16, z.N_t, z.N_q, z.N_s);
-    z.M_pk = (z.M_s << 6) | PK_NONE;
-    const uint32_t lim4 = 4u * (uint32_t)a.max_gap, bw4 = 4u * (uint32_t)(a.bw + 1);
-    int F1 = 0, F2 = 0, F3 = 0, F4 = 0, R1 = 0, R2 = 0, R3 = 0;    // scores of the four blocks before / their row maxima
-    int gmax = 0;                                                  // largest score of the group
-    unsigned long long bad = 0;
-    for (int i0 = 0; i0 < n_max; i0 += 16) {
-        // every lane l holds anchor i0 + l here; N = the block after it, P = the one after that
-        load_block(i0 + 32, P_t, P_q, P_s);                        // in flight during the block
-        const int cur_span = z.M_s >> 2;                           // the bound below needs the spans of this block's anchors
-        z.N_pk = (z.N_s << 6) | PK_NONE;
-        z.O_pk = PK_NONE;
-        dp16_prepare<0>(z, pen_tab, lim4, bw4);
-        dp16_steps<0>(z, pen_tab, lim4, bw4);
-        // every lane holds an anchor of the next block now: stamps of this block's senders become "previous block"
-        z.M_pk -= (z.M_pk & 255) != PK_NONE ? 16 : 0;
-        const bool live = i0 + rl < n;
-        const int O_f = live ? z.O_pk >> 8 : 0, O_st = z.O_pk & 255;
-        if (live) {
-            const uint32_t off = O_st == PK_NONE ? 0u : (uint32_t)(rl + 16 - O_st);
-            fp[(size_t)((long long)g_first + g_step * (i0 + rl))] = (uint32_t)O_f << 5 | off;
-        }
-        // far predecessors of lane l: block -4 lanes >= l, blocks -3 and -2, block -1 lanes < l
-        {
-            const int far4 = row_max_u_incl_suffix(F4);
-            const int pre1 = dpp_i32<0x111>(0, row_max_u_incl_prefix(F1));       // exclusive
-            int far = far4 > R3 ? far4 : R3;
-            far = far > R2 ? far : R2;
-            far = far > pre1 ? far : pre1;
-            bad |= __ballot(live && far + cur_span > O_f);
-            F4 = F3; F3 = F2; F2 = F1; F1 = O_f;
-            R3 = R2; R2 = R1; R1 = row_lane<15>(row_max_u_incl_prefix(O_f));
-            gmax = gmax > R1 ? gmax : R1;
-        }
-        // the block after next moves up
-        z.N_t = P_t; z.N_q = P_q; z.N_s = P_s;
-    }
-    const unsigned long long mine = (bad >> (16 * row)) & 0xffffull;
-    if (rl == 0 && gi < a.n_list) {
-        // 1: proven.  2: proven, and no chain of the group can reach the minimum score (a chain scores at most its largest
-        // f): nobody needs to look at it again.  0: the full DP decides.
-        gok[gi] = mine ? 0 : (gmax < a.min_score ? 2 : 1);
-        if (n > 0 && mine) atomicAdd(n_far, (unsigned long long)n);
-    }
 }
 
 }  // namespace
@@ -1175,48 +1205,40 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     const dim3 block(64 * CHAIN_WAVES);
     auto grid_for = [](size_t n_list) { return dim3((unsigned)std::max<size_t>(1, cdiv(n_list, (size_t)CHAIN_GROUPS * CHAIN_WAVES))); };
     if (packed && G && !getenv("HLMI_CHAIN_NO_DP16")) {
-        // first the 16-predecessor DP over every group (four groups per wave), which also proves per group whether the
-        // 64-predecessor DP of the specification would have given the same scores and predecessors; the chain
-        // bookkeeping then reads those, and only the groups without the proof run the full DP
+        // every wave first runs the 16-predecessor DP over its four groups, which also proves per group whether the
+        // 64-predecessor DP of the specification would have given the same scores and predecessors (dp16_groups); the
+        // chain bookkeeping of a proven group reads those, only the groups without the proof run the full DP
         DBuf<uint32_t> fp(A);
-        DBuf<uint8_t> gok(G);
-        DBuf<unsigned long long> n_far(1);
-        n_far.zero();
-        {
-            KTimer kt("chain_dp16");
-            hipLaunchKernelGGL(chain_dp16_kernel, dim3((unsigned)cdiv(G, (size_t)D16_WAVES * 4)), dim3(64 * D16_WAVES), 0, stream(), ca,
-                               fp.p, gok.p, n_far.p);
-        }
-        HIP_CHECK(hipGetLastError());
-        DBuf<uint32_t> pos_ok(G), pos_far(G), pos_junk(G), pos_none(1), g_ok(G), g_far(G), cnt4(4);
-        DBuf<uint8_t> cls(G);
-        hipLaunchKernelGGL(plus_one_u8_kernel, grid1(G), dim3(WG), 0, stream(), gok.p, cls.p, G);
-        select_classes4_async(cls.p, G, pos_far.p, pos_ok.p, pos_junk.p, pos_none.p, cnt4.p);
-        const std::vector<uint32_t> nc = cnt4.download(4);
-        const size_t n_rest = nc[0], n_ok = nc[1];
-        if (n_ok) hipLaunchKernelGGL(gather_u32_at_kernel, grid1(n_ok), dim3(WG), 0, stream(), gorder.p, pos_ok.p, g_ok.p, n_ok);
-        if (n_rest) hipLaunchKernelGGL(gather_u32_at_kernel, grid1(n_rest), dim3(WG), 0, stream(), gorder.p, pos_far.p, g_far.p, n_rest);
-        stat_add("chain_groups_below_min_score", (double)nc[2]);
-        stat_add("chain_groups_full_dp", (double)n_rest);
-        stat_add("chain_anchors_full_dp", (double)download_one(n_far.p));
-        DBuf<unsigned long long> prof(4);
-        if (getenv("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
-        KTimer kt("chain");
         ca.fp = fp.p;
-        if (n_ok) {
-            ca.gorder = g_ok.p; ca.n_list = n_ok;
-            hipLaunchKernelGGL((chain_kernel<3, true>), grid_for(n_ok), block, 0, stream(), ca);
-        }
-        if (n_rest) {
-            ca.gorder = g_far.p; ca.n_list = n_rest;
-            hipLaunchKernelGGL((chain_kernel<3, false>), grid_for(n_rest), block, 0, stream(), ca);
-        }
-        HIP_CHECK(hipGetLastError());
-        sync();                                   // fp and the lists go out of scope
-        if (ca.prof) {
-            const std::vector<unsigned long long> hp = prof.download(4);
-            stat_add("chain_prof_blocks_cyc", (double)hp[0]); stat_add("chain_prof_members_cyc", (double)hp[1]);
-            stat_add("chain_prof_fixed_cyc", (double)hp[2]); stat_add("chain_prof_groups", (double)hp[3]);
+        if (getenv("HLMI_CHAIN_DP16_CHECK")) {     // self-check: every group through the full DP, compared with the proven ones
+            DBuf<uint8_t> verdict(G), ok_of_group(G);
+            DBuf<unsigned long long> n_bad(8);
+            n_bad.zero();
+            ok_of_group.zero();
+            hipLaunchKernelGGL(chain_dp16_kernel, dim3((unsigned)cdiv(G, (size_t)D16_WAVES * 4)), dim3(64 * D16_WAVES), 0, stream(), ca, fp.p,
+                               verdict.p);
+            hipLaunchKernelGGL(mark_proven_kernel, grid1(G), dim3(WG), 0, stream(), gorder.p, verdict.p, G, ok_of_group.p);
+            ca.check_ok = ok_of_group.p; ca.check_bad = n_bad.p;
+            hipLaunchKernelGGL((chain_kernel<3, 0>), grid_for(G), block, 0, stream(), ca);
+            HIP_CHECK(hipGetLastError());
+            const std::vector<unsigned long long> hb = n_bad.download(8);
+            stat_add("chain_dp16_mismatches", (double)hb[0]);
+            if (hb[0]) fprintf(stderr, "dp16 check: group %llu anchor %llu of %llu: dp16 f %llu p %d, full f %llu p %d\n", hb[1], hb[2], hb[3],
+                               hb[4] >> 32, (int)(uint32_t)hb[4], hb[5] >> 32, (int)(uint32_t)hb[5]);
+        } else {
+            DBuf<unsigned long long> prof(4);
+            if (getenv("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
+            {
+                KTimer kt("chain");
+                hipLaunchKernelGGL((chain_kernel<3, 2>), grid_for(G), block, 0, stream(), ca);
+            }
+            HIP_CHECK(hipGetLastError());
+            sync();                                   // fp goes out of scope
+            if (ca.prof) {
+                const std::vector<unsigned long long> hp = prof.download(4);
+                stat_add("chain_prof_blocks_cyc", (double)hp[0]); stat_add("chain_prof_members_cyc", (double)hp[1]);
+                stat_add("chain_prof_fixed_cyc", (double)hp[2]); stat_add("chain_prof_groups", (double)hp[3]);
+            }
         }
     } else {
         KTimer kt("chain");
@@ -1231,6 +1253,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (hc[2]) fail(HLMI_ENOMEM, "chain output buffer overflowed (pieces %u/%u)", hc[0], ca.cap_pieces);
     out.n_pieces = hc[0];
     out.n_fp = hc[3];
+    stat_add("chain_groups_full_dp", (double)hc[1]);
 }
 
 }  // namespace hlmi
