@@ -173,7 +173,9 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         std::nth_element(ql.begin(), ql.begin() + (std::ptrdiff_t)k98, ql.end());
         const int spare = 64 - (bits_for(nT > 1 ? nT - 1 : 1) + 1 + bits_for(max_tlen) + bits_for(std::max<uint64_t>(ql[k98], 1)) + 8);
         // (never below 2048: a batch of many short reads rather takes the key + value form than ends early)
-        q_cap = std::min<size_t>(q_cap, std::max<size_t>(2048, (size_t)1 << std::max(0, std::min(spare, 16))));
+        size_t q_floor = 2048;
+        if (const char *e = getenv("HLMI_QCAP_MIN")) q_floor = (size_t)std::max(1, atoi(e));      // tuning hook
+        q_cap = std::min<size_t>(q_cap, std::max<size_t>(q_floor, (size_t)1 << std::max(0, std::min(spare, 16))));
     }
     size_t q = 0;
     while (q < nQ) {
