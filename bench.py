@@ -308,7 +308,7 @@ def main():
                                         "rows_after_v4", "snp_events", "pairs", "rows_out")}
     pass_steps = shares
     pass_s = (sum(step_s[-pass_steps:]) / min(pass_steps, len(step_s))) * pass_steps
-    pass_rows = (sum(step_rows[-pass_steps:]) / min(pass_steps, len(step_rows))) * pass_steps * (world if world > 1 else 1)
+    pass_rows = rows / args.steps * pass_steps          # all ranks, per complete pass
     line = dict(metric="long-read all-vs-all overlaps/sec", value=value, unit="overlaps/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                 scaling="weak" if slices > 1 else "strong", vs_baseline=None, dtype="u8/int32", data="synthetic",
@@ -317,6 +317,7 @@ def main():
                                   f"(chunk c: slice c % {slices}) x all queries; {shares} steps = one full pass"
                                   if slices > 1 else "one full pass"),
                             parallelism=f"chunks%{slices if slices > 1 else world}", **stage, overlaps_out=rows,
+                            candidate_rows_per_s=(stats.get("ava_rows", 0.0) * world) / step_s[-1],
                             last_step=counts),
                 roofline=roof,
                 # the drop-in call's view: FASTA parsing + upload of the reads + sketch/exchange + one full pass
