@@ -15,6 +15,7 @@
 // oracle/ava_oracle.c:band_dp.  VALU bound by nature: reads ~1 B per
 // DP row per sequence from HBM.
 #include <algorithm>
+#include <type_traits>
 
 #include "ava_internal.h"
 #include "dev_prims.h"
@@ -116,6 +117,7 @@ struct AlignArgs {
     const uint8_t *qcodes, *tcodes;
     long long q_total, t_total;   // bytes in qcodes / tcodes (4-base loads stay inside)
     int match, mismatch, go, ge, ambi;
+    int go2, ge2;           // second piece of the gap cost (go2 <= 0: one piece); only the 64-diagonal kernel can meet gaps long enough for it
     int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     int kgap1;              // 1: blocks with |n - m| = 1 and one substitution finish in the classifier (fifth certificate)
@@ -401,7 +403,9 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
                 runs[nr++] = (uint32_t)gap << 4 | (del ? OP_D : OP_I);
                 seg(p_star, mn);
                 const int subs = xpos >= 0 ? 1 : 0;
-                fast_score = a.match * (mn - subs) - a.mismatch * subs - a.go - a.ge * gap;
+                int gap_cost = a.go + a.ge * gap;
+                if (a.go2 && a.go2 + a.ge2 * gap < gap_cost) gap_cost = a.go2 + a.ge2 * gap;       // the cheaper piece
+                fast_score = a.match * (mn - subs) - a.mismatch * subs - gap_cost;
                 fast = true;
                 c = 0;
             }
@@ -937,15 +941,30 @@ __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArg
 constexpr int WT_PAD = 64;                                  // st index of target offset 0 (dlo >= -51)
 constexpr int WT_LEN = WT_PAD + SEQ_T_MAX + 64;
 
-template <bool AMBI, bool EXT, int W_CHUNKS>
+// Planes of the 64-diagonal kernel.  Two-piece gap cost: min(go + ge L, go2 + ge2 L) - every gap state exists once per
+// piece, E = max(E1, E2), F = max(F1, F2), the first piece on ties (oracle/ava_oracle.c:band_dp).  With one piece the
+// second piece's planes stay zero and its states at "-inf".
+//   DIAG  mm == h                 the cell took the diagonal move (ties: M > E > F)
+//   EGEF  e >= f                  otherwise E, else F
+//   EP/FP e2 > e1 / f2 > f1       the gap state that made E / F is the second piece
+//   EX1/2 e_p + go_p > h          E_p of the cell to the RIGHT extends this cell's E_p
+//   FX1/2 f_p - ge_p > h - go_p - ge_p   F_p of the cell BELOW extends this cell's F_p
+//   NE    q != t
+enum { WP_DIAG = 0, WP_EGEF, WP_EP, WP_FP, WP_EX1, WP_EX2, WP_FX1, WP_FX2, WP_NE, N_WPLANES };
+
+template <bool AMBI, bool EXT, bool TWO, int W_CHUNKS>
 __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int dlo, int lane, int end_row,
                                           const uint8_t *sq, const uint8_t *st, uint32_t (*pl)[W_CHUNKS][64], int &Hend,
                                           int &best_h, int &best_i) {
     const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * lane, goel = go + ge * lane;
+    const int go2 = a.go2, ge2 = a.ge2, goe2 = go2 + ge2, gel2 = ge2 * lane, goel2 = go2 + ge2 * lane;
     const int j0 = dlo + lane;
-    int H = j0 == 0 ? DP_BIAS : (j0 > 0 ? DP_BIAS - (go + ge * j0) : 0);      // row 0 (biased scores, see narrow_rows)
-    int G = H - goe;
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    // row 0 (biased scores, see narrow_rows): a gap from the corner, the cheaper piece
+    int gap0 = go + ge * j0;
+    if (TWO && go2 + ge2 * j0 < gap0) gap0 = go2 + ge2 * j0;
+    int H = j0 == 0 ? DP_BIAS : (j0 > 0 ? DP_BIAS - gap0 : 0);
+    int G = H - goe, G2 = TWO ? H - goe2 : 0;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     int v_match = a.match, v_mis = -a.mismatch;
     asm volatile("" : "+v"(v_match), "+v"(v_mis));
     const uint8_t *tp = st + WT_PAD + dlo + lane - 1;                 // target base of row i: tp[i]
@@ -960,17 +979,29 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
         int s = ne ? v_mis : v_match;
         if (AMBI) s = (qa | t2) > 3 ? -a.ambi : s;
         const int mm = H + s;
-        const int f = wave_shl1_z(G);
+        const int f1 = wave_shl1_z(G);
+        const int f2 = TWO ? wave_shl1_z(G2) : 0;
+        const int f = TWO && f2 > f1 ? f2 : f1;
         const int ht = mm > f ? mm : f;
-        const int e = wave_shr1(wave_prefix_max_incl_dpp(ht + gel), 0) - goel;
+        const int e1 = wave_shr1(wave_prefix_max_incl_dpp(ht + gel), 0) - goel;
+        const int e2 = TWO ? wave_shr1(wave_prefix_max_incl_dpp(ht + gel2), 0) - goel2 : 0;
+        const int e = TWO && e2 > e1 ? e2 : e1;
         const int h = ht > e ? ht : e;
-        const int fo = h - goe, fe = f - ge;
+        const int fo = h - goe, fe = f1 - ge;
         a0 = shift_in(a0, mm == h);
         a1 = shift_in(a1, e >= f);
-        a2 = shift_in(a2, e + go > h);
+        a2 = shift_in(a2, e1 + go > h);
         a3 = shift_in(a3, fe > fo);
         a4 = shift_in(a4, ne);
         G = fo > fe ? fo : fe;
+        if (TWO) {
+            const int fo2 = h - goe2, fe2 = f2 - ge2;
+            b0 = shift_in(b0, e2 > e1);
+            b1 = shift_in(b1, f2 > f1);
+            b2 = shift_in(b2, e2 + go2 > h);
+            b3 = shift_in(b3, fe2 > fo2);
+            G2 = fo2 > fe2 ? fo2 : fe2;
+        }
         H = h;
         qa = qa_next; t2 = t2_next;
         if (EXT) {
@@ -979,22 +1010,86 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
         }
         if ((i & 31) == 0) {
             const int c = (i >> 5) - 1;
-            pl[PL_DIAG][c][lane] = a0; pl[PL_EGEF][c][lane] = a1; pl[PL_EEXT][c][lane] = a2; pl[PL_FEXT][c][lane] = a3;
-            pl[PL_NE][c][lane] = a4;
+            pl[WP_DIAG][c][lane] = a0; pl[WP_EGEF][c][lane] = a1; pl[WP_EX1][c][lane] = a2; pl[WP_FX1][c][lane] = a3;
+            pl[WP_NE][c][lane] = a4;
+            if (TWO) { pl[WP_EP][c][lane] = b0; pl[WP_FP][c][lane] = b1; pl[WP_EX2][c][lane] = b2; pl[WP_FX2][c][lane] = b3; }
         }
     }
     Hend = H;
     if (m & 31) {
         const int c = m >> 5, up = 32 - (m & 31);
-        pl[PL_DIAG][c][lane] = a0 << up; pl[PL_EGEF][c][lane] = a1 << up; pl[PL_EEXT][c][lane] = a2 << up;
-        pl[PL_FEXT][c][lane] = a3 << up; pl[PL_NE][c][lane] = a4 << up;
+        pl[WP_DIAG][c][lane] = a0 << up; pl[WP_EGEF][c][lane] = a1 << up; pl[WP_EX1][c][lane] = a2 << up;
+        pl[WP_FX1][c][lane] = a3 << up; pl[WP_NE][c][lane] = a4 << up;
+        if (TWO) { pl[WP_EP][c][lane] = b0 << up; pl[WP_FP][c][lane] = b1 << up; pl[WP_EX2][c][lane] = b2 << up; pl[WP_FX2][c][lane] = b3 << up; }
     }
+}
+
+// Traceback of one 64-diagonal task by one lane (the scheme of narrow_walk with the gap states per piece): runs in
+// reverse, the first `cap` kept in `buf`, with `out` written to out[total-1 .. 0] (left extensions in emission order).
+template <bool TWO>
+__device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, int dlo, bool keep_order, uint32_t *out, uint32_t total,
+                              uint32_t *buf, uint32_t cap) {
+    auto word = [&](int plane, int c, int lane) { return pl[(plane * chunks + c) * 64 + lane]; };
+    int i = m0, j = n0, state = 0;                    // state: 0 H, 1 E1, 2 F1, 3 E2, 4 F2
+    uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
+    auto put = [&]() {
+        if (out) out[keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op;
+        else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
+        ++n_runs;
+    };
+    for (int it = 0; (i > 0 || j > 0) && it < 4 * (EXT_MAX + SEQ_T_MAX); ++it) {
+        uint32_t op, len;
+        if (i == 0) {                                          // row 0: H(0,j) is a gap from the corner
+            op = OP_D; len = (uint32_t)j; j = 0;
+        } else {
+            const int d = (j - i - dlo) & (BAND_W - 1);
+            const int c = (i - 1) >> 5, sh = 31 - ((i - 1) & 31);
+            const int i2 = i > 1 ? i - 2 : 0, c2 = i2 >> 5, sh2 = 31 - (i2 & 31);
+            int st = state;
+            if (st == 0) {
+                const uint32_t dg = word(WP_DIAG, c, d) >> sh;
+                if (dg & 1u) st = 0;
+                else if ((word(WP_EGEF, c, d) >> sh) & 1u) st = TWO && ((word(WP_EP, c, d) >> sh) & 1u) ? 3 : 1;
+                else st = TWO && ((word(WP_FP, c, d) >> sh) & 1u) ? 4 : 2;
+                if (st == 0) {
+                    const uint32_t ne = word(WP_NE, c, d) >> sh;
+                    const uint32_t inv = ~dg;
+                    const int r = inv ? __ffs((int)inv) - 1 : 32;                 // diagonal moves in a row (this word)
+                    const bool isx = (ne & 1u) != 0;
+                    const uint32_t flip = isx ? ~ne : ne;
+                    int l = flip ? __ffs((int)flip) - 1 : 32;
+                    l = l < r ? l : r;
+                    op = isx ? OP_X : OP_EQ; len = (uint32_t)l;
+                    i -= l; j -= l;
+                    state = 0;
+                    if (op == cur_op) cur_len += len;
+                    else { if (cur_len) put(); cur_op = op; cur_len = len; }
+                    continue;
+                }
+            }
+            if (st == 1 || st == 3) {                          // E_p of this cell extends the E_p of the cell to the left
+                const uint32_t ex = word(st == 1 ? WP_EX1 : WP_EX2, c, (d - 1) & 63) >> sh;
+                op = OP_D; len = 1;
+                state = (ex & 1u) ? st : 0;
+                --j;
+            } else {                                           // F_p of this cell extends the F_p of the cell above
+                const uint32_t fx = word(st == 2 ? WP_FX1 : WP_FX2, c2, (d + 1) & 63) >> sh2;
+                op = OP_I; len = 1;
+                state = (i > 1 && (fx & 1u)) ? st : 0;
+                --i;
+            }
+        }
+        if (op == cur_op) cur_len += len;
+        else { if (cur_len) put(); cur_op = op; cur_len = len; }
+    }
+    if (cur_len) put();
+    return n_runs;
 }
 
 template <int ROWS_MAX>
 __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
     constexpr int W_CHUNKS = ROWS_MAX / 32;
-    __shared__ uint32_t s_pl[WAVES][N_PLANES][W_CHUNKS][64];
+    __shared__ uint32_t s_pl[WAVES][N_WPLANES][W_CHUNKS][64];
     __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][ROWS_MAX + 4];
     __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][WT_LEN];
     __shared__ uint32_t s_runs[WAVES][RUN_BUF_WIDE];
@@ -1037,12 +1132,18 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         const int end_row = kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
         int Hend = 0, best_h = 0, best_i = 0;
         const bool amb = __any(ambig);
+        const bool two = a.go2 > 0;
+        auto rows_of = [&](auto AMB, auto EXTN, auto TW) {
+            wide_rows<decltype(AMB)::value, decltype(EXTN)::value, decltype(TW)::value, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend,
+                                                                                                best_h, best_i);
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
         if (kind == 0) {
-            if (amb) wide_rows<true, false, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
-            else wide_rows<false, false, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            if (two) { if (amb) rows_of(T_{}, F_{}, T_{}); else rows_of(F_{}, F_{}, T_{}); }
+            else { if (amb) rows_of(T_{}, F_{}, F_{}); else rows_of(F_{}, F_{}, F_{}); }
         } else {
-            if (amb) wide_rows<true, true, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
-            else wide_rows<false, true, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend, best_h, best_i);
+            if (two) { if (amb) rows_of(T_{}, T_{}, T_{}); else rows_of(F_{}, T_{}, T_{}); }
+            else { if (amb) rows_of(T_{}, T_{}, F_{}); else rows_of(F_{}, T_{}, F_{}); }
         }
         int ei, ej, score;
         if (kind == 0) {
@@ -1070,14 +1171,16 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_WIDE ? a.run_buf_cap : (uint32_t)RUN_BUF_WIDE;
         uint32_t cp_n = 0, cp_off = 0;
         if (lane == 0) {
-            const NarrowWalk w{&pl[0][0][0], W_CHUNKS, 0, ei, ej, dlo, BAND_W - 1, kind == 1};
-            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap);
+            const uint32_t *planes = &pl[0][0][0];
+            const uint32_t n_runs = two ? wide_walk<true>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, nullptr, 0, rbuf, rcap)
+                                        : wide_walk<false>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, nullptr, 0, rbuf, rcap);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
             if (ok && n_runs) {
                 if (n_runs <= rcap) { cp_n = n_runs; cp_off = off; }
-                else narrow_walk(w, a.runs + off, n_runs);
+                else if (two) wide_walk<true>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, a.runs + off, n_runs, nullptr, 0);
+                else wide_walk<false>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, a.runs + off, n_runs, nullptr, 0);
             }
             a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0,
                                 2u | ((uint32_t)m & 0xfffffu) << 2 | (kind != 0 && ei == end_row ? 0x80000000u : 0u)};
@@ -1252,6 +1355,10 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         aa.q_total = (long long)in.Q->total; aa.t_total = (long long)in.T->total;
         aa.end_bonus = o.end_bonus;
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
+        aa.go2 = o.gap_open2 > 0 ? o.gap_open2 : 0; aa.ge2 = o.gap_open2 > 0 ? o.gap_ext2 : 0;
+        // the 16-diagonal kernels (gaps of at most 15 bases) know the first piece only
+        if (aa.go2 && aa.go2 + aa.ge2 * (NARROW_W - 1) < aa.go + aa.ge * (NARROW_W - 1))
+            fail(HLMI_EINVAL, "two-piece gap cost: the second piece must not be the cheaper one below %d bases", NARROW_W);
         {   // largest k with k*(match+mismatch) < match + 2*(open+ext), capped at 3 (7 runs)
             const int den = o.match + o.mismatch, num = o.match + 2 * (o.gap_open + o.gap_ext);
             aa.kmax = den > 0 && num > 0 ? std::min(3, (num - 1) / den) : 0;

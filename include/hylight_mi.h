@@ -109,6 +109,10 @@ typedef struct {
     int min_dp_score;      /* alignment pieces below this DP score are dropped: 80 (long), 60 (-s 60, short) */
     int end_bonus;         /* bonus for an end extension that reaches the query end: 0 (long), 100 (short) */
     int pair_once;         /* 1: report a pair only with strcmp(qname,tname) < 0 (ava-pb -X); 0: every non-self pair */
+    int gap_open2, gap_ext2;   /* second piece of the gap cost: a gap of L bases costs min(gap_open + gap_ext L, gap_open2 +
+                                  gap_ext2 L): 24, 1 (long: the preset's -O4,24 -E2,1), 32, 1 (short: --sr's -O12,32 -E2,1);
+                                  gap_open2 <= 0: one piece.  The second piece must not be the cheaper one for gaps of
+                                  fewer than 16 bases (the 16-diagonal kernels work with the first piece alone). */
 } hlmi_ava_opts;
 void hlmi_ava_opts_long(hlmi_ava_opts *o);    /* the constants of slr2:51 (ava-pb -Hk19 -m100 -g10000) */
 void hlmi_ava_opts_short(hlmi_ava_opts *o);   /* the constants of slr2:55 (--sr -k21 -w11 -s60 -m30 -n2 -A4 -B2 --end-bonus=100) */

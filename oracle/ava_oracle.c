@@ -23,6 +23,7 @@ typedef struct {
     double mid_occ_frac;
     int match, mismatch, gap_open, gap_ext, ambi;
     int min_dp_score, end_bonus, pair_once;
+    int gap_open2, gap_ext2;   /* second piece of the gap cost: a gap of L bases costs min(open + ext L, open2 + ext2 L); open2 <= 0: one piece */
 } ava_opts_t;   /* same layout as hlmi_ava_opts (include/hylight_mi.h) */
 
 /* ---- fixed constants of the spec -------------------------------------------- */
@@ -303,18 +304,24 @@ static inline int sub_score(const ava_opts_t *o, int a, int b) {
  * Cells: H = max(M, E, F) with priority M, E, F on ties; E (gap in query, consumes target, 'D'),
  * F (gap in target, consumes query, 'I'); open preferred over extend on ties. */
 static __thread int g_last_rank;
+/* Two-piece gap cost (minimap2 -O4,24 -E2,1: filter_overlap_slr2.py:51 leaves the ava-pb preset's values in place): every
+ * gap state exists once per piece, E = max(E1, E2), F = max(F1, F2) with the first piece on ties.  Traceback byte:
+ * bits 0-1 source of H (0 M, 1 E, 2 F), bit 2 / 3 E1 / F1 extended, bit 4 / 5 E2 / F2 extended, bit 6 / 7 E / F is the
+ * second piece. */
 static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, const uint8_t *t, int tstride, int n,
                    int dlo, int W, int mode, int end_row, int *bi, int *bj, uint32_t *rev_ops, int *n_rev) {
-    const int go = o->gap_open, ge = o->gap_ext;
+    const int two = o->gap_open2 > 0;
+    const int go[2] = {o->gap_open, two ? o->gap_open2 : o->gap_open}, ge[2] = {o->gap_ext, two ? o->gap_ext2 : o->gap_ext};
     int rows = m + 1;
     uint8_t *tb = (uint8_t *)malloc((size_t)rows * W);
-    int32_t *H = (int32_t *)malloc((size_t)rows * W * 4), *E = (int32_t *)malloc((size_t)rows * W * 4),
-            *F = (int32_t *)malloc((size_t)rows * W * 4);
+    int32_t *H = (int32_t *)malloc((size_t)rows * W * 4);
+    int32_t *E[2], *F[2];
+    for (int p = 0; p < 2; ++p) { E[p] = (int32_t *)malloc((size_t)rows * W * 4); F[p] = (int32_t *)malloc((size_t)rows * W * 4); }
     int best = NEG_INF, best_i = 0, best_j = 0, best_h = NEG_INF;   /* best: score + end bonus (ranking), best_h: score */
     for (int i = 0; i <= m; ++i)
         for (int dd = 0; dd < W; ++dd) {
             int j = i + dlo + dd, idx = i * W + dd;
-            int h = NEG_INF, e = NEG_INF, f = NEG_INF;
+            int h = NEG_INF, e[2] = {NEG_INF, NEG_INF}, f[2] = {NEG_INF, NEG_INF};
             uint8_t b = 0;
             if (j >= 0 && j <= n) {
                 if (i == 0 && j == 0) h = 0;
@@ -324,19 +331,24 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
                         int hp = H[(i - 1) * W + dd];
                         if (hp > NEG_INF) mm = hp + sub_score(o, q[(i - 1) * qstride], t[(j - 1) * tstride]);
                     }
-                    if (j > 0 && dd > 0) {  /* horizontal: (i, j-1) = dd-1 same row */
-                        int hl = H[idx - 1], el = E[idx - 1];
-                        int open = hl > NEG_INF ? hl - go - ge : NEG_INF, ext = el > NEG_INF ? el - ge : NEG_INF;
-                        if (open >= ext) { e = open; } else { e = ext; b |= 4; }
+                    for (int p = 0; p < 1 + two; ++p) {
+                        if (j > 0 && dd > 0) {  /* horizontal: (i, j-1) = dd-1 same row */
+                            int hl = H[idx - 1], el = E[p][idx - 1];
+                            int open = hl > NEG_INF ? hl - go[p] - ge[p] : NEG_INF, ext = el > NEG_INF ? el - ge[p] : NEG_INF;
+                            if (open >= ext) { e[p] = open; } else { e[p] = ext; b |= p ? 16 : 4; }
+                        }
+                        if (i > 0 && dd + 1 < W) {  /* vertical: (i-1, j) = dd+1 in row i-1 */
+                            int hu = H[(i - 1) * W + dd + 1], fu = F[p][(i - 1) * W + dd + 1];
+                            int open = hu > NEG_INF ? hu - go[p] - ge[p] : NEG_INF, ext = fu > NEG_INF ? fu - ge[p] : NEG_INF;
+                            if (open >= ext) { f[p] = open; } else { f[p] = ext; b |= p ? 32 : 8; }
+                        }
                     }
-                    if (i > 0 && dd + 1 < W) {  /* vertical: (i-1, j) = dd+1 in row i-1 */
-                        int hu = H[(i - 1) * W + dd + 1], fu = F[(i - 1) * W + dd + 1];
-                        int open = hu > NEG_INF ? hu - go - ge : NEG_INF, ext = fu > NEG_INF ? fu - ge : NEG_INF;
-                        if (open >= ext) { f = open; } else { f = ext; b |= 8; }
-                    }
-                    if (mm >= e && mm >= f) { h = mm; b |= 0; }
-                    else if (e >= f) { h = e; b |= 1; }
-                    else { h = f; b |= 2; }
+                    int eb = e[0], fb = f[0];
+                    if (two && e[1] > e[0]) { eb = e[1]; b |= 64; }
+                    if (two && f[1] > f[0]) { fb = f[1]; b |= 128; }
+                    if (mm >= eb && mm >= fb) { h = mm; b |= 0; }
+                    else if (eb >= fb) { h = eb; b |= 1; }
+                    else { h = fb; b |= 2; }
                     if (h < NEG_INF) h = NEG_INF;
                 }
                 if (mode == 1 && h > NEG_INF) {
@@ -346,13 +358,14 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
                     }
                 }
             }
-            H[idx] = h; E[idx] = e; F[idx] = f; tb[idx] = b;
+            H[idx] = h; tb[idx] = b;
+            for (int p = 0; p < 2; ++p) { E[p][idx] = e[p]; F[p][idx] = f[p]; }
         }
     int ei, ej, score;
     if (mode == 0) { ei = m; ej = n; score = H[m * W + (n - m - dlo)]; }
     else { ei = best_i; ej = best_j; score = best_h; }
     /* traceback */
-    int i = ei, j = ej, state = 0, nr = 0;
+    int i = ei, j = ej, state = 0, piece = 0, nr = 0;
     while (i > 0 || j > 0) {
         int idx = i * W + (j - i - dlo);
         uint8_t b = tb[idx];
@@ -362,14 +375,14 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
                 int eq = q[(i - 1) * qstride] == t[(j - 1) * tstride];
                 rev_ops[nr++] = eq ? 7 : 8;
                 --i; --j;
-            } else state = src;   /* 1: E, 2: F */
+            } else { state = src; piece = src == 1 ? (b >> 6) & 1 : (b >> 7) & 1; }   /* 1: E, 2: F */
         } else if (state == 1) {
             rev_ops[nr++] = 2;   /* D */
-            if (!(b & 4)) state = 0;
+            if (!(b & (piece ? 16 : 4))) state = 0;
             --j;
         } else {
             rev_ops[nr++] = 1;   /* I */
-            if (!(b & 8)) state = 0;
+            if (!(b & (piece ? 32 : 8))) state = 0;
             --i;
         }
     }
@@ -377,7 +390,8 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
     g_last_rank = mode == 1 ? best : score;   /* extension: score + end bonus of the chosen cell */
     if (bi) *bi = ei;
     if (bj) *bj = ej;
-    free(tb); free(H); free(E); free(F);
+    free(tb); free(H);
+    for (int p = 0; p < 2; ++p) { free(E[p]); free(F[p]); }
     return score;
 }
 
@@ -513,22 +527,37 @@ static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
 static void chain_group(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa, const seqset_t *T,
                         const anchor_t *a, int n) {
     int32_t *f = (int32_t *)malloc(n * 4), *p = (int32_t *)malloc(n * 4), *bc = (int32_t *)malloc(n * 4);
+    /* ORACLE_CHAIN_MM2=1 (tests/test_deviation_effects.py only): the predecessor loop of minimap2's chaining as published
+     * (Li 2018 and the --max-chain-skip / max-iteration heuristics HyLight's command line sets: skip 25, 5000
+     * iterations) instead of the specification's fixed window of CHAIN_PRED - to MEASURE what the fixed window changes. */
+    static int mm2_mode = -1;
+    if (mm2_mode < 0) mm2_mode = getenv("ORACLE_CHAIN_MM2") ? 1 : 0;
+    int32_t *tmark = mm2_mode ? (int32_t *)calloc((size_t)n, 4) : 0;
+    if (tmark) for (int i = 0; i < n; ++i) tmark[i] = -1;
     for (int i = 0; i < n; ++i) {
         int32_t best = (int32_t)a[i].qspan, bp = -1;
-        for (int j = i - 1; j >= 0 && j >= i - CHAIN_PRED; --j) {
+        int n_skip = 0;
+        const int window = mm2_mode ? 5000 : CHAIN_PRED;
+        for (int j = i - 1; j >= 0 && j >= i - window; --j) {
             int32_t dr = (int32_t)a[i].tpos - (int32_t)a[j].tpos, dq = (int32_t)a[i].qpos - (int32_t)a[j].qpos;
             if (dq > o->max_gap) break;                       /* query positions only grow going back */
-            if (dr <= 0 || dr > o->max_gap || dq == 0) continue;
-            int32_t dd = dr > dq ? dr - dq : dq - dr;
-            if (dd > o->bandwidth) continue;
-            int32_t dg = dr < dq ? dr : dq;
-            int32_t sc = dg < (int32_t)a[i].qspan ? dg : (int32_t)a[i].qspan;
-            int32_t pen = dd ? (dd * o->k) / 100 + (ilog2_32((uint32_t)dd) >> 1) : 0;
-            int32_t cand = f[j] + sc - pen;
-            if (cand > best) { best = cand; bp = j; }
+            int32_t cand = NEG_INF;
+            if (!(dr <= 0 || dr > o->max_gap || dq == 0)) {
+                int32_t dd = dr > dq ? dr - dq : dq - dr;
+                if (dd <= o->bandwidth) {
+                    int32_t dg = dr < dq ? dr : dq;
+                    int32_t sc = dg < (int32_t)a[i].qspan ? dg : (int32_t)a[i].qspan;
+                    int32_t pen = dd ? (dd * o->k) / 100 + (ilog2_32((uint32_t)dd) >> 1) : 0;
+                    cand = f[j] + sc - pen;
+                }
+            }
+            if (cand > NEG_INF && cand > best) { best = cand; bp = j; if (mm2_mode && n_skip > 0) --n_skip; }
+            else if (mm2_mode && cand > NEG_INF && tmark[j] == i) { if (++n_skip > 25) break; }
+            if (mm2_mode && p[j] >= 0) tmark[p[j]] = i;
         }
         f[i] = best; p[i] = bp;
     }
+    free(tmark);
     for (int i = 0; i < n; ++i) bc[i] = -1;
     for (int i = 0; i < n; ++i)            /* ascending i: a later child wins only with a strictly larger f */
         if (p[i] >= 0 && (bc[p[i]] < 0 || f[i] > f[bc[p[i]]])) bc[p[i]] = i;

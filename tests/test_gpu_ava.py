@@ -146,8 +146,10 @@ def test_ava_noisy_reads(tmp_path, seed, errs):
 
 
 @pytest.mark.parametrize("changes", [
-    dict(mismatch=16, gap_open=20, gap_ext=2),           # scores too large for the 16-bit kernel: the 32-bit form by itself
-    dict(match=1, mismatch=1, gap_open=1, gap_ext=1),     # many ties: the traceback's tie rules decide every block
+    dict(mismatch=16, gap_open=20, gap_ext=2, gap_open2=0),           # scores too large for the 16-bit kernel: the 32-bit form by itself
+    dict(match=1, mismatch=1, gap_open=1, gap_ext=1, gap_open2=0),     # many ties: the traceback's tie rules decide every block
+    dict(gap_open2=0),                                    # one-piece gap cost
+    dict(gap_open=4, gap_ext=3, gap_open2=21, gap_ext2=2),              # second piece cheaper from 18 bases on
     dict(k=15, w=8, bandwidth=300, max_gap=2000, min_chain_score=40),     # other seeds, byte-table gap costs
     dict(bandwidth=3000),                                 # gap-cost table too small: costs computed in the chain DP
 ])
@@ -246,3 +248,52 @@ def test_ava_extremely_repetitive_chunk(tmp_path):
     got, want = open(tmp_path / "g.paf").read(), open(tmp_path / "o.paf").read()
     assert want.count("\n") > 500_000
     assert got == want
+
+
+def test_ava_long_gaps_take_the_second_gap_piece(tmp_path):
+    """minimap2's gap cost has two pieces (-O4,24 -E2,1 in the ava-pb preset HyLight uses): gaps of more than 20 bases are
+    cheaper under the second one.  Strain B differs from strain A by 24-36-base insertions and deletions, so alignments
+    between reads of different strains contain such gaps inside 64-diagonal blocks: the GPU rows must equal the
+    oracle's with the second piece on and off, and the long gaps must be there.  (The PAF carries no alignment score:
+    the second piece shows in the rows only where it tips a choice - a long gap against a run of substitutions, a piece
+    at the minimum DP score - so on most inputs, this one included, the two settings print the same rows.)"""
+    rng = np.random.default_rng(61)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    a = bases[rng.integers(0, 4, size=24_000)]
+    parts, pos = [], 0
+    for k, cut in enumerate(range(1500, 23_000, 1800)):
+        parts.append(a[pos:cut])
+        ln = int(rng.integers(24, 37))
+        if k % 2:
+            parts.append(bases[rng.integers(0, 4, size=ln)])      # insertion in B
+            pos = cut
+        else:
+            pos = cut + ln                                       # deletion in B
+    parts.append(a[pos:])
+    b = np.concatenate(parts)
+    reads = []
+    for i in range(30):
+        g = a if i % 2 == 0 else b
+        s = int(rng.integers(0, len(g) - 7000))
+        e = s + int(rng.integers(4000, 7000))
+        seq = g[s:e].copy()
+        err = rng.random(len(seq)) < 0.004
+        seq[err] = bases[rng.integers(0, 4, size=int(err.sum()))]
+        if i % 3 == 0:
+            seq = S.revcomp(seq)
+        reads.append(S.Read(f"g{i:02d}", np.ascontiguousarray(seq), None, i % 2, s, e, i % 3 == 0))
+    fa = _write(tmp_path, "gaps.fa", reads)
+    api.ava(fa, fa, tmp_path / "g.paf")
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    want = open(tmp_path / "o.paf").read()
+    assert open(tmp_path / "g.paf").read() == want
+    import re
+    long_gaps = [int(n) for n in re.findall(r"(\d+)[ID]", want) if int(n) > 20]
+    assert len(long_gaps) >= 20, len(long_gaps)
+    one = OA.opts_long()
+    one.gap_open2 = 0
+    OA.ava(fa, fa, tmp_path / "o1.paf", one)
+    g1 = api.ava_opts_long()
+    g1.gap_open2 = 0
+    api.ava(fa, fa, tmp_path / "g1.paf", g1)
+    assert open(tmp_path / "g1.paf").read() == open(tmp_path / "o1.paf").read()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel timers of one bench step, repeated: `python tools/slice_probe.py [workload=C3] [slice=0] [reps=3]`.
+"""Kernel timers of one bench step, repeated: `python tools/slice_probe.py [workload=C3] [slice=0] [reps=3] [scale=1]`.
 Prints the per-kernel HIP-event times of the last repetition and the wall time of each (tuning aid)."""
 import json
 import os
@@ -14,8 +14,9 @@ from hylight_amd.stage import StageRunner     # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 sl = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 slices = {"C3": 8, "C2": 1}.get(wl, 8)
-cfg = W.config(wl)
+cfg = W.config(wl, scale)
 work = os.environ.get("HL_BENCH_DIR") or tempfile.mkdtemp(prefix="hl_probe_")
 fa = os.path.join(work, cfg["name"] + ".fa")
 if not os.path.exists(fa):
