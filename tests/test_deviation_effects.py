@@ -63,3 +63,36 @@ def test_two_piece_gap_cost_vs_one_piece(sample):
     print("two-piece vs one-piece gap cost:", r)
     # C2 has single-base indels only: the second piece (gaps > 20 bases) cannot show
     assert r["identical"] == r["rows_a"] == r["rows_b"]
+
+
+def test_against_minimap2_when_one_is_installed(sample):
+    """Opportunistic: with a `minimap2` on $PATH, run the exact command of script/filter_overlap_slr2.py:51 on the sample
+    and report how the specification's rows relate to it (pair recall, coordinate deltas).  minimap2 is not part of the
+    reference tree, so without one this is skipped and a3 stays "parity unpinned"."""
+    import shutil
+    mm2 = shutil.which("minimap2")
+    if not mm2:
+        pytest.skip("no minimap2 on PATH: parity of the overlapper stays unpinned")
+    d, q, t = sample
+    spec = [l.split("\t") for l in _run(q, t, str(d / "spec_mm.paf"))]
+    with open(d / "real.paf", "w") as out:
+        subprocess.run([mm2, "-N", "40", "-t", "1", "-L", "--eqx", "-cx", "ava-pb", "-Hk19", "-m100", "-g10000",
+                        "--max-chain-skip", "25", t, q], stdout=out, stderr=subprocess.DEVNULL, check=True)
+    real = [l.split("\t") for l in open(d / "real.paf").read().split("\n")[:-1]]
+    key = lambda f: (f[0], f[5], f[4])
+    best = {}
+    for f in real:                                  # the longest row of a (query, target, strand)
+        if f[0] != f[5] and (key(f) not in best or int(f[10]) > int(best[key(f)][10])):
+            best[key(f)] = f
+    mine = {}
+    for f in spec:
+        if key(f) not in mine or int(f[10]) > int(mine[key(f)][10]):
+            mine[key(f)] = f
+    both = set(best) & set(mine)
+    deltas = sorted(max(abs(int(best[k][i]) - int(mine[k][i])) for i in (2, 3, 7, 8)) for k in both)
+    print("minimap2 rows %d (pairs %d), specification rows %d (pairs %d), common pairs %d, "
+          "median / p95 / max coordinate delta of the longest row: %s"
+          % (len(real), len(best), len(spec), len(mine), len(both),
+             (deltas[len(deltas) // 2], deltas[int(0.95 * (len(deltas) - 1))], deltas[-1]) if deltas else None))
+    long_pairs = {k for k, f in best.items() if int(f[10]) >= 6000}
+    assert len(long_pairs & set(mine)) >= 0.95 * len(long_pairs)      # recall on the pairs the stage could keep
