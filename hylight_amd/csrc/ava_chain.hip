@@ -146,6 +146,8 @@ struct SeedArgs {
     int pair_once;              // 1: only strcmp(qname,tname) < 0; 0: every pair except self
     int pb, tb;                 // key layout: tpos bits, target bits
     int vb;                     // payload bits below tpos: 8 + qpos bits when the anchor is one word, 0 with a value array
+    int sk;                     // 0, or the bytes (2 / 4) of a separate (target, strand) key: the word then holds the rest
+    void *oskey;                // that key array
 };
 
 // Wave-cooperative: a wave owns 64 consecutive query minimizers.  Every lane binary-searches the
@@ -249,7 +251,11 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
                 const unsigned long long at = w + __popcll(mask & ((1ull << lane) - 1));
                 const uint64_t kk = (uint64_t)(q - a.q_lo) << (a.tb + 1 + a.pb) | (uint64_t)t << (1 + a.pb) |
                                     (uint64_t)strand << a.pb | tpos;
-                if (a.vb) okey[at] = kk << a.vb | (uint64_t)qp << 8 | qspan;
+                if (a.sk) {         // the sorted bits apart: (target, strand) in a small key, the rest in one word
+                    okey[at] = ((uint64_t)(q - a.q_lo) << a.pb | tpos) << a.vb | (uint64_t)qp << 8 | qspan;
+                    if (a.sk == 2) ((uint16_t *)a.oskey)[at] = (uint16_t)(t << 1 | strand);
+                    else ((uint32_t *)a.oskey)[at] = t << 1 | strand;
+                } else if (a.vb) okey[at] = kk << a.vb | (uint64_t)qp << 8 | qspan;
                 else { okey[at] = kk; oval[at] = (uint64_t)qp << 32 | (uint64_t)qspan << 24; }
             }
             const uint32_t n = (uint32_t)__popcll(mask);
@@ -318,6 +324,8 @@ __device__ __forceinline__ bool block_ok(int q0, int t0, int q1, int t1) {
 
 struct ChainArgs {
     const uint64_t *key, *val;
+    const void *skey;                 // (target << 1 | strand) of every anchor when the key word does not hold them
+    int sk;                           //   its width in bytes (2 / 4), 0: the bits sit in `key` above the target position
     const uint32_t *gstart;
     const uint32_t *gorder;           // groups, largest first (the order the workgroups take them in)
     size_t n_list;                    // groups in gorder (this launch's share of the n_groups groups)
@@ -341,6 +349,13 @@ struct ChainArgs {
     unsigned long long *check_bad;    //   the full DP then compares its scores / predecessors with fp and counts differences
 };
 
+// query in the batch || target || strand of the group whose first anchor is b
+__device__ __forceinline__ uint64_t group_word(const ChainArgs &a, size_t b) {
+    const uint64_t top = a.key[b] >> (a.vb + a.pb);
+    if (!a.sk) return top;
+    const uint32_t ts = a.sk == 2 ? (uint32_t)((const uint16_t *)a.skey)[b] : ((const uint32_t *)a.skey)[b];
+    return top << (a.tb + 1) | ts;
+}
 // target position, query position, span of anchor idx
 __device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, int &t, int &q, int &sp) {
     const uint64_t key = a.key[idx];
@@ -571,7 +586,7 @@ __device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, u
         const size_t b = a.gstart[g], e = g + 1 < a.n_groups ? (size_t)a.gstart[g + 1] : a.n_anchors;
         n = (int)(e - b);
         if (n < a.min_cnt) n = 0;                                  // nobody chains it
-        const uint32_t strand = (uint32_t)(a.key[b] >> (a.vb + a.pb)) & 1u;
+        const uint32_t strand = (uint32_t)group_word(a, b) & 1u;
         g_first = strand ? b + (size_t)(e - b) - 1 : b;
         g_step = strand ? -1 : 1;
     }
@@ -706,7 +721,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         // depend on f (gap geometry, gap cost look-up) is computed one step ahead.  Predecessors arrive in ascending
         // order, so "candidate >= best" gives ties to the closest one; M_best starts at span + 1 so that the first
         // predecessor needs candidate > span.
-        const uint64_t key0 = a.key[b] >> (a.vb + a.pb);
+        const uint64_t key0 = group_word(a, b);
         const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1));
         const uint32_t tg = (uint32_t)(key0 >> 1) & ((1u << a.tb) - 1);
         const uint32_t strand = (uint32_t)key0 & 1u;
@@ -1129,10 +1144,16 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     const int qbits = bits_for((uint64_t)(q_hi - q_lo - 1 ? q_hi - q_lo - 1 : 1)), qpb = bits_for(max_qlen);
     // one 64-bit word per anchor when everything fits: the sort moves half the bytes and needs no value array
     // (HLMI_ANCHOR_PAIRS=1 forces the key + value form: test hook for the path wide inputs take)
-    const bool fits = qbits + tb + 1 + pb + qpb + 8 <= 64 && !getenv("HLMI_ANCHOR_PAIRS");
-    const int vb = fits ? qpb + 8 : 0;
+    // else, when the word holds everything but the (target, strand) bits, those go to a 2- or 4-byte key of their own: the
+    // sort moves 10 or 12 bytes per anchor instead of 16 (HLMI_ANCHOR_SPLIT=1 forces this form, test hook)
+    const bool pairs = getenv("HLMI_ANCHOR_PAIRS") != nullptr;
+    const bool fits = qbits + tb + 1 + pb + qpb + 8 <= 64 && !pairs && !getenv("HLMI_ANCHOR_SPLIT");
+    const bool split = !fits && !pairs && qbits + pb + qpb + 8 <= 64;
+    const int vb = fits || split ? qpb + 8 : 0;
+    const char *force = getenv("HLMI_ANCHOR_SPLIT");         // "4": the wide key also where two bytes would do
+    const int sk = split ? (tb + 1 <= 16 && !(force && force[0] == '4') ? 2 : 4) : 0;
     SeedArgs sa = make_seed_args(in, ix, plan, d_qlen, q_lo, q_hi);
-    sa.pb = pb; sa.tb = tb; sa.vb = vb;
+    sa.pb = pb; sa.tb = tb; sa.vb = vb; sa.sk = sk;
     if (!sa.n_mz || !ix.n) return;
     const uint32_t *cnt = plan.cnt.p + in.qmz_off[q_lo];
     DBuf<uint64_t> aoff(sa.n_mz);
@@ -1140,11 +1161,14 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     size_t A = 0;                               // the plan knows the anchors of every query: no round trip to the device
     for (size_t q = q_lo; q < q_hi; ++q) A += plan.per_query[q];
     st.anchors += A;
-    stat_add("anchor_bytes", (double)A * (vb ? 8.0 : 16.0));
+    stat_add("anchor_bytes", (double)A * (sk ? 8.0 + sk : vb ? 8.0 : 16.0));
     if (!A) return;
     if (A >= (1ull << 31) - 1024) fail(HLMI_EINVAL, "anchor batch too large");      // fixed points sit at 2 x anchor offsets
     HostTimer *ht_s = new HostTimer("seed_sort_phase");
     DBuf<uint64_t> akey(A), aval(vb ? 1 : A);
+    DBuf<uint16_t> sk16(sk == 2 ? A : 0);
+    DBuf<uint32_t> sk32(sk == 4 ? A : 0);
+    sa.oskey = sk == 2 ? (void *)sk16.p : (void *)sk32.p;
     {
         KTimer kt("seed_fill");
         hipLaunchKernelGGL(seed_kernel<true>, grid1(sa.n_mz), dim3(WG), 0, stream(), sa, nullptr, aoff.p, akey.p, aval.p);
@@ -1156,11 +1180,15 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         // grouping only: anchors are generated query by query, so a stable sort on the (target, strand) bits alone
         // leaves every (target, strand, query) group contiguous and in generation order = ascending query position
         // (descending on the reverse strand); neither the position bits nor the query bits are sorted
-        if (vb) sort_keys_u64(akey, A, vb + pb, vb + pb + 1 + tb);
+        if (sk == 2) sort_pairs_u16_u64(sk16, akey, A, 0, 1 + tb);
+        else if (sk == 4) sort_pairs_u32_u64(sk32, akey, A, 0, 1 + tb);
+        else if (vb) sort_keys_u64(akey, A, vb + pb, vb + pb + 1 + tb);
         else sort_pairs_u64_u64(akey.p, aval.p, A, pb, pb + 1 + tb);
     }
+    const void *skey = sk == 2 ? (const void *)sk16.p : (const void *)sk32.p;
     DBuf<uint32_t> gstart(A);
-    const size_t G = select_run_heads_u64(akey.p, A, vb + pb, gstart.p);
+    const size_t G = sk ? select_run_heads_split(skey, sk, akey.p, A, vb + pb, gstart.p)
+                        : select_run_heads_u64(akey.p, A, vb + pb, gstart.p);
     st.groups += G;
     delete ht_s;
 
@@ -1185,7 +1213,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
             }
         }
     }
-    ca.key = akey.p; ca.val = aval.p; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
+    ca.key = akey.p; ca.val = aval.p; ca.skey = skey; ca.sk = sk; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
     DBuf<int> mem(A), root(A);
     DBuf<unsigned long long> peak(A);             // written by the kernel at every chain start before it is voted on
     DBuf<uint32_t> sbase(A);

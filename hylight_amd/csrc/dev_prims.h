@@ -17,6 +17,9 @@ template <typename T> struct DBuf;
 void sort_keys_u64(DBuf<uint64_t> &keys, size_t n, int begin_bit = 0, int end_bit = 64);
 void sort_pairs_u64_u32(DBuf<uint64_t> &keys, DBuf<uint32_t> &vals, size_t n, int begin_bit = 0, int end_bit = 64);
 void sort_pairs_u32_u32(DBuf<uint32_t> &keys, DBuf<uint32_t> &vals, size_t n, int begin_bit = 0, int end_bit = 32);
+// small key + 64-bit value (anchor batches: the (target, strand) bits apart from the rest of the anchor)
+void sort_pairs_u16_u64(DBuf<uint16_t> &keys, DBuf<uint64_t> &vals, size_t n, int begin_bit = 0, int end_bit = 16);
+void sort_pairs_u32_u64(DBuf<uint32_t> &keys, DBuf<uint64_t> &vals, size_t n, int begin_bit = 0, int end_bit = 32);
 
 // out[i] = sum_{j<i} in[j]; returns nothing, total = out[n-1] + in[n-1] (use scan_total)
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n);
@@ -32,6 +35,8 @@ void select_classes4_async(const uint8_t *cls, size_t n, uint32_t *out1, uint32_
                            uint32_t *d_counts);
 // indices i where key[i] >> shift starts a new run (keys grouped): the group boundaries of a sorted / grouped array
 size_t select_run_heads_u64(const uint64_t *key, size_t n, int shift, uint32_t *out_idx);
+// same for a key kept in two arrays: a new run starts where skey[i] (key_bytes = 2 or 4 wide) or val[i] >> val_shift changes
+size_t select_run_heads_split(const void *skey, int key_bytes, const uint64_t *val, size_t n, int val_shift, uint32_t *out_idx);
 // number of significant bits of the maximum key value helper
 inline int bits_for(uint64_t max_value) {
     int b = 1;

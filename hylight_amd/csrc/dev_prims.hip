@@ -83,6 +83,23 @@ void sort_pairs_u32_u32(DBuf<uint32_t> &keys, DBuf<uint32_t> &vals, size_t n, in
     if (dv.current() != vals.p) std::swap(vals, v2);
 }
 
+template <typename K>
+static void sort_small_key_pairs(DBuf<K> &keys, DBuf<uint64_t> &vals, size_t n, int b0, int b1) {
+    if (n < 2) return;
+    DBuf<K> k2(keys.n);
+    DBuf<uint64_t> v2(vals.n);
+    rocprim::double_buffer<K> dk(keys.p, k2.p);
+    rocprim::double_buffer<uint64_t> dv(vals.p, v2.p);
+    size_t tmp_bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs<PairsOnesweep>(nullptr, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+    HIP_CHECK(rocprim::radix_sort_pairs<PairsOnesweep>(tmp.p, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    if (dk.current() != keys.p) std::swap(keys, k2);
+    if (dv.current() != vals.p) std::swap(vals, v2);
+}
+void sort_pairs_u16_u64(DBuf<uint16_t> &k, DBuf<uint64_t> &v, size_t n, int b0, int b1) { sort_small_key_pairs(k, v, n, b0, b1); }
+void sort_pairs_u32_u64(DBuf<uint32_t> &k, DBuf<uint64_t> &v, size_t n, int b0, int b1) { sort_small_key_pairs(k, v, n, b0, b1); }
+
 void sort_keys_u64(uint64_t *keys, size_t n, int b0, int b1) {
     if (n < 2) return;
     DBuf<uint64_t> k2(n);
@@ -157,6 +174,14 @@ __global__ __launch_bounds__(WG) void head_count_kernel(const uint64_t *key, siz
     const unsigned long long m = __ballot(f);
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) { cnt[i >> 6] = (uint32_t)__popcll(m); mask[i >> 6] = m; }
 }
+template <typename K>
+__global__ __launch_bounds__(WG) void head_count_split_kernel(const K *skey, const uint64_t *val, size_t n, int shift, uint32_t *cnt,
+                                                               unsigned long long *mask) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const bool f = i < n && (i == 0 || skey[i] != skey[i - 1] || (val[i] >> shift) != (val[i - 1] >> shift));
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) { cnt[i >> 6] = (uint32_t)__popcll(m); mask[i >> 6] = m; }
+}
 // second pass: the ballots of the first (8 B per 64 keys) instead of the keys again
 __global__ __launch_bounds__(WG) void head_scatter_kernel(const unsigned long long *mask, size_t n, const uint32_t *off,
                                                            uint32_t *out_idx, uint32_t *total) {
@@ -176,6 +201,23 @@ size_t select_run_heads_u64(const uint64_t *key, size_t n, int shift, uint32_t *
     DBuf<unsigned long long> mask(nw);
     const dim3 grid(cdiv(n, WG));
     hipLaunchKernelGGL(head_count_kernel, grid, dim3(WG), 0, stream(), key, n, shift, cnt.p, mask.p);
+    exclusive_scan_u32(cnt.p, off.p, nw);
+    hipLaunchKernelGGL(head_scatter_kernel, grid, dim3(WG), 0, stream(), mask.p, n, off.p, out_idx, total.p);
+    HIP_CHECK(hipGetLastError());
+    return (size_t)download_one(total.p);
+}
+
+size_t select_run_heads_split(const void *skey, int key_bytes, const uint64_t *val, size_t n, int val_shift, uint32_t *out_idx) {
+    if (!n) return 0;
+    if (n >= (1ull << 32)) fail(HLMI_EINVAL, "select_run_heads_split: more than 2^32 elements");
+    const size_t nw = (n + 63) / 64;
+    DBuf<uint32_t> cnt(nw), off(nw), total(1);
+    DBuf<unsigned long long> mask(nw);
+    const dim3 grid(cdiv(n, WG));
+    if (key_bytes == 2)
+        hipLaunchKernelGGL(head_count_split_kernel<uint16_t>, grid, dim3(WG), 0, stream(), (const uint16_t *)skey, val, n, val_shift, cnt.p, mask.p);
+    else
+        hipLaunchKernelGGL(head_count_split_kernel<uint32_t>, grid, dim3(WG), 0, stream(), (const uint32_t *)skey, val, n, val_shift, cnt.p, mask.p);
     exclusive_scan_u32(cnt.p, off.p, nw);
     hipLaunchKernelGGL(head_scatter_kernel, grid, dim3(WG), 0, stream(), mask.p, n, off.p, out_idx, total.p);
     HIP_CHECK(hipGetLastError());

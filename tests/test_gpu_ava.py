@@ -72,6 +72,14 @@ def test_ava_key_value_anchor_form(tmp_path, monkeypatch):
     monkeypatch.setenv("HLMI_ANCHOR_PAIRS", "1")
     api.ava(fa, fa, tmp_path / "pairs.paf")
     assert open(tmp_path / "pairs.paf").read() == open(tmp_path / "packed.paf").read()
+    assert api.last_stats()["anchor_bytes"] == 16 * api.last_stats()["anchors"]
+    # in between: everything but the (target, strand) bits in the word, those in a 2- or 4-byte key of their own
+    monkeypatch.delenv("HLMI_ANCHOR_PAIRS")
+    for width in ("2", "4"):
+        monkeypatch.setenv("HLMI_ANCHOR_SPLIT", width)
+        api.ava(fa, fa, tmp_path / "split.paf")
+        assert open(tmp_path / "split.paf").read() == open(tmp_path / "packed.paf").read()
+        assert api.last_stats()["anchor_bytes"] == (8 + int(width)) * api.last_stats()["anchors"]
 
 
 def test_ava_index_search_forms(tmp_path, monkeypatch):
