@@ -332,7 +332,6 @@ struct ChainArgs {
     size_t n_groups, n_anchors;
     uint32_t *fp;                     // MODE 2: score << 5 | distance to the predecessor (0: none) of every anchor, from chain_dp16_kernel
     uint32_t *sbase;                  // per chain start: f(parent of the start) | has a child << 31
-    int *mem;                         // member lists of the chains that score enough (scratch, one slot per anchor)
     int *root;                        // chain id of every anchor (index of the chain's start inside the group)
     unsigned long long *peak;         // per chain, at its root: best f << 32 | ~(first index reaching it)
     int k, max_gap, bw, min_score, min_cnt;
@@ -366,8 +365,8 @@ __device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, in
         t = (int)(key & a.pmask); q = (int)(val >> 32); sp = (int)((val >> 24) & 0xff);
     }
 }
-// Fixed-point selection over the member list mem[0..len) of one chain (oracle/ava_oracle.c:align_chain).
-// 64 members at a time sit in registers; the next fixed point = first later member that is >= BLOCK_MIN away
+// Fixed-point selection over the members of one chain (oracle/ava_oracle.c:align_chain).
+// 64 anchors at a time sit in registers; the next fixed point = first later member that is >= BLOCK_MIN away
 // in both sequences (or the last member) comes from one ballot instead of a scan over ~16 anchors.
 // One pass: the fixed points go into a range reserved for the worst case (a chain of len members has at most
 // 2 * len of them: one per member plus one more per piece), every piece takes its slot when it closes.
@@ -386,19 +385,27 @@ __device__ __forceinline__ void flush_pieces(const ChainArgs &a, int lane, const
     __builtin_amdgcn_wave_barrier();
     n_buf = 0;
 }
-__device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step, int lane, const int *mem, int s, int len,
+// The members of chain s are the anchors s <= i <= peak whose chain id (root) is s.  There is no member list: the
+// windows below are 64 consecutive ANCHORS of the group (coalesced reads of the anchors and their chain ids), lanes
+// that hold another chain's anchor are masked and carry the coordinates of the member before them, which keeps the
+// coordinates monotone along the window for the successor search.  Returns false (nothing written) when the chain has
+// fewer than min_cnt members.
+__device__ bool emit_chain(const ChainArgs &a, size_t b, size_t g_first, long long g_step, int lane, int s, int peak_i,
                            uint32_t q, uint32_t t, uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t fp_base,
                            Piece *buf, int &n_buf) {
     bool open = false;
     int cq = 0, ct = 0;
     uint32_t np = 0, nf = 0, piece_fp0 = 0;
     const bool wr = lane == 0;
+    n_pieces = n_fps = 0;
     auto close_piece = [&]() {
         if (wr) buf[n_buf] = Piece{q, t, strand, (uint32_t)s, np, fp_base + piece_fp0, nf - piece_fp0, 0};
         ++np;
         if (++n_buf == PIECE_BUF) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); flush_pieces(a, lane, buf, n_buf); }
     };
-    int base = -(1 << 30), te_l = 0, qe_l = 0, sp_l = 0;
+    const int end = peak_i + 1;                                // the peak is the chain's last member
+    int base = s, te_l = 0, qe_l = 0, sp_l = 0;
+    unsigned long long memb = 0;                               // member lanes of the window
     // Successor links of the window (long chains): nxt = the member that becomes the next fixed point when this one
     // is the current one (64: none inside the window), okm = lanes whose block to that successor passes block_ok.
     // Member coordinates grow strictly, so "far enough in both sequences, or the last member" is monotone along
@@ -406,25 +413,47 @@ __device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step,
     // then one readlane per fixed point, and the run is stored by all its lanes at once.
     int nxt = 64, links_base = -(1 << 30);
     unsigned long long okm = 0;
-    // windows of 64 members, the next one already in flight while this one is worked on (two dependent reads each)
-    auto load_window = [&](int x0, int &te, int &qe, int &sp) {
-        te = qe = sp = 0;
-        if (x0 + lane < len) {
-            const int idx = mem[x0 + lane];
-            anchor_fields(a, (size_t)((long long)g_first + g_step * idx), te, qe, sp);
+    // raw window: end coordinates + span of the anchors x0 .. x0 + 63, chain id in rt (-1 past the peak)
+    auto load_window = [&](int x0, int &te, int &qe, int &sp, int &rt) {
+        te = qe = sp = 0; rt = -1;
+        if (x0 + lane < end) {
+            rt = a.root[b + (size_t)(x0 + lane)];
+            anchor_fields(a, (size_t)((long long)g_first + g_step * (x0 + lane)), te, qe, sp);
             ++te; ++qe;
         }
     };
-    int te_n = 0, qe_n = 0, sp_n = 0;
-    for (int x = 0; x < len;) {
-        if (x >= base + 64) {                                  // (always the window that follows: x never skips one)
-            if (x == base + 64) { te_l = te_n; qe_l = qe_n; sp_l = sp_n; }
-            else load_window(x, te_l, qe_l, sp_l);             // the first window
-            base = x;
-            if (base + 64 < len) load_window(base + 64, te_n, qe_n, sp_n);
+    // masks the other chains' anchors: they take the coordinates of the last member at or before them
+    auto settle = [&](int te, int qe, int sp, int rt) {
+        memb = __ballot(rt == s);
+        const unsigned long long upto = memb & ((2ull << lane) - 1ull);
+        const int src = upto ? 63 - __clzll((long long)upto) : lane;
+        te_l = __shfl(te, src, 64); qe_l = __shfl(qe, src, 64); sp_l = sp;
+        if (!upto) { te_l = 0; qe_l = 0; }
+    };
+    int te_n = 0, qe_n = 0, sp_n = 0, rt_n = -1;
+    {
+        int te0, qe0, sp0, rt0;
+        load_window(s, te0, qe0, sp0, rt0);
+        if (s + 64 < end) load_window(s + 64, te_n, qe_n, sp_n, rt_n);
+        settle(te0, qe0, sp0, rt0);
+        int cnt = __popcll(memb);
+        if (cnt < a.min_cnt) {                                 // (rare) the first window does not settle it: count on
+            if (s + 64 < end) cnt += __popcll(__ballot(rt_n == s));
+            for (int w0 = s + 128; w0 < end && cnt < a.min_cnt; w0 += 64)
+                cnt += __popcll(__ballot(w0 + lane < end && a.root[b + (size_t)(w0 + lane)] == s));
+            if (cnt < a.min_cnt) return false;
         }
-        if (!open) {                                           // a piece starts at the START of member x
-            const int l = x - base;
+    }
+    for (int x = s; x < end;) {
+        if (x >= base + 64) {                                  // (always the window that follows: x never skips one)
+            base += 64;
+            settle(te_n, qe_n, sp_n, rt_n);
+            if (base + 64 < end) load_window(base + 64, te_n, qe_n, sp_n, rt_n);
+        }
+        if (!open) {                                           // a piece starts at the START of the next member from x on
+            const unsigned long long rem = memb & ~((1ull << (x - base)) - 1ull);
+            if (!rem) { x = base + 64; continue; }
+            const int l = __ffsll((long long)rem) - 1;
             const int te = __builtin_amdgcn_readlane(te_l, l), qe = __builtin_amdgcn_readlane(qe_l, l),
                       sp = __builtin_amdgcn_readlane(sp_l, l);
             int q0 = qe - sp, t0 = te - sp;
@@ -437,20 +466,20 @@ __device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step,
                 nf += 2;
                 cq = qe; ct = te; open = true;
             }
-            ++x;
+            x = base + l + 1;
             continue;
         }
         // open piece: first member j >= x in the window that qualifies as the next fixed point
         const int j_l = base + lane;
-        const bool ok = j_l >= x && j_l < len && qe_l > cq && te_l > ct &&
-                        ((qe_l - cq >= BLOCK_MIN && te_l - ct >= BLOCK_MIN) || j_l == len - 1);
+        const bool ok = ((memb >> lane) & 1ull) && j_l >= x && qe_l > cq && te_l > ct &&
+                        ((qe_l - cq >= BLOCK_MIN && te_l - ct >= BLOCK_MIN) || j_l == peak_i);
         const unsigned long long m = __ballot(ok);
         if (!m) { x = base + 64; continue; }                   // nothing in this window
         const int l = __ffsll((long long)m) - 1;
         const int te = __builtin_amdgcn_readlane(te_l, l), qe = __builtin_amdgcn_readlane(qe_l, l);
         if (block_ok(cq, ct, qe, te)) {
-            const int wend = len - base < 64 ? len - base : 64;
-            if (wend - l < 8) {                                // few members left in the window: one at a time
+            const int wend = end - base < 64 ? end - base : 64;
+            if (wend - l < 8) {                                // few anchors left in the window: one at a time
                 if (wr) a.fps[fp_base + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
                 ++nf;
                 cq = qe; ct = te;
@@ -463,7 +492,7 @@ __device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step,
                 for (int r = 0; r < 6; ++r) {
                     const int mid = (lo + hi) >> 1;
                     const int qm = __shfl(qe_l, mid & 63, 64), tm = __shfl(te_l, mid & 63, 64);
-                    const bool far = (qm - qe_l >= BLOCK_MIN && tm - te_l >= BLOCK_MIN) || base + mid == len - 1;
+                    const bool far = (qm - qe_l >= BLOCK_MIN && tm - te_l >= BLOCK_MIN) || base + mid == peak_i;
                     if (lo < hi) { if (far) hi = mid; else lo = mid + 1; }
                 }
                 nxt = lo < wend ? lo : 64;
@@ -491,6 +520,7 @@ __device__ void emit_chain(const ChainArgs &a, size_t g_first, long long g_step,
     if (open) close_piece();
     n_pieces = np;
     n_fps = nf;
+    return true;
 }
 
 constexpr int PEN_TAB = 2048;         // gap-cost table entries (bandwidth + 2 must fit; else the VALU form runs)
@@ -555,7 +585,7 @@ __device__ __forceinline__ void dp16_prepare(Dp16State &z, const int *pen_tab, u
     di = di < bw4 ? di : bw4;
     const int pen = *(const int *)((const char *)pen_tab + di);
     const uint32_t mn = lo < (uint32_t)z.M_s ? lo : (uint32_t)z.M_s;
-    z.w = (lo >= 4u) & (hi <= lim4) ? (int)(mn << 6) + pen : PK_NEG;
+    z.w = ((lo >= 4u) & (hi <= lim4)) ? (int)(mn << 6) + pen : PK_NEG;
 }
 // steps J .. 15 of a block: finish the sender, push it, prepare the next one
 template <int J>
@@ -931,7 +961,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         resolve((n - 1) & ~63, P1_f, P1_p, P2_f);
         __threadfence_block();
         if (a.prof) { const long long t = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&a.prof[0], (unsigned long long)(t - tp0)); tp0 = t; }
-        int moff = 0;                                      // member lists of the group's chains are disjoint
+        uint32_t fcur = 2u * (uint32_t)b;                  // next free fixed-point slot of the group
         for (int s0 = 0; s0 < n; s0 += 64) {
             int pk_i = 0;
             bool cand = false;
@@ -951,31 +981,12 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                 cm &= cm - 1;
                 const int s = s0 + l;
                 const int peak_i = __builtin_amdgcn_readlane(pk_i, l);
-                // member list up to the peak: one ballot per window between the start and the peak
-                int *mem = a.mem + b + moff;
-                int best_len = 0;
-                for (int w0 = s0; w0 <= peak_i; w0 += 256) {                  // four windows per trip to memory
-                    int rt[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = w0 + 64 * u + lane; rt[u] = i <= peak_i ? a.root[b + i] : -1; }   // peak_i < n
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = w0 + 64 * u + lane;
-                        const bool in = rt[u] == s;
-                        const unsigned long long mm = __ballot(in);
-                        if (in) mem[best_len + __popcll(mm & ((1ull << lane) - 1ull))] = i;
-                        best_len += __popcll(mm);
-                    }
-                }
-                moff += best_len;
-                if (best_len < a.min_cnt) continue;
-                __threadfence_block();
-                // fixed points of this chain: at most 2 per member, and the member lists of a batch are disjoint
-                // ranges of the anchor array - twice the list's own offset is a private range, no counter needed
+                // fixed points of this chain: at most 2 per member, and the chains of a group have disjoint members -
+                // the group's range of the array (twice its anchors) is handed out chain after chain, no counter needed
                 uint32_t np = 0, nf = 0;
-                const uint32_t fb = 2u * (uint32_t)(b + (size_t)(moff - best_len));
                 const long long te = a.prof ? (long long)__builtin_readcyclecounter() : 0;
-                emit_chain(a, g_first, g_step, lane, mem, s, best_len, qg, tg, strand, np, nf, fb, pbuf, n_pbuf);
+                emit_chain(a, b, g_first, g_step, lane, s, peak_i, qg, tg, strand, np, nf, fcur, pbuf, n_pbuf);
+                fcur += nf;
                 if (a.prof) tpc += (long long)__builtin_readcyclecounter() - te;
                 wave_fps += nf;
             }
@@ -1214,10 +1225,10 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         }
     }
     ca.key = akey.p; ca.val = aval.p; ca.skey = skey; ca.sk = sk; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
-    DBuf<int> mem(A), root(A);
+    DBuf<int> root(A);
     DBuf<unsigned long long> peak(A);             // written by the kernel at every chain start before it is voted on
     DBuf<uint32_t> sbase(A);
-    ca.sbase = sbase.p; ca.mem = mem.p; ca.root = root.p; ca.peak = peak.p;
+    ca.sbase = sbase.p; ca.root = root.p; ca.peak = peak.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
