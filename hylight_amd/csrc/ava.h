@@ -32,9 +32,17 @@ struct Mz {                 // one minimizer, 16 B (the unit all-gathered betwee
 };
 
 struct DevReads {           // a read set resident in HBM: 1 B/base codes (0..3 ACGT, 4 other)
+    static constexpr size_t PAD = 64;   // bytes of code 4 in front of the first and behind the last base: 8-byte loads that
+                                        // start a few bases outside the array need no bounds test
     size_t n = 0;
     uint64_t total = 0;
-    DBuf<uint8_t> codes;
+    DBuf<uint8_t> store;    // PAD + total + PAD bytes
+    uint8_t *codes() const { return store.p + PAD; }
+    void alloc_codes() {
+        store.alloc(total + 2 * PAD);
+        HIP_CHECK(hipMemsetAsync(store.p, 4, PAD, stream()));
+        HIP_CHECK(hipMemsetAsync(store.p + PAD + total, 4, PAD, stream()));
+    }
     DBuf<uint64_t> off;     // n+1 base offsets
     std::vector<uint64_t> h_off;
 };

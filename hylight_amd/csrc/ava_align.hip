@@ -55,62 +55,72 @@ __global__ void piece_task_count_kernel(const Piece *pieces, size_t n, uint32_t 
     if (i < n) cnt[i] = pieces[i].n_fp + 1;      // (n_fp - 1) blocks + 2 extensions
 }
 
-// Where the task records come from: geometry of the pieces (fixed points, read lengths and offsets)
+// Where the task records come from.  Per task 8 bytes: its piece, its kind (0 block, 1 left, 2 right extension) and the
+// index of its first fixed point; per piece 32 bytes with everything else the record needs.  The classifier reaches a
+// task's bases in three dependent reads (reference, then piece geometry and fixed points side by side, then the bases)
+// instead of five, and fetches the reference a round ahead.
+struct TaskRef { uint32_t pk, fp; };       // piece | kind << 30; block k: fixed point k - 1, left extension: 0, right: the last
+struct PieceGeom {                         // 32 B
+    uint64_t qo, to;                       // first base of the query / target in the code arrays
+    uint32_t ql, tl;
+    uint32_t strand, pad;
+};
 struct TaskGeom {
-    const Piece *pieces;
+    const TaskRef *ref;
+    const PieceGeom *pg;
     const FixPt *fps;
-    const uint32_t *task_off;      // first task of every piece
-    const uint32_t *qlen, *tlen;
-    const uint64_t *qoff, *toff;
 };
 // Window element x of a task: query = qcodes[qa + x] (complemented and read downwards, qcodes[qa - x], when exactly one
 // of "left extension" and "reverse strand" holds; complemented whenever the strand is reverse); target =
 // tcodes[ta + x], downwards for a left extension.
-__device__ __forceinline__ Task build_task(const TaskGeom &g, uint32_t i, uint32_t k) {
-    const Piece p = g.pieces[i];
-    const FixPt *fp = g.fps + p.fp_off;
-    const int ql = (int)g.qlen[p.q], tl = (int)g.tlen[p.t];
-    const uint64_t qo = g.qoff[p.q], to = g.toff[p.t];
+__device__ __forceinline__ Task build_task(const PieceGeom &p, uint32_t piece, uint32_t kind, FixPt f0, FixPt f1) {
+    const int ql = (int)p.ql, tl = (int)p.tl;
+    const uint64_t qo = p.qo, to = p.to;
     const uint16_t rev = p.strand ? TASK_REV : 0;
     // aligned query position pos -> offset in qcodes
     auto qaddr = [&](int pos) { return p.strand ? qo + (uint64_t)(ql - 1 - pos) : qo + (uint64_t)pos; };
-    if (k == 0) {                       // left extension: elements run downwards from the fixed point
-        const int qs = (int)fp[0].q, ts = (int)fp[0].t;
-        return Task{i, (uint16_t)(1u | rev), (uint16_t)(qs <= EXT_MAX ? (qs + 1) << 1 : 0), qaddr(qs - 1),
+    if (kind == 1) {                    // left extension: elements run downwards from the fixed point
+        const int qs = (int)f0.q, ts = (int)f0.t;
+        return Task{piece, (uint16_t)(1u | rev), (uint16_t)(qs <= EXT_MAX ? (qs + 1) << 1 : 0), qaddr(qs - 1),
                     to + (uint64_t)(ts - 1), (int16_t)(qs < EXT_MAX ? qs : EXT_MAX), (int16_t)(ts < SEQ_T_MAX ? ts : SEQ_T_MAX),
                     (int16_t)(-(BAND_W / 2 - 1)), 0};
     }
-    if (k == p.n_fp) {                  // right extension
-        const int qe = (int)fp[p.n_fp - 1].q, te = (int)fp[p.n_fp - 1].t;
+    if (kind == 2) {                    // right extension
+        const int qe = (int)f0.q, te = (int)f0.t;
         const int m = ql - qe < EXT_MAX ? ql - qe : EXT_MAX, n2 = tl - te < SEQ_T_MAX ? tl - te : SEQ_T_MAX;
-        return Task{i, (uint16_t)(2u | rev), (uint16_t)(ql - qe <= EXT_MAX ? (ql - qe + 1) << 1 : 0), qaddr(qe),
+        return Task{piece, (uint16_t)(2u | rev), (uint16_t)(ql - qe <= EXT_MAX ? (ql - qe + 1) << 1 : 0), qaddr(qe),
                     to + (uint64_t)te, (int16_t)m, (int16_t)n2, (int16_t)(-(BAND_W / 2 - 1)), 0};
     }
-    const uint32_t b = k - 1;           // block between fixed points k-1 and k
-    const int q0 = (int)fp[b].q, t0 = (int)fp[b].t, m = (int)fp[b + 1].q - q0, n2 = (int)fp[b + 1].t - t0;
+    // block between two fixed points
+    const int q0 = (int)f0.q, t0 = (int)f0.t, m = (int)f1.q - q0, n2 = (int)f1.t - t0;
     const int delta = n2 - m;
     // band rule: near-diagonal blocks use the 16-diagonal band
     const bool narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
-    return Task{i, rev, (uint16_t)(narrow ? 1 : 0), qaddr(q0), to + (uint64_t)t0, (int16_t)m, (int16_t)n2,
+    return Task{piece, rev, (uint16_t)(narrow ? 1 : 0), qaddr(q0), to + (uint64_t)t0, (int16_t)m, (int16_t)n2,
                 (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD)), 0};
 }
-// piece of every task (one wave per piece): the classifier builds its task from the piece, only the tasks that need a
-// DP get a 32-byte record
-__global__ __launch_bounds__(WG) void task_piece_kernel(const Piece *pieces, const uint32_t *task_off, size_t n, uint32_t *task_piece) {
+// references of the tasks of every piece and the piece's geometry (one wave per piece)
+__global__ __launch_bounds__(WG) void task_ref_kernel(const Piece *pieces, const uint32_t *task_off, size_t n, const uint32_t *qlen,
+                                                       const uint32_t *tlen, const uint64_t *qoff, const uint64_t *toff,
+                                                       TaskRef *task_ref, PieceGeom *pg) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t i = wave; i < n; i += n_waves) {
-        const uint32_t n_tasks = pieces[i].n_fp + 1;
-        uint32_t *out = task_piece + task_off[i];
-        for (uint32_t k = (uint32_t)lane; k < n_tasks; k += 64) out[k] = (uint32_t)i;
+        const Piece p = pieces[i];
+        const uint32_t n_tasks = p.n_fp + 1;
+        TaskRef *out = task_ref + task_off[i];
+        for (uint32_t k = (uint32_t)lane; k < n_tasks; k += 64) {
+            const uint32_t kind = k == 0 ? 1u : (k == p.n_fp ? 2u : 0u);
+            out[k] = TaskRef{(uint32_t)i | kind << 30, p.fp_off + (k == 0 ? 0u : k - 1)};
+        }
+        if (lane == 0) pg[i] = PieceGeom{qoff[p.q], toff[p.t], qlen[p.q], tlen[p.t], p.strand, 0};
     }
 }
 
 struct AlignArgs {
     Task *tasks;            // records of the tasks that need a DP (written by the classifier, read by the DP kernels)
     TaskGeom geom;
-    const uint32_t *task_piece;
     size_t n_tasks;
     const uint32_t *list;   // task ids this launch works on (n_list of them)
     size_t n_list;
@@ -220,6 +230,19 @@ __device__ __forceinline__ uint64_t load_window8(const uint8_t *codes, long long
     return v;
 }
 
+// the same without the bounds test: the code arrays carry DevReads::PAD bytes of code 4 on both sides, and the
+// classifier's loads stay within a few bases of its blocks
+__device__ __forceinline__ uint64_t load_window8p(const uint8_t *codes, long long a0, bool down, bool comp, int x) {
+    uint64_t v;
+    __builtin_memcpy(&v, codes + (down ? a0 - x - 7 : a0 + x), 8);
+    if (down) v = __builtin_bswap64(v);
+    if (comp) {
+        const uint64_t n = v & 0x0404040404040404ull;
+        v = (v ^ 0x0303030303030303ull) & ~((n >> 1) | (n >> 2));
+    }
+    return v;
+}
+
 // One lane per task: a square block is compared 8 bases at a time and given up at the third mismatch (kmax <= 3
 // would still pass with 3), so the typical task costs 8-9 iterations of two 8-byte loads; a block with m != n gets
 // its common prefix / suffix measured the same way (second certificate below); the runs of the tasks that finish
@@ -229,8 +252,12 @@ __device__ __forceinline__ uint64_t load_window8(const uint8_t *codes, long long
 // block) are only flagged.  PASS 2 runs the second and third certificate over the list of the flagged tasks, every lane
 // busy with the same kind of work (in one pass those few lanes cost a third of the kernel).
 template <int PASS>
-__global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls, unsigned long long *stats) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 4 : 5))) void classify_kernel(AlignArgs a, uint8_t *cls, unsigned long long *stats) {
     __shared__ unsigned long long s_stat[WAVES][N_ALIGN_STATS];
+    constexpr int CMP_PIECES = PASS == 1 ? 64 * (BLOCK_MAX / 8) : 1;     // 8-base pieces of a wave's 64 square blocks
+    __shared__ uint8_t s_mm[WAVES][CMP_PIECES], s_up[WAVES][CMP_PIECES], s_dn[WAVES][CMP_PIECES];
+    __shared__ uint64_t s_qa[WAVES][PASS == 1 ? 64 : 1], s_ta[WAVES][PASS == 1 ? 64 : 1];
+    __shared__ uint32_t s_geo[WAVES][PASS == 1 ? 64 : 1], s_amb[WAVES][2];
     const int lane = threadIdx.x & 63;
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
@@ -238,12 +265,31 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
     uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
     const size_t n_units = PASS == 1 ? a.n_tasks : (size_t)*a.defer_count;
     const size_t rounds = (n_units + n_thr - 1) / n_thr;              // uniform trip count: the allocation is per wave
+    // the reference of a task (PASS 2: its index in the list) is fetched a round ahead
+    TaskRef ref_n{0, 0};
+    uint32_t ti_n = 0;
+    if (PASS == 1) { if (tid < n_units) ref_n = a.geom.ref[tid]; }
+    else if (tid < n_units) ti_n = a.defer_list[tid];
     for (size_t r = 0; r < rounds; ++r) {
         const size_t u = r * n_thr + tid;
         bool live = u < n_units;
-        const size_t ti = PASS == 1 || !live ? u : (size_t)a.defer_list[u];
+        const size_t ti = PASS == 1 || !live ? u : (size_t)ti_n;
+        TaskRef ref = ref_n;
+        if (PASS == 2 && live) ref = a.geom.ref[ti];
+        {
+            const size_t un = u + n_thr;
+            if (PASS == 1) { if (un < n_units) ref_n = a.geom.ref[un]; }
+            else if (un < n_units) ti_n = a.defer_list[un];
+        }
         Task tk{};
-        if (live) { const uint32_t pc = a.task_piece[ti]; tk = build_task(a.geom, pc, (uint32_t)ti - a.geom.task_off[pc]); }
+        if (live) {
+            const uint32_t pc = ref.pk & 0x3fffffffu, kind = ref.pk >> 30;
+            const PieceGeom pg = a.geom.pg[pc];
+            const FixPt f0 = a.geom.fps[ref.fp];
+            FixPt f1{0, 0};
+            if (kind == 0) f1 = a.geom.fps[ref.fp + 1];
+            tk = build_task(pg, pc, kind, f0, f1);
+        }
         const int m = tk.m, n = tk.n;
         uint8_t c = 2;
         bool try_fast = false;
@@ -258,49 +304,131 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
             if (defer) { live = false; try_fast = false; }
         }
         int k = 0, mpos[3] = {0, 0, 0};
-        bool ambig = false;
-        if (try_fast) {
-            const bool rev = (tk.kind & TASK_REV) != 0;
-            for (int x = 0; x < m && k <= a.kmax + a.kshift && !ambig; x += 8) {
-                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
-                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
-                const int left = m - x;                        // bases of this step inside the block (>= 1)
-                const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
-                uint64_t d = (q8 ^ t8) & keep;
-                ambig = ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
-                d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;      // codes are 0..4: three bits
-                while (d) {
-                    const int y = (__ffsll((long long)d) - 1) >> 3;
-                    d &= d - 1;
-                    if (k < 3) mpos[k] = x + y;
-                    ++k;
+        bool ambig = false, shift_ok = false;
+        if constexpr (PASS == 1) {
+            // The square blocks of the wave's 64 tasks are compared 8 bases per lane and step with the LANES SPREAD OVER
+            // THE 8-BASE PIECES of all of them (a lane per task would run every lane as long as the longest block of
+            // the wave, and its loads would touch 64 different lines): piece c of the wave belongs to the task whose first
+            // piece is the last one marked at or before c (a running prefix maximum over the marks), neighbouring lanes read
+            // neighbouring bytes, and each piece leaves one byte of mismatch bits in LDS for its task to read back.
+            const int wv = threadIdx.x >> 6;
+            // (the owner marks and the mismatch bytes share an array: a piece's mark is read before its byte is written)
+            uint8_t *own = s_mm[wv], *mm = s_mm[wv], *mup = s_up[wv], *mdn = s_dn[wv];
+            const uint32_t nch = try_fast ? (uint32_t)(m + 7) >> 3 : 0u;
+            const uint32_t incl = wave_prefix_sum_incl_dpp(nch), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t st0 = incl - nch;
+            for (uint32_t c = (uint32_t)lane; c < tot; c += 64) own[c] = 0;
+            if (lane < 2) s_amb[wv][lane] = 0;
+            s_qa[wv][lane] = tk.qa; s_ta[wv][lane] = tk.ta;
+            s_geo[wv][lane] = st0 | (uint32_t)m << 16 | ((tk.kind & TASK_REV) ? 0x80000000u : 0u);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (nch) own[st0] = (uint8_t)lane;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            int carry = 0;
+            constexpr int CU = 4;                                   // pieces per lane and trip: their loads are issued together
+            for (uint32_t c0 = 0; c0 < tot; c0 += 64 * CU) {
+                int ow[CU], xs[CU], left[CU];
+                bool rv[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const uint32_t c = c0 + 64u * u + (uint32_t)lane;
+                    int o = c < tot ? (int)own[c] : 0;
+                    o = wave_prefix_max_incl_dpp(o);
+                    o = o > carry ? o : carry;
+                    carry = __builtin_amdgcn_readlane(o, 63);
+                    const uint32_t geo = s_geo[wv][o];
+                    ow[u] = o;
+                    xs[u] = (int)(c - (geo & 0xffffu)) * 8;
+                    left[u] = c < tot ? (int)(geo >> 16 & 0x7fffu) - xs[u] : 0;      // bases of the piece inside its block (>= 1)
+                    rv[u] = (geo >> 31) != 0;
+                }
+                uint64_t q8[CU], t8[CU];
+                uint32_t q_end = 0, t_end = 0;         // lane 63: the base behind the trip's last piece (fourth certificate)
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    q8[u] = t8[u] = 0;
+                    if (left[u] > 0) {
+                        q8[u] = load_window8p(a.qcodes, (long long)s_qa[wv][ow[u]], rv[u], rv[u], xs[u]);
+                        t8[u] = load_window8p(a.tcodes, (long long)s_ta[wv][ow[u]], false, false, xs[u]);
+                        if (u == CU - 1 && lane == 63 && a.kshift) {
+                            q_end = (uint32_t)load_window8p(a.qcodes, (long long)s_qa[wv][ow[u]], rv[u], rv[u], xs[u] + 8) & 0xffu;
+                            t_end = (uint32_t)load_window8p(a.tcodes, (long long)s_ta[wv][ow[u]], false, false, xs[u] + 8) & 0xffu;
+                        }
+                    }
+                }
+                int nq[CU], nt[CU];
+                if (a.kshift) {
+#pragma unroll
+                    for (int u = 0; u < CU; ++u) {
+                        const int q_after = u + 1 < CU ? __builtin_amdgcn_readlane((int)((uint32_t)q8[u + 1 < CU ? u + 1 : u] & 0xffu), 0) : (int)q_end;
+                        const int t_after = u + 1 < CU ? __builtin_amdgcn_readlane((int)((uint32_t)t8[u + 1 < CU ? u + 1 : u] & 0xffu), 0) : (int)t_end;
+                        nq[u] = wave_shl1((int)((uint32_t)q8[u] & 0xffu), q_after);
+                        nt[u] = wave_shl1((int)((uint32_t)t8[u] & 0xffu), t_after);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    if (left[u] <= 0) continue;
+                    const uint64_t keep = left[u] >= 8 ? ~0ull : (1ull << (8 * left[u])) - 1ull;
+                    uint64_t d = (q8[u] ^ t8[u]) & keep;
+                    if ((q8[u] | t8[u]) & keep & 0x0404040404040404ull) atomicOr(&s_amb[wv][ow[u] >> 5], 1u << (ow[u] & 31));
+                    d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;      // codes are 0..4: three bits
+                    // byte y set -> bit y: the four flags of a half gather in its top byte
+                    auto squeeze = [](uint64_t f) {
+                        return (uint8_t)((((uint32_t)f * 0x10204080u) >> 28) | (((uint32_t)(f >> 32) * 0x10204080u) >> 28) << 4);
+                    };
+                    mm[c0 + 64u * u + (uint32_t)lane] = squeeze(d);
+                    if (a.kshift) {       // fourth certificate: bit i = q[i + 1] != t[i] / q[i] != t[i + 1]
+                        // the windows one base further: the base behind a piece is the first of the next piece (the next lane;
+                        // where that is another block's, the position lies outside [p1, pk) and is never looked at)
+                        const uint64_t q9 = q8[u] >> 8 | (uint64_t)(uint32_t)nq[u] << 56, t9 = t8[u] >> 8 | (uint64_t)(uint32_t)nt[u] << 56;
+                        uint64_t du = q9 ^ t8[u], dd = q8[u] ^ t9;
+                        du = (du | du >> 1 | du >> 2) & 0x0101010101010101ull;
+                        dd = (dd | dd >> 1 | dd >> 2) & 0x0101010101010101ull;
+                        mup[c0 + 64u * u + (uint32_t)lane] = squeeze(du);
+                        mdn[c0 + 64u * u + (uint32_t)lane] = squeeze(dd);
+                    }
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (try_fast) {
+                ambig = (s_amb[wv][lane >> 5] >> (lane & 31)) & 1u;
+                for (uint32_t j = 0; j < nch && k <= a.kmax + a.kshift; ++j) {
+                    uint32_t bits = mm[st0 + j];
+                    while (bits) {
+                        const int y = __ffs((int)bits) - 1;
+                        bits &= bits - 1;
+                        if (k < 3) mpos[k] = (int)(8 * j) + y;
+                        ++k;
+                    }
+                }
+            }
+            // Fourth certificate, square blocks with exactly kmax + 1 substitutions at p1 < .. < pk.  A gapped path scores at
+            // most match (m - 1 - x) - mismatch x - 2 (open + ext) with x mismatching diagonal moves, and by the choice of
+            // kmax it beats the diagonal only with x = 0, one inserted and one deleted base (the host checks that longer or
+            // further gaps cannot make up their cost): it follows the main diagonal without a mismatch up to p1 at the
+            // latest, runs one diagonal higher or lower past pk with every pair matching, and comes back.  The least
+            // constrained such path leaves at p1 and returns after pk: if neither (q[i + 1], t[i]) nor (q[i], t[i + 1])
+            // match for all i in [p1, pk), no gapped path ties or beats the diagonal - it is the unique optimum.
+            if (try_fast && !ambig && a.kshift && k == a.kmax + 1) {
+                const int p1 = mpos[0], pk = mpos[k - 1];
+                uint32_t any_up = 0, any_dn = 0;                     // a mismatch of the shifted segment inside [p1, pk)
+                for (int j = p1 >> 3; j <= (pk - 1) >> 3; ++j) {
+                    uint32_t keepb = 0xffu;
+                    if (j == p1 >> 3) keepb &= 0xffu << (p1 & 7);
+                    if (j == (pk - 1) >> 3) keepb &= 0xffu >> (7 - ((pk - 1) & 7));
+                    any_up |= mup[st0 + (uint32_t)j] & keepb;
+                    any_dn |= mdn[st0 + (uint32_t)j] & keepb;
+                }
+                shift_ok = any_up != 0 && any_dn != 0;
+            }
+            __builtin_amdgcn_wave_barrier();                   // the next round reuses the arrays
         }
         bool fast = try_fast && !ambig && k <= a.kmax;
-        // Fourth certificate, square blocks with exactly kmax + 1 substitutions at p1 < .. < pk.  A gapped path scores at
-        // most match (m - 1 - x) - mismatch x - 2 (open + ext) with x mismatching diagonal moves, and by the choice of
-        // kmax it beats the diagonal only with x = 0, one inserted and one deleted base (the host checks that longer or
-        // further gaps cannot make up their cost): it follows the main diagonal without a mismatch up to p1 at the
-        // latest, runs one diagonal higher or lower past pk with every pair matching, and comes back.  The least
-        // constrained such path leaves at p1 and returns after pk: if neither (q[i + 1], t[i]) nor (q[i], t[i + 1])
-        // match for all i in [p1, pk), no gapped path ties or beats the diagonal - it is the unique optimum.
-        if (try_fast && !ambig && a.kshift && k == a.kmax + 1) {
-            const bool rev = (tk.kind & TASK_REV) != 0;
-            const int p1 = mpos[0], len = mpos[k - 1] - mpos[0];
-            bool up = true, down = true;                              // the two shifted segments match so far
-            for (int x = 0; x < len && (up || down); x += 8) {
-                const uint64_t q0 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, p1 + x);
-                const uint64_t q1 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, p1 + x + 1);
-                const uint64_t t0 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, p1 + x);
-                const uint64_t t1 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, p1 + x + 1);
-                const int left = len - x;
-                const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
-                up = up && ((q1 ^ t0) & keep) == 0;
-                down = down && ((q0 ^ t1) & keep) == 0;
-            }
-            fast = !up && !down;
-        }
+        if (shift_ok) fast = true;
         uint32_t runs[7];
         uint32_t nr = 0;
         int fast_score = a.match * (m - k) - a.mismatch * k;
@@ -320,8 +448,8 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
             const int end_row = (int)(tk.narrow >> 1) - 1;
             bool same = a.end_bonus == 0 || end_row < 0 || L == end_row;
             for (int x = 0; x < L && same; x += 8) {
-                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, left != rev, rev, x);
-                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, left, false, x);
+                const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, left != rev, rev, x);
+                const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, left, false, x);
                 const int rest = L - x;
                 const uint64_t keep = rest >= 8 ? ~0ull : (1ull << (8 * rest)) - 1ull;
                 same = ((q8 ^ t8) & keep) == 0 && ((q8 | t8) & keep & 0x0404040404040404ull) == 0;
@@ -355,8 +483,8 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
             int found_a = 0, found_b = 0, a1 = mn, a2 = mn, b1 = -1, b2 = -1;
             bool amb = false;
             for (int x = 0; x < mn && found_a < want; x += 8) {
-                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
-                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
+                const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, rev, rev, x);
+                const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, false, false, x);
                 const int left = mn - x;
                 const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
                 amb |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
@@ -371,8 +499,8 @@ __global__ __launch_bounds__(WG) void classify_kernel(AlignArgs a, uint8_t *cls,
             const int sq = m > n ? m - n : 0, st_ = n > m ? n - m : 0;   // shift of the end diagonal in q / t
             for (int y = 0; y < mn && found_b < want; y += 8) {           // end diagonal, elements mn-8-y .. mn-1-y
                 const int e0 = mn - 8 - y;
-                const uint64_t q8 = load_window8(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, e0 + sq);
-                const uint64_t t8 = load_window8(a.tcodes, a.t_total, (long long)tk.ta, false, false, e0 + st_);
+                const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, rev, rev, e0 + sq);
+                const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, false, false, e0 + st_);
                 const int left = mn - y;
                 const uint64_t keep = left >= 8 ? ~0ull : ~0ull << (8 * (8 - left));
                 amb |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
@@ -1328,9 +1456,11 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     exclusive_scan_u32(tcnt.p, toff.p, P);
     const size_t NT = ch.n_fp + P;              // a piece of n fixed points has n - 1 blocks and two extensions
     DBuf<Task> tasks(NT);
-    DBuf<uint32_t> task_piece(NT);
-    hipLaunchKernelGGL(task_piece_kernel, dim3((unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
-                       ch.pieces.p, toff.p, P, task_piece.p);
+    if (P >= (1u << 30)) fail(HLMI_EINVAL, "more than 2^30 alignment pieces in one batch");
+    DBuf<TaskRef> task_ref(NT);
+    DBuf<PieceGeom> pgeom(P);
+    hipLaunchKernelGGL(task_ref_kernel, dim3((unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
+                       ch.pieces.p, toff.p, P, d_qlen, d_tlen, in.Q->off.p, in.T->off.p, task_ref.p, pgeom.p);
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
     DBuf<uint32_t> counters(2);
@@ -1349,9 +1479,8 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         counters.zero();
         AlignArgs aa{};
         aa.tasks = tasks.p; aa.n_tasks = NT;
-        aa.task_piece = task_piece.p;
-        aa.geom = TaskGeom{ch.pieces.p, ch.fps.p, toff.p, d_qlen, d_tlen, in.Q->off.p, in.T->off.p};
-        aa.qcodes = in.Q->codes.p; aa.tcodes = in.T->codes.p;
+        aa.geom = TaskGeom{task_ref.p, pgeom.p, ch.fps.p};
+        aa.qcodes = in.Q->codes(); aa.tcodes = in.T->codes();
         aa.q_total = (long long)in.Q->total; aa.t_total = (long long)in.T->total;
         aa.end_bonus = o.end_bonus;
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;

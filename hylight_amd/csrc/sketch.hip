@@ -196,10 +196,10 @@ static void finish_upload(const std::string &bases, const std::vector<uint64_t> 
     out.h_off = off;
     if (out.total >= (1ull << 32)) fail(HLMI_EINVAL, "read set of %llu bases exceeds the 4 Gbase batch limit",
                                         (unsigned long long)out.total);
-    out.codes.alloc(out.total ? out.total : 1);
+    out.alloc_codes();
     if (out.total) {
-        HIP_CHECK(hipMemcpyAsync(out.codes.p, bases.data(), out.total, hipMemcpyHostToDevice, stream()));
-        hipLaunchKernelGGL(encode_kernel, grid1(out.total), dim3(WG), 0, stream(), out.codes.p, out.total);
+        HIP_CHECK(hipMemcpyAsync(out.codes(), bases.data(), out.total, hipMemcpyHostToDevice, stream()));
+        hipLaunchKernelGGL(encode_kernel, grid1(out.total), dim3(WG), 0, stream(), out.codes(), out.total);
     }
     out.off.upload(off);
     sync();
@@ -235,13 +235,13 @@ void subset_reads_device(const DevReads &all, const std::vector<uint32_t> &ids, 
     out.n = ids.size();
     out.total = off.back();
     out.h_off = off;
-    out.codes.alloc(out.total ? out.total : 1);
+    out.alloc_codes();
     out.off.upload(off);
     if (!ids.empty()) {
         DBuf<uint32_t> d_ids;
         d_ids.upload(ids);
-        hipLaunchKernelGGL(copy_reads_kernel, dim3((unsigned)ids.size()), dim3(WG), 0, stream(), all.codes.p, all.off.p,
-                           d_ids.p, out.off.p, out.codes.p);
+        hipLaunchKernelGGL(copy_reads_kernel, dim3((unsigned)ids.size()), dim3(WG), 0, stream(), all.codes(), all.off.p,
+                           d_ids.p, out.off.p, out.codes());
         HIP_CHECK(hipGetLastError());
         sync();
     }
@@ -261,7 +261,7 @@ static int64_t sketch_core(const DevReads &r, int k, int w, int hpc, uint32_t ri
     DBuf<uint8_t> flag(n);
     flag.zero();
     hipLaunchKernelGGL(mark_read_last_kernel, grid1(r.n), dim3(WG), 0, stream(), r.off.p, r.n, flag.p);
-    hipLaunchKernelGGL(slot_flag_kernel, grid1(n), dim3(WG), 0, stream(), r.codes.p, n, hpc, flag.p);
+    hipLaunchKernelGGL(slot_flag_kernel, grid1(n), dim3(WG), 0, stream(), r.codes(), n, hpc, flag.p);
     DBuf<uint32_t> slot_pos(n);
     const size_t ns = select_flagged_indices(flag.p, slot_pos.p, n);
     flag.release();
@@ -272,7 +272,7 @@ static int64_t sketch_core(const DevReads &r, int k, int w, int hpc, uint32_t ri
     DBuf<uint64_t> sx(ns);
     DBuf<uint32_t> spz(ns);
     DBuf<uint8_t> sl(ns), pick(ns);
-    hipLaunchKernelGGL(kmer_kernel, grid1(ns), dim3(WG), 0, stream(), r.codes.p, r.off.p, slot_pos.p, slot_rid.p,
+    hipLaunchKernelGGL(kmer_kernel, grid1(ns), dim3(WG), 0, stream(), r.codes(), r.off.p, slot_pos.p, slot_rid.p,
                        rslot0.p, ns, k, w, hpc, sx.p, spz.p, sl.p);
     hipLaunchKernelGGL(pick_kernel, grid1(ns), dim3(WG), 0, stream(), sx.p, sl.p, slot_rid.p, rslot0.p, ns, k, w, pick.p);
     HIP_CHECK(hipGetLastError());
