@@ -40,7 +40,8 @@ struct Task {               // 32 B, self-contained: the kernels reach the bases
     uint64_t qa, ta;        // offsets in qcodes / tcodes of window element 0 (see load_window4 for the directions)
     int16_t m, n;           // rows (query), cols (target)
     int16_t dlo;            // first diagonal of the band
-    int16_t pad;
+    int16_t trim;           // near-diagonal blocks: exactly matching bases cut off the end of both sequences (m, n are without
+                            // them); the traceback starts with a run of that many '='
 };
 constexpr uint16_t TASK_REV = 4;
 struct TaskOut {            // 24 B
@@ -131,6 +132,7 @@ struct AlignArgs {
     int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     int kgap1;              // 1: blocks with |n - m| = 1 and one substitution finish in the classifier (fifth certificate)
+    int trim_ok;            // 1: near-diagonal DP tasks lose their exactly matching suffix (HLMI_NO_SUFFIX_TRIM: test hook)
     int kshift;             // 1: a square block with kmax + 1 substitutions also finishes here when the one-base shift
                             // that could avoid them all does not match (fourth certificate, see classify_kernel)
     TaskOut *out;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             a.defer_flag[ti] = defer ? 1 : 0;
             if (defer) { live = false; try_fast = false; }
         }
-        int k = 0, mpos[3] = {0, 0, 0};
+        int k = 0, mpos[3] = {0, 0, 0}, last_x = -1;
         bool ambig = false, shift_ok = false;
         if constexpr (PASS == 1) {
             // The square blocks of the wave's 64 tasks are compared 8 bases per lane and step with the LANES SPREAD OVER
@@ -425,6 +427,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 }
                 shift_ok = any_up != 0 && any_dn != 0;
             }
+            if (try_fast && k > 0 && !ambig) {                  // last substitution of the diagonal (suffix trim below)
+                for (int j = (int)nch - 1; j >= 0; --j) {
+                    const uint32_t bits = mm[st0 + (uint32_t)j];
+                    if (bits) { last_x = 8 * j + 31 - __clz((int)bits); break; }
+                }
+            }
             __builtin_amdgcn_wave_barrier();                   // the next round reuses the arrays
         }
         bool fast = try_fast && !ambig && k <= a.kmax;
@@ -519,6 +527,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 else if (want == 2 && b2 < a1) { p_star = b2 + 1; xpos = b1; }            // s* = 1, substitution in the suffix
                 else if (want == 2 && b1 < a2) { p_star = b1 + 1; xpos = a1; in_prefix = true; }   // ... in the prefix
             }
+            if (p_star < 0 && !amb && b1 >= 0) last_x = b1;     // (suffix trim below; positions count along the shorter sequence)
             if (p_star >= 0) {
                 auto seg = [&](int from, int to) {            // [from, to) of one diagonal, with the substitution if it lies inside
                     if (xpos >= from && xpos < to) {
@@ -567,6 +576,26 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         } else if (live && c == 0) {
             a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
         }
+        // Suffix trim of the near-diagonal DP tasks.  Behind the last substitution of the end diagonal the two sequences
+        // agree base for base (no ambiguous code): T bases.  In the (banded) recurrence a matching pair makes the diagonal
+        // move at least as good as any gap into the same cell - H(i-1,j-1) + match >= H(i,j-k) - open - k ext for every k
+        // (take the path into (i,j-k): if it ends with a diagonal move, the same gap one row higher plus this match scores
+        // at least as much; if it ends in a gap, joining or shortening the gaps does) and likewise for the other gap
+        // direction, all within the same diagonals - and the traceback prefers the diagonal on ties: from (m, n) it walks
+        // the T cells of the suffix diagonally whatever lies before.  The cells of the first m - T rows do not depend on
+        // the suffix, so the DP of the block without it followed by T matches is the DP of the block, bit for bit
+        // (needs match > 0 and gap costs >= 0, as the certificates; one row is always left).
+        int m_dp = m;
+        if (live && !fast && (c == 1 || c == 3) && a.kmax >= 0 && last_x >= 0 && a.trim_ok) {
+            const int mn = m < n ? m : n;
+            int T = mn - 1 - last_x;
+            T = T < mn - 1 ? T : mn - 1;
+            if (T > 0) {
+                tk.m = (int16_t)(m - T); tk.n = (int16_t)(n - T); tk.trim = (int16_t)T;
+                m_dp = m - T;
+                c = m_dp <= NR_SHORT ? 1 : 3;
+            }
+        }
         if (live) {
             cls[ti] = c;
             if (c != 0) a.tasks[ti] = tk;                      // a DP kernel will want the record
@@ -578,7 +607,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 else {
                     ++st[ST_DP];
                     if (c == 2 || c == 4) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
-                    else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m; if (c == 1 && m < NR_SMALL) ++st[ST_NARROW_SMALL]; }
+                    else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m_dp; if (c == 1 && m_dp < NR_SMALL) ++st[ST_NARROW_SMALL]; }
                 }
             }
         }
@@ -646,6 +675,7 @@ struct NarrowWalk {
     int m, n, dlo;                          // the walk starts at cell (m, n)
     int wmask;                              // band width - 1
     bool keep_order;                        // left extensions: the reversed sequences make end -> start the forward order
+    int trim;                               // bases matched behind (m, n): the path ends with that many '='
     __device__ __forceinline__ uint32_t word(int plane, int c, int lane) const { return pl[(plane * chunks + c) * 64 + lane]; }
 };
 struct WalkScore {                          // score of the walked path from its runs (no ambiguous base on it)
@@ -660,7 +690,7 @@ struct WalkScore {                          // score of the walked path from its
 __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total, uint32_t *buf = nullptr, uint32_t cap = 0,
                                 WalkScore *ws = nullptr) {
     int i = w.m, j = w.n, state = 0;
-    uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
+    uint32_t cur_op = OP_EQ, cur_len = (uint32_t)w.trim, n_runs = 0;
     auto put = [&]() {
         if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op;
         else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
@@ -826,14 +856,14 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         int Hend = 0;
         if (__any(ambig)) narrow_rows<true, NR_CHUNKS>(a, rows, m, dlo, l, sq, st, pl, lane, Hend);
         else narrow_rows<false, NR_CHUNKS>(a, rows, m, dlo, l, sq, st, pl, lane, Hend);
-        const int score = __shfl(Hend, g * 16 + ((n - m - dlo) & (NARROW_W - 1)), 64) - DP_BIAS;
+        const int score = __shfl(Hend, g * 16 + ((n - m - dlo) & (NARROW_W - 1)), 64) - DP_BIAS + a.match * tk.trim;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         uint32_t *rbuf = s_runs[wv * 4 + g];
         const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_NARROW ? a.run_buf_cap : (uint32_t)RUN_BUF_NARROW;
         uint32_t cp_n = 0, cp_off = 0;                          // runs the group copies out of LDS
         if (live && l == 0) {
-            const NarrowWalk w{&pl[0][0][0], NR_CHUNKS, g * 16, m, n, dlo, NARROW_W - 1, false};
+            const NarrowWalk w{&pl[0][0][0], NR_CHUNKS, g * 16, m, n, dlo, NARROW_W - 1, false, tk.trim};
             const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap);
             uint32_t off = 0;
             bool ok = true;
@@ -1029,12 +1059,12 @@ __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArg
         // lanes 0 and 1 of every group walk the two tasks of the group
         const int hf = l & 1;
         const bool walker = l < 2 && (hf ? liveB : liveA);
-        const int wm = hf ? tB.m : tA.m, wn = hf ? tB.n : tA.n, wd = hf ? tB.dlo : tA.dlo;
+        const int wm = hf ? tB.m : tA.m, wn = hf ? tB.n : tA.n, wd = hf ? tB.dlo : tA.dlo, wtrim = hf ? tB.trim : tA.trim;
         uint32_t *rbuf = s_runs[g * 2 + hf];
         const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF ? a.run_buf_cap : (uint32_t)RUN_BUF;
         uint32_t cp_n = 0, cp_off = 0;
         if (walker) {
-            const NarrowWalk w{&s_pl[wv][0][0][0][0] + hf * (N_PLANES * NR_CHUNKS * 64), NR_CHUNKS, g * 16, wm, wn, wd, NARROW_W - 1, false};
+            const NarrowWalk w{&s_pl[wv][0][0][0][0] + hf * (N_PLANES * NR_CHUNKS * 64), NR_CHUNKS, g * 16, wm, wn, wd, NARROW_W - 1, false, wtrim};
             WalkScore ws{a.match, a.mismatch, a.go, a.ge, 0};
             const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap, &ws);
             uint32_t off = 0;
@@ -1044,7 +1074,7 @@ __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArg
                 if (n_runs <= rcap) { cp_n = n_runs; cp_off = off; }
                 else narrow_walk(w, a.runs + off, n_runs);
             }
-            const int score = amb ? (hf ? endB : endA) : ws.total;
+            const int score = amb ? (hf ? endB : endA) + a.match * wtrim : ws.total;
             a.out[hf ? tiB : tiA] = TaskOut{score, wm, wn, off, ok ? n_runs : 0, 2u | (uint32_t)wm << 2};
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -1501,6 +1531,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             aa.kshift = aa.kmax >= 0 && k <= 3 && k * U > T && k * U < T + o.match + std::min(2 * o.gap_ext, o.gap_open + o.gap_ext) &&
                         !getenv("HLMI_NO_SHIFT_CERT") ? 1 : 0;
         }
+        aa.trim_ok = getenv("HLMI_NO_SUFFIX_TRIM") ? 0 : 1;
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         aa.run_buf_cap = 0xffffffffu;
         if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
@@ -1536,28 +1567,28 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         const int worst = std::max(std::max(o.match, o.mismatch), std::max(o.ambi, o.gap_open + o.gap_ext));
         const bool packed = worst > 0 && (long long)worst * (BLOCK_MAX + NARROW_W + 2) <= 4000 && o.match >= 0 && o.mismatch >= 0 &&
                             o.ambi >= 0 && o.gap_open >= 0 && o.gap_ext >= 0 && !getenv("HLMI_NARROW_UNPACKED");
-        if (n1) {
+        if (n1 && packed) {
+            // the list is in ascending row order: its head (fewer than NR_SMALL rows, counted by the classifier)
+            // runs in the instance with half the plane LDS and twice the resident waves
+            size_t n_small = 0;
+            if (n1 >= 8) n_small = std::min<size_t>(n1, (size_t)astats.download(N_ALIGN_STATS)[ST_NARROW_SMALL]);
+            if (n_small) {
+                KTimer kt("align_narrow_small");
+                aa.list = list1.p; aa.n_list = n_small;
+                const unsigned nb = (unsigned)std::min<size_t>(((n_small + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
+                hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SMALL>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
+            }
+            if (n1 > n_small) {
+                KTimer kt("align_narrow");
+                aa.list = list1.p + n_small; aa.n_list = n1 - n_small;
+                const unsigned nb = (unsigned)std::min<size_t>(((aa.n_list + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
+                hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
+            }
+        } else if (n1) {
             KTimer kt("align_narrow");
             aa.list = list1.p; aa.n_list = n1;
-            if (packed) {
-                // the list is in ascending row order: its head (fewer than NR_SMALL rows, counted by the classifier)
-                // runs in the instance with half the plane LDS and twice the resident waves
-                size_t n_small = 0;
-                if (n1 >= 8) n_small = std::min<size_t>(n1, (size_t)astats.download(N_ALIGN_STATS)[ST_NARROW_SMALL]);
-                if (n_small) {
-                    aa.n_list = n_small;
-                    const unsigned nb = (unsigned)std::min<size_t>(((n_small + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
-                    hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SMALL>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
-                }
-                if (n1 > n_small) {
-                    aa.list = list1.p + n_small; aa.n_list = n1 - n_small;
-                    const unsigned nb = (unsigned)std::min<size_t>(((aa.n_list + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
-                    hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
-                }
-            } else {
-                const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
-                hipLaunchKernelGGL(align_narrow_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
-            }
+            const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
+            hipLaunchKernelGGL(align_narrow_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
         if (n3) {
             KTimer kt("align_narrow_long");
