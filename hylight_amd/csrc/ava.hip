@@ -13,7 +13,9 @@ namespace hlmi {
 namespace {
 constexpr int WG = 256;
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
-constexpr size_t ANCHOR_BATCH = 128u << 20;  // anchors per query batch (8 or 16 B each, x2 for the sort; 48 M measured 6 % slower on C2)
+constexpr size_t ANCHOR_BATCH = 384u << 20;  // anchors per query batch: ~80 B of buffers each (anchor x2 for the sort, chain scratch, fixed
+                                             // points, pieces) = 30 GB of the 288; on C3 128 M costs 8 % more per step (per-batch fixed
+                                             // costs: scans, fills, list selections), 512 M outgrows the buffer pool's cap
 constexpr size_t QUERY_BATCH = 1u << 16;     // queries per batch (ava_chain.hip: QL_BITS)
 
 __global__ void lens_kernel(const uint64_t *off, size_t n, uint32_t *len) {
@@ -174,8 +176,8 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         const size_t k98 = (nQ - 1) * 98 / 100;
         std::nth_element(ql.begin(), ql.begin() + (std::ptrdiff_t)k98, ql.end());
         const int spare = 64 - (bits_for(nT > 1 ? nT - 1 : 1) + 1 + bits_for(max_tlen) + bits_for(std::max<uint64_t>(ql[k98], 1)) + 8);
-        // (never below 2048: a batch of many short reads rather takes the key + value form than ends early)
-        size_t q_floor = 2048;
+        // (never below 8192: a batch of many short reads rather takes the wider anchor form than ends early)
+        size_t q_floor = 8192;
         if (const char *e = getenv("HLMI_QCAP_MIN")) q_floor = (size_t)std::max(1, atoi(e));      // tuning hook
         q_cap = std::min<size_t>(q_cap, std::max<size_t>(q_floor, (size_t)1 << std::max(0, std::min(spare, 16))));
     }
@@ -193,18 +195,20 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         stat_add("pieces", (double)ch.n_pieces);
         stat_add("fixed_points", (double)ch.n_fp);
         if (ch.n_pieces) {
-            AlignOut ao;
             HostTimer ht("align_pieces");
-            align_pieces(in, o, qlen.p, tlen.p, ch, ao);
-            if (in.max_out_bytes && in.n_chunks > 1 && parts.empty() && acc) {     // first batch with output: project the run
-                const double projected = (double)ava_out_bytes(ao.n_rows, ao.n_ops) / (double)acc * (double)total_anchors;
+            const bool first = parts.empty();
+            const size_t before = parts.size();
+            align_pieces(in, o, qlen.p, tlen.p, ch, parts);
+            if (in.max_out_bytes && in.n_chunks > 1 && first && acc && parts.size() > before) {     // first batch with output: project the run
+                size_t rows = 0, ops = 0;
+                for (size_t i = before; i < parts.size(); ++i) { rows += parts[i].n_rows; ops += parts[i].n_ops; }
+                const double projected = (double)ava_out_bytes(rows, ops) / (double)acc * (double)total_anchors;
                 if (projected > (double)in.max_out_bytes) {
                     out.refused_anchors = total_anchors;
                     out.refused_shrink = 0.8 * (double)in.max_out_bytes / projected;
                     return;
                 }
             }
-            if (ao.n_rows) parts.push_back(std::move(ao));
         }
         q = hi;
     }

@@ -1476,8 +1476,10 @@ __global__ void compact_rows_kernel(const uint32_t *idx, size_t n, const PafRec 
 }
 }  // namespace
 
-void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
-                  const ChainOut &ch, AlignOut &out) {
+// pieces [0, P) of `pieces` with n_fp fixed points between them
+struct PieceSpan { struct { const Piece *p; } pieces; size_t n_pieces, n_fp; struct { const FixPt *p; } fps; };
+static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
+                       const PieceSpan &ch, AlignOut &out) {
     out = AlignOut();
     const size_t P = ch.n_pieces;
     if (!P) return;
@@ -1500,10 +1502,12 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     constexpr size_t MAX_BLOCKS = 256 * 16;
     // (a pool that overflows costs a second run of every DP kernel: 12 runs per task cover read sets with a few per cent
     // of errors, where the average is 8)
-    size_t cap_runs = std::max<size_t>(NT * 12, 1 << 16) + MAX_BLOCKS * (4 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL) +
-                      (size_t)2 * 256 * 32 * 8 * PK_WAVES * RUN_CHUNK_SMALL;  // (two packed launches: 8 allocating lanes per wave)
+    const size_t open_chunks = MAX_BLOCKS * (4 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL) +
+                               (size_t)2 * 256 * 32 * 8 * PK_WAVES * RUN_CHUNK_SMALL;  // (two packed launches: 8 allocating lanes per wave)
+    size_t run_share = std::max<size_t>(NT * 12, 1 << 16);
     DBuf<uint32_t> runs;
     for (int attempt = 0;; ++attempt) {
+        const size_t cap_runs = run_share + open_chunks;
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
         runs.alloc(cap_runs);
         counters.zero();
@@ -1614,7 +1618,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
         std::vector<uint32_t> hc = counters.download(2);
         if (!hc[1]) break;
         if (attempt >= 3) fail(HLMI_ENOMEM, "CIGAR run pool overflow");
-        cap_runs *= 4;
+        run_share *= 4;
     }
     stat_add("align_tasks", (double)NT);
     {
@@ -1668,4 +1672,46 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     out.n_ops = n_ops;
 }
 
+}  // namespace hlmi
+
+namespace hlmi {
+// The CIGAR run pool and the task lists of one alignment pass are indexed with 32 bits: a batch with more tasks than
+// that allows (many short pieces per anchor: divergent read sets) is aligned in spans of consecutive pieces.
+void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
+                  const ChainOut &ch, std::vector<AlignOut> &outs) {
+    const size_t P = ch.n_pieces;
+    if (!P) return;
+    size_t span_tasks = 64u << 20;               // (x 12 runs, x 4 once when a span overflows its pool: below 2^32)
+    if (const char *e = getenv("HLMI_ALIGN_SPAN_TASKS")) span_tasks = (size_t)std::max(64, atoi(e));      // test hook
+    const size_t NT = ch.n_fp + P;
+    if (NT <= span_tasks) {
+        AlignOut ao;
+        align_span(in, o, d_qlen, d_tlen, PieceSpan{{ch.pieces.p}, P, ch.n_fp, {ch.fps.p}}, ao);
+        if (ao.n_rows) outs.push_back(std::move(ao));
+        return;
+    }
+    DBuf<uint32_t> tcnt(P), toff(P);
+    hipLaunchKernelGGL(piece_task_count_kernel, dim3((unsigned)cdiv(P, (size_t)256)), dim3(256), 0, stream(), ch.pieces.p, P, tcnt.p);
+    exclusive_scan_u32(tcnt.p, toff.p, P);
+    const size_t n_spans = cdiv(NT, span_tasks);
+    size_t p0 = 0, t0 = 0;                       // first piece / first task of the span
+    for (size_t k = 1; k <= n_spans && p0 < P; ++k) {
+        size_t p1 = P, t1 = NT;
+        if (k < n_spans) {                       // first piece whose tasks start at or behind k / n_spans of all tasks
+            const size_t want = NT / n_spans * k;
+            size_t lo = p0 + 1, hi = P;
+            while (lo < hi) {
+                const size_t mid = (lo + hi) / 2;
+                if ((size_t)download_one(toff.p + mid) < want) lo = mid + 1; else hi = mid;
+            }
+            p1 = lo;
+            t1 = p1 < P ? (size_t)download_one(toff.p + p1) : NT;
+        }
+        AlignOut ao;
+        align_span(in, o, d_qlen, d_tlen, PieceSpan{{ch.pieces.p + p0}, p1 - p0, (t1 - t0) - (p1 - p0), {ch.fps.p}}, ao);
+        if (ao.n_rows) outs.push_back(std::move(ao));
+        p0 = p1; t0 = t1;
+    }
+    stat_add("align_spans", (double)n_spans);
+}
 }  // namespace hlmi

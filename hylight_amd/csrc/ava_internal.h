@@ -58,7 +58,8 @@ struct AlignOut {
     DBuf<uint32_t> ops;
     DBuf<uint64_t> ord_hi, ord_lo;   // stream-order keys of each row
 };
+// appends the rows of the batch's pieces (one AlignOut, or one per span of pieces when the batch has too many tasks)
 void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
-                  const ChainOut &ch, AlignOut &out);
+                  const ChainOut &ch, std::vector<AlignOut> &outs);
 
 }  // namespace hlmi

@@ -305,3 +305,15 @@ def test_ava_long_gaps_take_the_second_gap_piece(tmp_path):
     g1.gap_open2 = 0
     api.ava(fa, fa, tmp_path / "g1.paf", g1)
     assert open(tmp_path / "g1.paf").read() == open(tmp_path / "o1.paf").read()
+
+
+def test_ava_alignment_in_spans_of_pieces(tmp_path, monkeypatch):
+    """A batch with more alignment tasks than the 32-bit run pool can index is aligned in spans of consecutive pieces
+    (divergent read sets at full batch size); HLMI_ALIGN_SPAN_TASKS forces spans of a few thousand tasks here."""
+    reads = _sim(36, 80, n_strains=3, genome_len=15000, err_sub=0.01, err_ins=0.004, err_del=0.004)
+    fa = _write(tmp_path, "r.fa", reads)
+    api.ava(fa, fa, tmp_path / "one.paf")
+    monkeypatch.setenv("HLMI_ALIGN_SPAN_TASKS", "3000")
+    api.ava(fa, fa, tmp_path / "spans.paf")
+    assert api.last_stats().get("align_spans", 0) >= 2
+    assert open(tmp_path / "spans.paf").read() == open(tmp_path / "one.paf").read()
