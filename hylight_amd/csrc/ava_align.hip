@@ -35,7 +35,7 @@ inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 
 struct Task {               // 32 B, self-contained: the kernels reach the bases without touching Piece / offset tables
     uint32_t piece;
-    uint16_t kind;          // 0 block, 1 left extension, 2 right extension; bit 2: query on the reverse strand
+    uint16_t kind;          // 0 block, 1 left extension, 2 right extension; bit 2: query on the reverse strand; bit 3: TASK_ONE
     uint16_t narrow;        // block: 1 = 16-diagonal band; extensions: (row that reaches the query end + 1) << 1, 0 = out of reach
     uint64_t qa, ta;        // offsets in qcodes / tcodes of window element 0 (see load_window4 for the directions)
     int16_t m, n;           // rows (query), cols (target)
@@ -44,6 +44,7 @@ struct Task {               // 32 B, self-contained: the kernels reach the bases
                             // them); the traceback starts with a run of that many '='
 };
 constexpr uint16_t TASK_REV = 4;
+constexpr uint16_t TASK_ONE = 8;             // extension: no gap long enough for the second piece of the gap cost can be on or tie the best path
 struct TaskOut {            // 24 B
     int32_t score;
     int32_t bi, bj;         // extension: rows / cols consumed
@@ -132,6 +133,7 @@ struct AlignArgs {
     int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     int kgap1;              // 1: blocks with |n - m| = 1 and one substitution finish in the classifier (fifth certificate)
+    int one_ok;             // 1: extensions may be certified for the one-piece rows (HLMI_NO_ONE_PIECE_CERT: test hook)
     int trim_ok;            // 1: near-diagonal DP tasks lose their exactly matching suffix (HLMI_NO_SUFFIX_TRIM: test hook)
     int kshift;             // 1: a square block with kmax + 1 substitutions also finishes here when the one-base shift
                             // that could avoid them all does not match (fourth certificate, see classify_kernel)
@@ -209,7 +211,7 @@ __device__ __forceinline__ uint32_t load_window4(const uint8_t *codes, long long
 
 // stats[]: 0 bases (Lq + Lt) of all tasks, 1 of the square blocks compared here, 2 of the narrow DP tasks, 3 of the
 // wide DP tasks, 4 tasks finished on the diagonal fast path, 5 DP tasks, 6 DP rows
-enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, N_ALIGN_STATS };
+enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, N_ALIGN_STATS };
 constexpr int NR_SMALL = 64;                    // narrow tasks with fewer rows than this run in the instance with half the plane LDS
 
 // 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
-    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
+    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
     const size_t n_units = PASS == 1 ? a.n_tasks : (size_t)*a.defer_count;
     const size_t rounds = (n_units + n_thr - 1) / n_thr;              // uniform trip count: the allocation is per wave
     // the reference of a task (PASS 2: its index in the list) is fetched a round ahead
@@ -455,13 +457,32 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             const int L = m < n ? m : n;
             const int end_row = (int)(tk.narrow >> 1) - 1;
             bool same = a.end_bonus == 0 || end_row < 0 || L == end_row;
-            for (int x = 0; x < L && same; x += 8) {
+            // One-piece certificate for the extensions the DP will get.  The second piece of the gap cost prices a gap at or
+            // below the first from g* = ceil((open2 - open) / (ext - ext2)) bases on; a path with such a gap ends in a cell
+            // (i, j) with at most match * min(i, j) - (open2 + ext2 g*) <= match * L - cost*, L = min(m, n).  The main diagonal alone reaches
+            // match * L - (match + mismatch) * k at (L, L) with k substitutions: if that is MORE than the bound, no path with
+            // a long gap is the best cell's path or ties with it anywhere on it (a tie would make a long-gap path of the best
+            // score), every cell on the traceback has the same arrivals under both costs, and the DP with the first piece
+            // alone returns the same cell and path (k <= allow below; no end bonus in play, no ambiguous base).
+            int allow = -1, k_ext = 0;
+            bool amb_ext = false;
+            if (a.go2 > 0 && a.ge > a.ge2 && a.end_bonus == 0 && a.one_ok) {
+                int g = (a.go2 - a.go + (a.ge - a.ge2) - 1) / (a.ge - a.ge2);
+                g = g < 1 ? 1 : g;
+                allow = (a.go2 + a.ge2 * g - 1) / (a.match + a.mismatch);      // (match + mismatch) * k < cost*
+            }
+            for (int x = 0; x < L && (same || (k_ext <= allow && !amb_ext)); x += 8) {
                 const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, left != rev, rev, x);
                 const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, left, false, x);
                 const int rest = L - x;
                 const uint64_t keep = rest >= 8 ? ~0ull : (1ull << (8 * rest)) - 1ull;
-                same = ((q8 ^ t8) & keep) == 0 && ((q8 | t8) & keep & 0x0404040404040404ull) == 0;
+                uint64_t d = (q8 ^ t8) & keep;
+                amb_ext |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
+                d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
+                k_ext += __popcll(d);
+                same = same && d == 0 && !amb_ext;
             }
+            if (!same && !amb_ext && k_ext <= allow) { tk.kind |= TASK_ONE; ++st[ST_WIDE_ONE]; }
             if (same) {
                 runs[nr++] = (uint32_t)L << 4 | OP_EQ;
                 fast_score = a.match * L;
@@ -1290,7 +1311,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         const int end_row = kind != 0 ? (int)(tk.narrow >> 1) - 1 : -1;
         int Hend = 0, best_h = 0, best_i = 0;
         const bool amb = __any(ambig);
-        const bool two = a.go2 > 0;
+        const bool two = a.go2 > 0 && !(tk.kind & TASK_ONE);
         auto rows_of = [&](auto AMB, auto EXTN, auto TW) {
             wide_rows<decltype(AMB)::value, decltype(EXTN)::value, decltype(TW)::value, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend,
                                                                                                 best_h, best_i);
@@ -1536,6 +1557,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                         !getenv("HLMI_NO_SHIFT_CERT") ? 1 : 0;
         }
         aa.trim_ok = getenv("HLMI_NO_SUFFIX_TRIM") ? 0 : 1;
+        aa.one_ok = getenv("HLMI_NO_ONE_PIECE_CERT") ? 0 : 1;
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         aa.run_buf_cap = 0xffffffffu;
         if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
@@ -1630,6 +1652,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         stat_add("align_bases_classify", (double)h[ST_BASES_SQUARE]);
         stat_add("align_bases_narrow", (double)h[ST_BASES_NARROW]);
         stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
+        stat_add("align_tasks_wide_one_piece", (double)h[ST_WIDE_ONE]);
     }
     // assemble
     AsmArgs as{};
