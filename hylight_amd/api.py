@@ -25,6 +25,13 @@ class AvaOpts(C.Structure):
                 ("gap_open2", C.c_int), ("gap_ext2", C.c_int)]
 
 
+class VqOverlap(C.Structure):
+    _fields_ = [("id1", C.c_uint64), ("id2", C.c_uint64), ("pos1", C.c_uint32), ("pos2", C.c_uint32),
+                ("perc1", C.c_uint32), ("perc2", C.c_uint32), ("len1", C.c_uint32), ("len2", C.c_uint32),
+                ("ord", C.c_char), ("ori1", C.c_char), ("ori2", C.c_char), ("type1", C.c_char), ("type2", C.c_char),
+                ("pad", C.c_char * 3)]
+
+
 # every symbol include/hylight_mi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "hlmi_init": (C.c_int, [C.c_int, C.c_int]),
@@ -49,6 +56,10 @@ SYMBOLS = {
     "hlmi_ava": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(AvaOpts), C.c_char_p]),
     "hlmi_miniasm": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
     "hlmi_sfo2overlaps": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
+    "hlmi_vq_parse_overlaps": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(VqOverlap),
+                                         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hlmi_vq_transitive_edges": (C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]),
     "hlmi_job_open": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "hlmi_job_close": (None, [C.c_void_p]),
     "hlmi_job_num_queries": (C.c_int64, [C.c_void_p]),
@@ -188,6 +199,33 @@ def miniasm(paf, reads_fa, out_path, bub_dist=10000, n_rounds_arg=1, max_ext=1, 
 
 def sfo2overlaps(in_sfo, out_savage, num_singles, num_pairs=0):
     _check(load().hlmi_sfo2overlaps(_b(in_sfo), _b(out_savage), num_singles, num_pairs))
+
+
+def vq_parse_overlaps(savage_path, min_len=150, min_perc=0, relax_pe=False, max_overlaps=100000000):
+    """edge candidates of a 13-column overlaps file -> (list of dicts, n_nonedge, n_skipped)."""
+    n, ne, sk = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _check(load().hlmi_vq_parse_overlaps(_b(savage_path), min_len, min_perc, int(relax_pe), max_overlaps, None, 0,
+                                         C.byref(n), C.byref(ne), C.byref(sk)))
+    buf = (VqOverlap * max(n.value, 1))()
+    _check(load().hlmi_vq_parse_overlaps(_b(savage_path), min_len, min_perc, int(relax_pe), max_overlaps, buf, n.value,
+                                         C.byref(n), C.byref(ne), C.byref(sk)))
+    rows = []
+    for o in buf[:n.value]:
+        rows.append(dict(id1=o.id1, id2=o.id2, pos1=o.pos1, pos2=o.pos2, ord=o.ord.decode(), ori1=o.ori1.decode(),
+                         ori2=o.ori2.decode(), perc1=o.perc1, perc2=o.perc2, len1=o.len1, len2=o.len2,
+                         type1=o.type1.decode(), type2=o.type2.decode()))
+    return rows, ne.value, sk.value
+
+
+def vq_transitive_edges(n_vertices, src, dst, ovlen=None, remove_trans=1):
+    """-> (flags per edge as bytes: bit 0 transitive in the last round, bit 1 scheduled by the branch reduction; count)."""
+    n = len(src)
+    a32 = lambda v: (C.c_uint32 * max(n, 1))(*v)
+    flags = (C.c_uint8 * max(n, 1))()
+    cnt = C.c_uint64(0)
+    _check(load().hlmi_vq_transitive_edges(n_vertices, n, a32(src), a32(dst), a32(ovlen) if ovlen is not None else None,
+                                           remove_trans, flags, C.byref(cnt)))
+    return list(flags[:n]), cnt.value
 
 
 class Job:

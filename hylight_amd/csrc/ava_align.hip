@@ -542,11 +542,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 }
             }
             int p_star = -1, xpos = -1;
-            bool in_prefix = false;
             if (!amb) {
                 if (b1 < a1) p_star = b1 + 1;                                             // s* = 0
                 else if (want == 2 && b2 < a1) { p_star = b2 + 1; xpos = b1; }            // s* = 1, substitution in the suffix
-                else if (want == 2 && b1 < a2) { p_star = b1 + 1; xpos = a1; in_prefix = true; }   // ... in the prefix
+                else if (want == 2 && b1 < a2) { p_star = b1 + 1; xpos = a1; }   // ... in the prefix
             }
             if (p_star < 0 && !amb && b1 >= 0) last_x = b1;     // (suffix trim below; positions count along the shorter sequence)
             if (p_star >= 0) {

@@ -287,6 +287,24 @@ int hlmi_sfo2overlaps(const char *in_sfo, const char *out_savage, int num_single
     });
 }
 
+int hlmi_vq_parse_overlaps(const char *savage_path, uint32_t min_overlap_len, uint32_t min_overlap_perc, int relax_pe,
+                           uint64_t max_overlaps, hlmi_vq_overlap *out, uint64_t cap, uint64_t *n_out,
+                           uint64_t *n_nonedge, uint64_t *n_skipped) {
+    return guarded([&] {
+        if (!savage_path || !n_out || !n_nonedge || !n_skipped || (cap && !out)) fail(HLMI_EINVAL, "hlmi_vq_parse_overlaps: NULL argument");
+        vq_parse_overlaps(savage_path, min_overlap_len, min_overlap_perc, relax_pe, max_overlaps, out, cap, n_out, n_nonedge, n_skipped);
+    });
+}
+
+int hlmi_vq_transitive_edges(uint32_t n_vertices, uint64_t n_edges, const uint32_t *src, const uint32_t *dst,
+                             const uint32_t *ovlen, int remove_trans, uint8_t *flags, uint64_t *n_transitive) {
+    return guarded([&] {
+        if (!n_transitive || (n_edges && (!src || !dst || !flags))) fail(HLMI_EINVAL, "hlmi_vq_transitive_edges: NULL argument");
+        require_device();
+        vq_transitive_edges(n_vertices, n_edges, src, dst, ovlen, remove_trans, flags, n_transitive);
+    });
+}
+
 hlmi_job *hlmi_job_open(const char *reads_fa, const char *ref_fa, int nsplit, int long_mode) {
     hlmi_job *j = nullptr;
     guarded([&] {

@@ -131,6 +131,36 @@ int hlmi_miniasm(const char *paf, const char *reads_fa, int bub_dist, int n_roun
 /* ---- a18: sfo2overlaps.py (--num_pairs 0 branch, HyLight.py:315-318) --------------------- */
 int hlmi_sfo2overlaps(const char *in_sfo, const char *out_savage, int num_singles, int num_pairs);
 
+/* ---- f3 (STARTED): front end of the SAVAGE overlap-graph assembler ------ */
+/* tools/HaploConduct/src (ViralQuasispecies) needs Boost and cannot be built here: these two entry points restate its
+ * text of record and are checked against oracle/vq.py only (parity unpinned).  Not built: the quality-aware overlap score
+ * (EdgeCalculator.cpp:26-139, log / pow / exp thresholds), edge orientation (Edge.h), everything after the graph. */
+typedef struct {
+    uint64_t id1, id2;                 /* strtoul(..., 0) of columns 1, 2                        (Overlap.h:39-40, Types.h:99)  */
+    uint32_t pos1, pos2, perc1, perc2, len1, len2;   /* atoi; pos2 = perc2 = len2 = 0 when column 4 is "-" (Overlap.h:53-57) */
+    char ord, ori1, ori2, type1, type2; /* '1' '2' '-';  '+' '-';  's' 'p'                                                  */
+    char pad[3];
+} hlmi_vq_overlap;
+/* EdgeCalculator.cpp:561-666 construct_edges, the part in front of process_overlaps: lines are trimmed of outer tabs and
+ * blanks and split at tabs; a line without 13 fields is skipped ("incorrect overlap"), as is id1 == id2; an overlap is an
+ * edge candidate when (s,s: len1 >= min_len) or (a 'p' type: len1, len2 >= min_len / 2, or with relax_pe len1 + len2 >=
+ * min_len) and perc >= min_perc, where perc = (perc1 + perc2) / 2 truncated when perc2 > 0, else perc1 (Overlap.h:196).
+ * Reads at most max_overlaps lines.  Candidates go to out[0 .. min(*n_out, cap)) in file order; *n_nonedge counts the rows
+ * the reference writes back to nonedge_overlaps.txt, *n_skipped the other ones.  out may be NULL (cap 0) to count. */
+int hlmi_vq_parse_overlaps(const char *savage_path, uint32_t min_overlap_len, uint32_t min_overlap_perc, int relax_pe,
+                           uint64_t max_overlaps, hlmi_vq_overlap *out, uint64_t cap, uint64_t *n_out,
+                           uint64_t *n_nonedge, uint64_t *n_skipped);
+/* GraphAlgos.cpp:746-795 (findTransEdges, nonemptyIntersect) and :938-993 (removeTransitiveEdges up to the deletion):
+ * edge k = src[k] -> dst[k] of a directed graph on n_vertices vertices.  An edge u -> v is transitive when some w has
+ * u -> w and w -> v.  remove_trans = 1: flags bit 0 marks the transitive edges; 2 / 3: the search is repeated on the graph
+ * of the edges found so far ("double" / "triple" transitive), bit 0 marks the last round's set - the edges the reference
+ * then removes.  With remove_trans == 1 and ovlen != NULL (branch_reduction > 0, :970-993) bit 1 marks the edges
+ * scheduled for deletion: for every transitive edge u -> v of overlap length L, every out-edge of u and every in-edge of v
+ * whose length is <= L.  GPU: one wave per vertex, its out-neighbours in an LDS hash table, the in-lists streamed by the
+ * lanes. */
+int hlmi_vq_transitive_edges(uint32_t n_vertices, uint64_t n_edges, const uint32_t *src, const uint32_t *dst,
+                             const uint32_t *ovlen, int remove_trans, uint8_t *flags, uint64_t *n_transitive);
+
 /* ---- staged multi-GPU job: sketch shard -> (RCCL all-gather by the caller) -> run -------- */
 /* One process per GPU.  Every rank opens the same files, sketches its slice of the query
  * reads into a caller-owned device buffer (16 B per minimizer: two uint64), the caller
