@@ -83,6 +83,8 @@ void sort_pairs_u32_u32(DBuf<uint32_t> &keys, DBuf<uint32_t> &vals, size_t n, in
     if (dv.current() != vals.p) std::swap(vals, v2);
 }
 
+// (small key + 64-bit value: the library's own gfx950 shape measured 113.9 ms per C3 step against 119.3 with PairsOnesweep;
+// 1024 x 8, 512 x 12, 512 x 16, 256 x 16 and 1024 x 4 were slower)
 template <typename K>
 static void sort_small_key_pairs(DBuf<K> &keys, DBuf<uint64_t> &vals, size_t n, int b0, int b1) {
     if (n < 2) return;
@@ -91,9 +93,9 @@ static void sort_small_key_pairs(DBuf<K> &keys, DBuf<uint64_t> &vals, size_t n, 
     rocprim::double_buffer<K> dk(keys.p, k2.p);
     rocprim::double_buffer<uint64_t> dv(vals.p, v2.p);
     size_t tmp_bytes = 0;
-    HIP_CHECK(rocprim::radix_sort_pairs<PairsOnesweep>(nullptr, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, b0, b1, stream()));
     DBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
-    HIP_CHECK(rocprim::radix_sort_pairs<PairsOnesweep>(tmp.p, tmp_bytes, dk, dv, n, b0, b1, stream()));
+    HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, dk, dv, n, b0, b1, stream()));
     if (dk.current() != keys.p) std::swap(keys, k2);
     if (dv.current() != vals.p) std::swap(vals, v2);
 }
