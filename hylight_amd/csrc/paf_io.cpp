@@ -218,6 +218,12 @@ void read_seqs_subset(const char *path, const std::function<bool(std::string_vie
         return true;
     };
     out.n_lines = want ? 0 : (uint64_t)std::count(d.begin(), d.end(), '\n');     // (only the stage's chunking asks for it)
+    if (!want) {                                     // one allocation instead of a gigabyte grown by doubling
+        out.bases.reserve(N);
+        out.names.reserve(out.n_lines / 2 + 1);
+        out.off.reserve(out.n_lines / 2 + 2);
+        out.first_line.reserve(out.n_lines / 2 + 1);
+    }
     std::string_view L;
     bool have = next_line(L);
     while (have) {

@@ -190,7 +190,7 @@ __global__ void read_count_kernel(const uint32_t *midx, size_t n_mz, const uint3
 }
 }  // namespace
 
-static void finish_upload(const std::string &bases, const std::vector<uint64_t> &off, DevReads &out) {
+static void finish_upload(const char *bases, const std::vector<uint64_t> &off, DevReads &out) {
     out.n = off.size() - 1;
     out.total = off.back();
     out.h_off = off;
@@ -198,7 +198,7 @@ static void finish_upload(const std::string &bases, const std::vector<uint64_t> 
                                         (unsigned long long)out.total);
     out.alloc_codes();
     if (out.total) {
-        HIP_CHECK(hipMemcpyAsync(out.codes(), bases.data(), out.total, hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(out.codes(), bases, out.total, hipMemcpyHostToDevice, stream()));
         hipLaunchKernelGGL(encode_kernel, grid1(out.total), dim3(WG), 0, stream(), out.codes(), out.total);
     }
     out.off.upload(off);
@@ -208,8 +208,7 @@ static void finish_upload(const std::string &bases, const std::vector<uint64_t> 
 void upload_reads(const SeqSet &s, size_t lo, size_t hi, DevReads &out) {
     std::vector<uint64_t> off(hi - lo + 1);
     for (size_t i = lo; i <= hi; ++i) off[i - lo] = s.off[i] - s.off[lo];
-    std::string bases = s.bases.substr(s.off[lo], s.off[hi] - s.off[lo]);
-    finish_upload(bases, off, out);
+    finish_upload(s.bases.data() + s.off[lo], off, out);       // (a contiguous stretch of the file's bases: no copy)
 }
 
 void upload_reads(const SeqSet &s, const std::vector<uint32_t> &ids, DevReads &out) {
@@ -219,7 +218,7 @@ void upload_reads(const SeqSet &s, const std::vector<uint32_t> &ids, DevReads &o
         bases.append(s.bases, s.off[ids[i]], s.off[ids[i] + 1] - s.off[ids[i]]);
         off[i + 1] = bases.size();
     }
-    finish_upload(bases, off, out);
+    finish_upload(bases.data(), off, out);
 }
 
 __global__ void copy_reads_kernel(const uint8_t *src, const uint64_t *src_off, const uint32_t *ids, const uint64_t *dst_off,

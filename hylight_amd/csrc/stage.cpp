@@ -17,7 +17,10 @@
 namespace hlmi {
 
 struct Job::Impl {
-    SeqSet Q, T;
+    SeqSet Q, T_own;
+    SeqSet &T;                        // the target set: Q itself when both paths name the same file
+    explicit Impl(bool same) : T(same ? Q : T_own) {}
+    size_t n_bases_q = 0;
     bool long_mode = true;
     hlmi_ava_opts opts{};
     std::vector<std::pair<uint32_t, uint32_t>> chunks;   // target read ranges [lo,hi) per chunk
@@ -35,12 +38,15 @@ static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode) : impl_(new Impl) {
+Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode)
+    : impl_(new Impl(std::string(reads_fa) == ref_fa)) {
     Impl &m = *impl_;
     m.long_mode = long_mode;
     m.opts = long_mode ? ava_opts_long() : ava_opts_short();   // filter_overlap_slr2.py:51 / :55
     read_seqs(reads_fa, m.Q);
-    if (std::string(reads_fa) == ref_fa) m.T = m.Q; else read_seqs(ref_fa, m.T);
+    const bool same = std::string(reads_fa) == ref_fa;
+    if (!same) read_seqs(ref_fa, m.T);
+    m.n_bases_q = m.Q.bases.size();
     name_ranks(m.T.names, m.Q.names, m.rank_t, m.rank_q, m.name_of_rank);
     // --nsplit chunking by LINES (utils.py:44-47): nu = `wc -l`, per = int(nu/(8*nsplit)+1)*8
     const uint64_t nu = m.T.n_lines;
@@ -58,8 +64,11 @@ Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode) :
         r = e;
     }
     upload_reads(m.Q, 0, m.Q.size(), m.dQ);
-    if (std::string(reads_fa) == ref_fa) m.dT = &m.dQ;
+    if (same) m.dT = &m.dQ;
     else { upload_reads(m.T, 0, m.T.size(), m.dT_own); m.dT = &m.dT_own; }
+    // the bases live in HBM from here on: the host copies (a gigabyte at 100 k reads) go
+    std::string().swap(m.Q.bases);
+    std::string().swap(m.T.bases);
     m.d_rank_q.upload(m.rank_q);
     if (m.rank_q.empty()) m.d_rank_q.alloc(1);
 }
@@ -256,7 +265,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     stat_set("t_total_s", now_s() - t0);
 
     // the counts SURVEY.md 8d's byte formula is evaluated on (bench.py: roofline.stage)
-    stat_set("bases_q", (double)m.Q.bases.size());
+    stat_set("bases_q", (double)m.n_bases_q);
     uint64_t bt = 0;
     for (uint32_t t : tids) bt += m.T.len(t);
     stat_set("bases_t", (double)bt);
