@@ -148,13 +148,9 @@ struct AlignArgs {
 
 // exclusive prefix sum over the wave; total = sum of all lanes
 __device__ __forceinline__ uint32_t wave_excl_sum_u32(uint32_t v, int lane, uint32_t &total) {
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)x, o, 64);
-        if (lane >= o) x += u;
-    }
-    total = (uint32_t)__shfl((int)x, 63, 64);
+    (void)lane;
+    const uint32_t x = wave_prefix_sum_incl_dpp(v);          // six DPP adds (the shuffle form was six trips through the LDS crossbar)
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 
