@@ -196,6 +196,16 @@ __device__ __forceinline__ uint32_t load_window4(const uint8_t *codes, long long
     return v;
 }
 
+// the same without the bounds test (the code arrays carry DevReads::PAD bytes of code 4 on both sides; the windows of
+// the DP kernels stay within a few bases of their reads)
+__device__ __forceinline__ uint32_t load_window4p(const uint8_t *codes, long long a0, bool down, bool comp, int x) {
+    uint32_t v;
+    __builtin_memcpy(&v, codes + (down ? a0 - x - 3 : a0 + x), 4);
+    if (down) v = __builtin_bswap32(v);
+    if (comp) v = comp_codes4(v);
+    return v;
+}
+
 // ---- pass 1: classification + diagonal fast path, one lane per task --------------------------------
 // cls[task] = 0 done here (empty task or fast path), 1 / 3 DP in the 16-diagonal band (<= / > NR_SHORT rows),
 // 4 / 2 DP in the 64-diagonal band (<= / > WIDE_SHORT rows).
@@ -847,13 +857,13 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
             for (int r = 0; r < NQ_STEPS; ++r) {
                 const int x = 4 * (l + 16 * r);
                 vq[r] = 0;
-                if (x < m) vq[r] = load_window4(a.qcodes, a.q_total, (long long)tk.qa, rev, rev, x);
+                if (x < m) vq[r] = load_window4p(a.qcodes, (long long)tk.qa, rev, rev, x);
             }
 #pragma unroll
             for (int r = 0; r < NT_STEPS; ++r) {
                 const int x = 4 * (l + 16 * r);
                 vt[r] = 0;
-                if (x < n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)tk.ta, false, false, x);
+                if (x < n) vt[r] = load_window4p(a.tcodes, (long long)tk.ta, false, false, x);
             }
 #pragma unroll
             for (int r = 0; r < NQ_STEPS; ++r) {
@@ -1029,13 +1039,13 @@ __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArg
             for (int r = 0; r < NQ_STEPS; ++r) {
                 const int x = 4 * (l + 16 * r);
                 vq[r] = 0;
-                if (x < t.m) vq[r] = load_window4(a.qcodes, a.q_total, (long long)t.qa, rev, rev, x);
+                if (x < t.m) vq[r] = load_window4p(a.qcodes, (long long)t.qa, rev, rev, x);
             }
 #pragma unroll
             for (int r = 0; r < NT_STEPS; ++r) {
                 const int x = 4 * (l + 16 * r);
                 vt[r] = 0;
-                if (x < t.n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)t.ta, false, false, x);
+                if (x < t.n) vt[r] = load_window4p(a.tcodes, (long long)t.ta, false, false, x);
             }
 #pragma unroll
             for (int r = 0; r < NQ_STEPS; ++r) {
@@ -1289,10 +1299,10 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         {   // stage the two windows (DP order), 4 bases per lane and step
             const bool rev = (tk.kind & TASK_REV) != 0, left = kind == 1;
             uint32_t vq = 0, vt[2] = {0, 0};
-            if (4 * lane < m) vq = load_window4(a.qcodes, a.q_total, (long long)tk.qa, left != rev, rev, 4 * lane);
+            if (4 * lane < m) vq = load_window4p(a.qcodes, (long long)tk.qa, left != rev, rev, 4 * lane);
 #pragma unroll
             for (int r = 0; r < 2; ++r)
-                if (4 * (lane + 64 * r) < n) vt[r] = load_window4(a.tcodes, a.t_total, (long long)tk.ta, left, false, 4 * (lane + 64 * r));
+                if (4 * (lane + 64 * r) < n) vt[r] = load_window4p(a.tcodes, (long long)tk.ta, left, false, 4 * (lane + 64 * r));
             if (4 * lane < m) { *(uint32_t *)(sq + 4 * lane) = vq; ambig |= (vq & 0x04040404u) != 0; }
 #pragma unroll
             for (int r = 0; r < 2; ++r)
