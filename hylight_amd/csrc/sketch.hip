@@ -194,8 +194,6 @@ static void finish_upload(const char *bases, const std::vector<uint64_t> &off, D
     out.n = off.size() - 1;
     out.total = off.back();
     out.h_off = off;
-    if (out.total >= (1ull << 32)) fail(HLMI_EINVAL, "read set of %llu bases exceeds the 4 Gbase batch limit",
-                                        (unsigned long long)out.total);
     out.alloc_codes();
     if (out.total) {
         HIP_CHECK(hipMemcpyAsync(out.codes(), bases, out.total, hipMemcpyHostToDevice, stream()));
@@ -252,6 +250,7 @@ static int64_t sketch_core(const DevReads &r, int k, int w, int hpc, uint32_t ri
     if (!(k & 1) || k < 3 || k > 28 || w < 1 || w > 64) fail(HLMI_EINVAL, "sketch needs odd k in [3,28], w in [1,64]");
     const size_t n = r.total;
     if (!r.n) return 0;
+    if (n >= (1ull << 32)) fail(HLMI_EINVAL, "sketch of %zu bases in one piece (the kernels index bases with 32 bits: the job sketches in parts)", n);
     if (!n) {
         HIP_CHECK(hipMemsetAsync(d_counts, 0, r.n * 4, stream()));
         sync();                  // the caller reads the counts from another stream (torch) right after the call

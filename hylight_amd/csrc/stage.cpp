@@ -87,13 +87,26 @@ int64_t Job::sketch_range(int64_t lo, int64_t hi, void *dev_mz, int64_t cap, voi
     Impl &m = *impl_;
     if (lo < 0 || hi < lo || (size_t)hi > m.Q.size()) fail(HLMI_EINVAL, "sketch range out of bounds");
     if (lo == hi) return 0;
-    if (lo == 0 && (size_t)hi == m.Q.size())     // the reads are already resident in HBM
+    // The sketch kernels index bases with 32 bits: a range of more than SKETCH_PART bases (BASELINE configs[3]: a million
+    // long reads are 10 Gbases) is sketched in parts of consecutive reads, each appended to the output.
+    uint64_t part_bases = 3ull << 30;
+    if (const char *e = getenv("HLMI_SKETCH_PART_MBASES")) part_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
+    const uint64_t bases = m.Q.off[hi] - m.Q.off[lo];
+    if (lo == 0 && (size_t)hi == m.Q.size() && bases <= part_bases)     // the reads are already resident in HBM
         return sketch_device_into(m.dQ, m.opts.k, m.opts.w, m.opts.hpc, 0, (Mz *)dev_mz, cap, (uint32_t *)dev_counts);
-    DevReads part;
-    std::vector<uint32_t> ids((size_t)(hi - lo));
-    for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)(lo + (int64_t)i);
-    subset_reads_device(m.dQ, ids, part);
-    return sketch_device_into(part, m.opts.k, m.opts.w, m.opts.hpc, (uint32_t)lo, (Mz *)dev_mz, cap, (uint32_t *)dev_counts);
+    int64_t total = 0;
+    for (int64_t a = lo; a < hi;) {
+        int64_t b = a + 1;
+        while (b < hi && m.Q.off[b + 1] - m.Q.off[a] <= part_bases) ++b;
+        DevReads part;
+        std::vector<uint32_t> ids((size_t)(b - a));
+        for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)(a + (int64_t)i);
+        subset_reads_device(m.dQ, ids, part);
+        total += sketch_device_into(part, m.opts.k, m.opts.w, m.opts.hpc, (uint32_t)a, (Mz *)dev_mz + total, cap - total,
+                                    (uint32_t *)dev_counts + (a - lo));
+        a = b;
+    }
+    return total;
 }
 
 void Job::set_query_sketch(const void *dev_mz, int64_t n, const void *dev_counts) {
@@ -112,7 +125,40 @@ void Job::set_query_sketch(const void *dev_mz, int64_t n, const void *dev_counts
 
 void Job::sketch_all_queries() {
     Impl &m = *impl_;
-    sketch_device(m.dQ, m.opts.k, m.opts.w, m.opts.hpc, 0, m.own);
+    uint64_t part_bases = 3ull << 30;
+    if (const char *e = getenv("HLMI_SKETCH_PART_MBASES")) part_bases = (uint64_t)std::max(1, atoi(e)) << 20;
+    if (m.Q.off.back() <= part_bases) {
+        sketch_device(m.dQ, m.opts.k, m.opts.w, m.opts.hpc, 0, m.own);
+    } else {                                     // in parts of consecutive reads, each sketched to its exact size, then joined
+        const size_t nq = m.Q.size();
+        std::vector<DevSketch> parts;
+        std::vector<size_t> first;
+        size_t total = 0;
+        for (size_t a = 0; a < nq;) {
+            size_t b = a + 1;
+            while (b < nq && m.Q.off[b + 1] - m.Q.off[a] <= part_bases) ++b;
+            DevReads part;
+            std::vector<uint32_t> ids(b - a);
+            for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)(a + i);
+            subset_reads_device(m.dQ, ids, part);
+            parts.emplace_back();
+            sketch_device(part, m.opts.k, m.opts.w, m.opts.hpc, (uint32_t)a, parts.back());
+            first.push_back(a);
+            total += parts.back().n;
+            a = b;
+        }
+        m.own.mz.alloc(total ? total : 1);
+        m.own.counts.alloc(nq ? nq : 1);
+        size_t at = 0;
+        for (size_t p = 0; p < parts.size(); ++p) {
+            const size_t n_reads = (p + 1 < parts.size() ? first[p + 1] : nq) - first[p];
+            if (parts[p].n) HIP_CHECK(hipMemcpyAsync(m.own.mz.p + at, parts[p].mz.p, parts[p].n * sizeof(Mz), hipMemcpyDeviceToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(m.own.counts.p + first[p], parts[p].counts.p, n_reads * 4, hipMemcpyDeviceToDevice, stream()));
+            at += parts[p].n;
+        }
+        sync();
+        m.own.n = total;
+    }
     set_query_sketch(m.own.mz.p, (int64_t)m.own.n, m.own.counts.p);
 }
 

@@ -152,3 +152,35 @@ def test_subruns_do_not_change_the_result(workload, monkeypatch):
     api.split_reads2(fa, fa, 100, d, alt, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
     assert api.last_stats()["subruns"] >= 4
     assert open(alt).read() == open(out).read()
+
+
+def test_sketch_in_parts_changes_nothing(tmp_path, monkeypatch):
+    """Read sets of more than 3 Gbases (BASELINE configs[3]: 10 Gbases of long reads) are sketched in parts of consecutive
+    reads; HLMI_SKETCH_PART_MBASES forces parts of a megabase here, on the single-GPU path and on a rank's slice."""
+    from hylight_amd import api
+    from hylight_amd import simulate as S
+    reads, _ = S.simulate_reads(seed=91, n_strains=3, genome_len=40_000, n_reads=600, mean_len=6000, min_len=1500,
+                                max_len=20_000)
+    fa = tmp_path / "r.fa"
+    S.write_fasta(reads, fa)
+    stage = dict(len_over=3000, mc=2, iden=0.95)
+    one = tmp_path / "one.paf"
+    api.split_reads2(fa, fa, 12, tmp_path, one, long=True, **stage)
+    monkeypatch.setenv("HLMI_SKETCH_PART_MBASES", "1")
+    parts = tmp_path / "parts.paf"
+    api.split_reads2(fa, fa, 12, tmp_path, parts, long=True, **stage)
+    assert open(parts).read() == open(one).read() and os.path.getsize(one) > 0
+    # the staged job: a slice of the reads sketched in parts into a caller buffer
+    import torch
+    j = api.Job(str(fa), str(fa), 12, True)
+    nq = j.num_queries
+    lo, hi = nq // 3, nq
+    cap = j.sketch_bound(lo, hi)
+    mz = torch.empty((cap, 2), dtype=torch.int64, device="cuda")
+    cnt = torch.empty(hi - lo, dtype=torch.int32, device="cuda")
+    n1 = j.sketch(lo, hi, mz.data_ptr(), cap, cnt.data_ptr())
+    a, ca = mz[:n1].clone(), cnt.clone()
+    monkeypatch.delenv("HLMI_SKETCH_PART_MBASES")
+    n2 = j.sketch(lo, hi, mz.data_ptr(), cap, cnt.data_ptr())
+    assert n1 == n2 and torch.equal(a, mz[:n2]) and torch.equal(ca, cnt)
+    j.close()
