@@ -17,6 +17,8 @@ OUT = os.path.join(HERE, "libhylight_mi.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
+if os.environ.get("HLMI_INSTRUMENT"):            # kernel phase counters / self-checks (tuning builds only, never benched)
+    FLAGS.append("-DHLMI_INSTRUMENT")
 
 
 def sources():

@@ -30,6 +30,13 @@ constexpr int WG = 256;
 constexpr int HB = 1024;             // occurrence histogram bins per chunk
 // anchor key = qlocal | target | strand | tpos, packed with the bit widths the batch actually needs (pb bits of
 // target position, tb bits of target id): the anchor radix sort then runs 5 passes instead of 8 on C2
+// instrumentation (phase cycle counters, the 16-predecessor self-check, group size histogram) is compiled in only with
+// -DHLMI_INSTRUMENT (HLMI_INSTRUMENT=1 python -m hylight_amd.build): the shipped library carries none of it
+#ifdef HLMI_INSTRUMENT
+constexpr bool INSTR = true;
+#else
+constexpr bool INSTR = false;
+#endif
 constexpr int QL_BITS = 16, T_BITS_MAX = 21, TPOS_BITS_MAX = 24;     // chain scores (<= target length) carry 6 tie-break bits in 32
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         for (int k = lane; k < BC_RING; k += 64) bc[k] = 0;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        long long tp0 = a.prof ? (long long)__builtin_readcyclecounter() : 0, tpc = 0;
+        long long tp0 = (INSTR && a.prof) ? (long long)__builtin_readcyclecounter() : 0, tpc = 0;
         int P1_f = 0, P1_p = -1, P2_f = 0;                 // f / p of the block before, f of the one before that
         int prev_root = 0;                                 // roots of the last resolved block (lane = index mod 64)
         auto resolve = [&](int w0, int Rf, int Rp, int Bf) {
@@ -908,7 +915,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                 if (nb == 64) M_pk -= (M_pk & 255) != PK_NONE ? 64 : 0;
                 const int O_f = O_pk >> 8, O_st = O_pk & 255;
                 const int O_p = O_st == PK_NONE ? -1 : i0 - 64 + O_st;
-                if (a.check_ok && a.check_ok[g] && i0 + lane < n) {
+                if (INSTR && a.check_ok && a.check_ok[g] && i0 + lane < n) {
                     const uint32_t v = a.fp[(size_t)((long long)g_first + g_step * (i0 + lane))];
                     const int f16 = (int)(v >> 5), p16 = (v & 31u) ? i0 + lane - (int)(v & 31u) : -1;
                     if (f16 != O_f || p16 != O_p) {
@@ -960,7 +967,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         }
         resolve((n - 1) & ~63, P1_f, P1_p, P2_f);
         __threadfence_block();
-        if (a.prof) { const long long t = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&a.prof[0], (unsigned long long)(t - tp0)); tp0 = t; }
+        if (INSTR && a.prof) { const long long t = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&a.prof[0], (unsigned long long)(t - tp0)); tp0 = t; }
         uint32_t fcur = 2u * (uint32_t)b;                  // next free fixed-point slot of the group
         for (int s0 = 0; s0 < n; s0 += 64) {
             int pk_i = 0;
@@ -984,14 +991,14 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                 // fixed points of this chain: at most 2 per member, and the chains of a group have disjoint members -
                 // the group's range of the array (twice its anchors) is handed out chain after chain, no counter needed
                 uint32_t np = 0, nf = 0;
-                const long long te = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+                const long long te = (INSTR && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
                 emit_chain(a, b, g_first, g_step, lane, s, peak_i, qg, tg, strand, np, nf, fcur, pbuf, n_pbuf);
                 fcur += nf;
-                if (a.prof) tpc += (long long)__builtin_readcyclecounter() - te;
+                if (INSTR && a.prof) tpc += (long long)__builtin_readcyclecounter() - te;
                 wave_fps += nf;
             }
         }
-        if (a.prof && lane == 0) {
+        if (INSTR && a.prof && lane == 0) {
             const long long t = (long long)__builtin_readcyclecounter();
             atomicAdd(&a.prof[1], (unsigned long long)(t - tp0 - tpc));
             atomicAdd(&a.prof[2], (unsigned long long)tpc);
@@ -1212,7 +1219,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (G) {
         hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p);
         sort_pairs_u32_u32(gkey.p, gorder.p, G, 0, 16);
-        if (getenv("HLMI_GROUP_HIST")) {
+        if (INSTR && getenv("HLMI_GROUP_HIST")) {
             DBuf<unsigned long long> hist(64);
             hist.zero();
             hipLaunchKernelGGL(group_hist_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, hist.p);
@@ -1249,7 +1256,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         // chain bookkeeping of a proven group reads those, only the groups without the proof run the full DP
         DBuf<uint32_t> fp(A);
         ca.fp = fp.p;
-        if (getenv("HLMI_CHAIN_DP16_CHECK")) {     // self-check: every group through the full DP, compared with the proven ones
+        if (INSTR && getenv("HLMI_CHAIN_DP16_CHECK")) {     // self-check: every group through the full DP, compared with the proven ones
             DBuf<uint8_t> verdict(G), ok_of_group(G);
             DBuf<unsigned long long> n_bad(8);
             n_bad.zero();
@@ -1266,14 +1273,14 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
                                hb[4] >> 32, (int)(uint32_t)hb[4], hb[5] >> 32, (int)(uint32_t)hb[5]);
         } else {
             DBuf<unsigned long long> prof(4);
-            if (getenv("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
+            if (INSTR && getenv("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
             {
                 KTimer kt("chain");
                 hipLaunchKernelGGL((chain_kernel<3, 2>), grid_for(G), block, 0, stream(), ca);
             }
             HIP_CHECK(hipGetLastError());
             sync();                                   // fp goes out of scope
-            if (ca.prof) {
+            if (INSTR && ca.prof) {
                 const std::vector<unsigned long long> hp = prof.download(4);
                 stat_add("chain_prof_blocks_cyc", (double)hp[0]); stat_add("chain_prof_members_cyc", (double)hp[1]);
                 stat_add("chain_prof_fixed_cyc", (double)hp[2]); stat_add("chain_prof_groups", (double)hp[3]);

@@ -112,6 +112,8 @@ struct KTimer {
 };
 void ktimer_flush();
 void ktimer_discard();           // drop pending timers without reading them (error paths)
+size_t ktimer_mark();            // number of pending timers; ktimer_rollback(mark) forgets the ones started since
+void ktimer_rollback(size_t mark);
 
 // Host wall-clock of a scope (stream drained at both ends) -> stats "host_s.<name>"; active only with HLMI_HOST_TIMERS set
 struct HostTimer {

@@ -49,16 +49,30 @@ void write_lines(const char *path, const std::vector<std::string> &lines) {
     write_lines(path, v);
 }
 void write_lines(const char *path, const std::vector<std::string_view> &lines) {
-    // written next to the target and renamed on success: a short write (ENOSPC, quota) never leaves a truncated file
-    // under the final name for the next tool of the pipeline to read
-    const std::string tmp = std::string(path) + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) fail(HLMI_EIO, "cannot write %s: %s", path, strerror(errno));
+    // A regular-file target is written next to itself under a name of this process's own and renamed on success: a short
+    // write (ENOSPC, quota) never leaves a truncated file under the final name for the next tool of the pipeline to read,
+    // and two writers of one target do not share a temporary.  Anything else (/dev/stdout, a FIFO) is written directly.
+    struct stat st;
+    const bool direct = stat(path, &st) == 0 && !S_ISREG(st.st_mode);
+    std::string tmp = path;
+    FILE *f = nullptr;
+    if (direct) {
+        f = fopen(path, "wb");
+    } else {
+        tmp += ".XXXXXX";
+        const int fd = mkstemp(&tmp[0]);
+        if (fd >= 0) {
+            fchmod(fd, 0666 & ~[] { const mode_t m = umask(0); umask(m); return m; }());
+            f = fdopen(fd, "wb");
+            if (!f) { const int e = errno; close(fd); remove(tmp.c_str()); errno = e; }
+        }
+    }
+    if (!f) fail(HLMI_EIO, "cannot write %s: %s", tmp.c_str(), strerror(errno));
     std::string buf;                             // one buffer, few large writes
     buf.reserve(8u << 20);
-    bool ok = true;
+    int err = 0;                                 // errno of the first failing call
     auto flush = [&]() {
-        if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) ok = false;
+        if (!err && !buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) err = errno ? errno : EIO;
         buf.clear();
     };
     for (auto &l : lines) {
@@ -67,14 +81,17 @@ void write_lines(const char *path, const std::vector<std::string_view> &lines) {
         if (buf.size() > (7u << 20)) flush();
     }
     flush();
-    if (ferror(f)) ok = false;
-    if (fclose(f) != 0) ok = false;
-    if (!ok) {
+    if (!err && fflush(f) != 0) err = errno ? errno : EIO;
+    if (fclose(f) != 0 && !err) err = errno ? errno : EIO;
+    if (err) {
+        if (!direct) remove(tmp.c_str());
+        fail(HLMI_EIO, "write error on %s: %s", tmp.c_str(), strerror(err));
+    }
+    if (!direct && rename(tmp.c_str(), path) != 0) {
         const int e = errno;
         remove(tmp.c_str());
-        fail(HLMI_EIO, "write error on %s: %s", path, strerror(e));
+        fail(HLMI_EIO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(e));
     }
-    if (rename(tmp.c_str(), path) != 0) fail(HLMI_EIO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(errno));
 }
 
 static bool parse_u32(std::string_view s, uint32_t &v) {

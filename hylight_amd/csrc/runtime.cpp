@@ -87,6 +87,14 @@ void ktimer_flush() {
     g_krecs.clear();
 }
 
+size_t ktimer_mark() { return g_krecs.size(); }
+void ktimer_rollback(size_t mark) {            // forget the timers started after `mark` (a run that was given up)
+    if (mark >= g_krecs.size()) return;
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    for (size_t i = mark; i < g_krecs.size(); ++i) { (void)hipEventDestroy(g_krecs[i].a); (void)hipEventDestroy(g_krecs[i].b); }
+    g_krecs.resize(mark);
+}
+
 void ktimer_discard() {
     if (g_krecs.empty()) return;
     if (g_stream) (void)hipStreamSynchronize(g_stream);

@@ -180,7 +180,11 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         if ((int)(c % (size_t)world) == rank) my_chunks.push_back((uint32_t)c);
     constexpr double SUBRUN_ANCHORS = 1.2e10, SUBRUN_OUT_BYTES = 64e9;
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
-    constexpr double SUBRUN_ANCHORS_MAX = 2.4e10;
+    double subrun_anchors_max = 2.4e10, subrun_out_max = 1.5 * SUBRUN_OUT_BYTES;
+    // test hooks: the refusal / retry path below with small inputs (millions of anchors / MB of output)
+    if (const char *e = getenv("HLMI_SUBRUN_MAX_MANCHORS")) subrun_anchors_max = 1e6 * std::max(1e-3, atof(e));
+    if (const char *e = getenv("HLMI_SUBRUN_MAX_OUT_MB")) subrun_out_max = 1e6 * std::max(1e-3, atof(e));
+    const double subrun_anchors = std::min(SUBRUN_ANCHORS, subrun_anchors_max / 2), subrun_out = std::min(SUBRUN_OUT_BYTES, subrun_out_max / 1.5);
     uint64_t budget_bases = 128ull << 20;
     if (const char *e = getenv("HLMI_SUBRUN_MBASES")) budget_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
     const bool fixed_budget = getenv("HLMI_SUBRUN_MBASES") != nullptr;
@@ -220,14 +224,20 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         in.n_chunks = n_my; in.d_qmz = m.d_qmz; in.qmz_off = m.qmz_off;
         in.n_ranks = m.name_of_rank.size();
         if (m.dT == &m.dQ) in.t_query = sub_tids;     // reads vs themselves: the targets' minimizers are in the query sketch
-        in.max_anchors = (uint64_t)SUBRUN_ANCHORS_MAX;
-        in.max_out_bytes = (uint64_t)(1.5 * SUBRUN_OUT_BYTES);
+        in.max_anchors = (uint64_t)subrun_anchors_max;
+        in.max_out_bytes = (uint64_t)subrun_out_max;
         AvaRows rows;
         const double a0 = stats()["anchors"];
+        // a run that is given up (it may already have aligned its first query batch) leaves no trace in the pass's
+        // counts and kernel timers: bench.py's roofline bytes are computed from them
+        const std::map<std::string, double> stats_before = stats();
+        const size_t timers_before = ktimer_mark();
         ava_device(in, m.opts, rows);
         if (rows.refused_anchors) {           // deeper than the estimate: come back with fewer chunks
             budget_bases = std::max<uint64_t>(1, (uint64_t)(rows.refused_shrink * (double)sub_bases));
             ci -= n_my;
+            stats() = stats_before;
+            ktimer_rollback(timers_before);
             stat_add("subruns_refused", 1);
             continue;
         }
@@ -237,9 +247,9 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         done_anchors += stats()["anchors"] - a0;
         done_out_bytes += (double)ava_out_bytes(rows.n_rows, rows.n_ops);
         if (!fixed_budget && done_anchors > 0) {        // next sub-run: as many target bases as give ~SUBRUN_ANCHORS anchors and
-            const double by_anchors = SUBRUN_ANCHORS * (double)done_bases / done_anchors;      // ~SUBRUN_OUT_BYTES of output
-            const double by_bytes = done_out_bytes > 0 ? SUBRUN_OUT_BYTES * (double)done_bases / done_out_bytes : by_anchors;
-            budget_bases = std::min<uint64_t>(SUBRUN_MAX_BASES, std::max<uint64_t>(4ull << 20, (uint64_t)std::min(by_anchors, by_bytes)));
+            const double by_anchors = subrun_anchors * (double)done_bases / done_anchors;      // ~SUBRUN_OUT_BYTES of output
+            const double by_bytes = done_out_bytes > 0 ? subrun_out * (double)done_bases / done_out_bytes : by_anchors;
+            budget_bases = std::min<uint64_t>(SUBRUN_MAX_BASES, std::max<uint64_t>(subrun_anchors < SUBRUN_ANCHORS || subrun_out < SUBRUN_OUT_BYTES ? 1 : 4ull << 20, (uint64_t)std::min(by_anchors, by_bytes)));
         }
         const double t1 = now_s();
         t_ava += t1 - ts0;

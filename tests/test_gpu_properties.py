@@ -154,6 +154,29 @@ def test_subruns_do_not_change_the_result(workload, monkeypatch):
     assert open(alt).read() == open(out).read()
 
 
+@pytest.mark.parametrize("hook", [("HLMI_SUBRUN_MAX_MANCHORS", "40"), ("HLMI_SUBRUN_MAX_OUT_MB", "12")])
+def test_refused_subrun_is_retried_and_leaves_no_trace(workload, monkeypatch, hook):
+    """A sub-run that turns out deeper than its budget is given up (after the counting pass: too many anchors; after
+    its first query batch: projected output too large) and retried with fewer chunks (csrc/stage.cpp).  The limits are
+    compile-time constants sized for 288 GB; the hooks lower them so that the first sub-run of C2mini is refused.  The
+    output must not change, and the abandoned run must not show in the pass's counts (bench.py's roofline bytes)."""
+    d, fa, reads, out = workload
+    base = d / "base_counts.paf"
+    api.split_reads2(fa, fa, 100, d, base, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    want = api.last_stats()
+    assert want.get("subruns_refused", 0) == 0
+    monkeypatch.setenv(*hook)
+    alt = d / f"refused_{hook[0]}.paf"
+    api.split_reads2(fa, fa, 100, d, alt, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    got = api.last_stats()
+    assert got["subruns_refused"] >= 1 and got["subruns"] >= 2
+    assert open(alt).read() == open(out).read()
+    for k in ("anchors", "pieces", "fixed_points", "align_tasks", "cigar_ops", "ava_rows", "rows_after_v4", "snp_events"):
+        assert got[k] == want[k], (k, got[k], want[k])
+    # one timer per launch that counted: as many chain launches as the kept sub-runs had query batches
+    assert got["kernel_launches.chain"] >= got["subruns"]
+
+
 def test_sketch_in_parts_changes_nothing(tmp_path, monkeypatch):
     """Read sets of more than 3 Gbases (BASELINE configs[3]: 10 Gbases of long reads) are sketched in parts of consecutive
     reads; HLMI_SKETCH_PART_MBASES forces parts of a megabase here, on the single-GPU path and on a rank's slice."""
