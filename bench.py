@@ -2,7 +2,9 @@
 """bench.py - long-read all-vs-all overlaps/sec of the hot path on synthetic reads (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W [--workload C3|C2|...]
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: bench.py starts its N rank processes itself (one per GPU, before any GPU call: hylight_amd/launch.py); under an
+    external launcher (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...) it uses the ranks
+    it was given.
 
 Workload at N=1 = the configuration BASELINE.json's metric is quoted on (north_star: "synthetic 100k-long-read
 ava"): C3 = configs[2], 100 000 synthetic ONT reads, mean 10 kb, 20 strains x 1 Mb, --nsplit 200, with the stage
@@ -170,30 +172,30 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
+    from hylight_amd import launch
+    if args.gpus > 1 and not launch.launched():
+        # one process per GPU, started here before anything has touched the GPU (this process never does); a rank that
+        # fails ends the run with its status
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]))
+
     import torch
     import torch.distributed as dist
     from hylight_amd import api
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = launch.rank_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # one rank per GPU; HL_BENCH_BACKEND=gloo lets several ranks share a card (the 1-GPU rehearsal of the N > 1 flow:
-    # RCCL wants one device per rank)
-    backend = os.environ.get("HL_BENCH_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
+    # one rank per GPU; HL_BACKEND=gloo (HL_BENCH_BACKEND: older name) lets several ranks share a card (the 1-GPU
+    # rehearsal of the N > 1 flow: RCCL wants one device per rank)
+    backend = os.environ.get("HL_BACKEND") or os.environ.get("HL_BENCH_BACKEND") or "nccl"
+    n_dev = torch.cuda.device_count()                   # (counting does not initialise the GPU)
     if backend == "nccl" and world > max(n_dev, 1):
         raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {n_dev}")
     dev_id = local % max(n_dev, 1)
     torch.cuda.set_device(dev_id)
     api.init(dev_id, 0)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
-        else:
-            dist.init_process_group(backend)
-        assert dist.get_world_size() == world and dist.get_rank() == rank
+    launch.init_process_group(dev_id, backend)
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     cfg = W.config(args.workload, args.scale)
@@ -310,6 +312,8 @@ def main():
     pass_s = (sum(step_s[-pass_steps:]) / min(pass_steps, len(step_s))) * pass_steps
     pass_rows = rows / args.steps * pass_steps          # all ranks, per complete pass
     line = dict(metric="long-read all-vs-all overlaps/sec", value=value, unit="overlaps/s", n_gpus=world,
+                rccl_ranks=rccl_ranks, backend=(backend if world > 1 else None),
+                launcher=(os.environ.get("HL_LAUNCHER", "external") if world > 1 else None),
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                 scaling="weak" if slices > 1 else "strong", vs_baseline=None, dtype="u8/int32", data="synthetic",
                 config=dict(workload=W.describe(cfg), nsplit=cfg["nsplit"],

@@ -9,9 +9,16 @@ failing tool stops the run with a message.  The two short-read overlap calls of 
 run in the library's short mode.  `extend_con` (HyLight.py:282-326) is wired up to the SAVAGE overlap file: contigs ->
 contigs_b.fastq -> self-overlaps (the `minimap2 --sr -X ... -r 0` call as hlmi_ava) -> v3 window filter with -sfo ->
 sfo2overlaps; the consumers of that file - short-read clustering, POLYTE and the stage-b contig merge
-(pipeline_per_stage.py / ViralQuasispecies) - are outside this implementation (SURVEY.md sections 2 and 8f): the run
-says so on stderr and exits 0 with everything up to tmp/stageb/sfoverlap.out.savage in place.  The text passes
-(filter_non_atcg, gfa2fa, pick_up) are the library's native ones.
+(pipeline_per_stage.py / ViralQuasispecies) - are outside this implementation (SURVEY.md sections 2 and 8f): without
+`--stageb_cmd` the run says so on stderr and, because the contractual output final_contigs.fa was not written, exits
+with EXIT_NO_FINAL (3) and everything up to tmp/stageb/sfoverlap.out.savage in place (`--stop_after savage` declares
+that partial run and exits 0).  The text passes (filter_non_atcg, gfa2fa, pick_up) are the library's native ones.
+
+`--gpus N` (extension): every split_reads2 call is sharded over N GPUs of the node, chunk i -> rank i % N, the way the
+reference fans its chunks out with `xargs -P` (script/utils.py:44-69).  The process starts N - 1 further copies of
+itself before it touches the GPU (hylight_amd/launch.py); rank 0 runs the pipeline (text passes, graph builds, external
+tools, merges), the other ranks only take part in the stage calls (stage.py:StagePool).  Started under torchrun
+(RANK / WORLD_SIZE in the environment) it uses the ranks it was given.
 """
 from __future__ import annotations
 
@@ -22,10 +29,15 @@ import subprocess
 import sys
 import time
 
-from . import api
-from .stage import StageRunner
+from . import api, launch
+from .stage import StagePool
 
 __version__ = "1.0.1-mi355x"
+EXIT_NO_FINAL = 3        # everything this implementation covers ran, but final_contigs.fa (the stage-b merge) was not written
+
+# test hook (tests/test_multirank_gloo.py): (job_factory, device) replacing api.Job on "cuda" - the CPU tests of the
+# N > 1 control flow run the driver over gloo with an oracle-backed job
+TEST_BACKEND = None
 
 
 def fq_or_fa(path):
@@ -144,9 +156,11 @@ def build_parser():
     p.add_argument("--insert_size", dest="insert_size", default=450, type=int)
     p.add_argument("--average_read_len", dest="average_read_len", default=250, type=int)
     p.add_argument("--version", "-v", action="version", version="%(prog)s version: " + __version__)
-    p.add_argument("--stop_after", choices=["overlap", "contigs1", "polish"], default=None,
-                   help="(extension) stop after the named long-read stage")
-    p.add_argument("--device", type=int, default=0, help="(extension) GPU index")
+    p.add_argument("--stop_after", choices=["overlap", "contigs1", "polish", "savage"], default=None,
+                   help="(extension) stop after the named stage (savage: the contig overlap file of extend_con)")
+    p.add_argument("--device", type=int, default=0, help="(extension) GPU index of a single-GPU run")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="(extension) shard every overlap stage over this many GPUs of the node (one process per GPU)")
     p.add_argument("--short_contigs", default=None,
                    help="(extension) contigs of the short-read branch (POLYTE, run elsewhere) to merge with the long-read contigs")
     p.add_argument("--stageb_cmd", default=None,
@@ -154,18 +168,43 @@ def build_parser():
     return p
 
 
-def stage(fa, ref, nsplit, out_file, len_over, mc, iden, long=True):
-    r = StageRunner(fa, ref, nsplit, long_mode=long)
-    try:
-        r.run(out_file, len_over, mc, iden)
-    finally:
-        r.close()
-    return out_file
-
-
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
-    api.init(args.device, args.threads)
+    if args.gpus > 1 and not launch.launched():
+        # one process per GPU, started before this one has made any GPU call; this process only waits for them
+        return launch.spawn_ranks(args.gpus, [sys.executable, "-m", "hylight_amd.driver", *argv])
+    rank, world, local = launch.rank_env()
+    if launch.launched() and args.gpus not in (1, world):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if TEST_BACKEND is None:
+        import torch
+        n_dev = torch.cuda.device_count()                     # (counting devices does not initialise the GPU)
+        dev = args.device if world == 1 else local % max(n_dev, 1)
+        torch.cuda.set_device(dev)
+        api.init(dev, args.threads)
+        launch.init_process_group(dev)
+        pool = StagePool(rank, world)
+    else:
+        launch.init_process_group(backend="gloo")
+        pool = StagePool(rank, world, job_factory=TEST_BACKEND[0], device=TEST_BACKEND[1])
+    try:
+        if rank != 0:
+            pool.serve()
+            return 0
+        return _pipeline(args, pool)
+    finally:
+        pool.shutdown()
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def _pipeline(args, pool):
+    """The run itself (rank 0).  `pool.stage` = utils.split_reads2 on every rank."""
+    def stage(fa, ref, nsplit, out_file, len_over, mc, iden, long=True):
+        return pool.stage(fa, ref, nsplit, out_file, len_over, mc, iden, long)
+
     outdir, nsplit, iden = args.outdir, args.nsplit, args.min_identity
     len_over, max_tip = args.min_ovlp_len, args.max_tip_len
     long_reads = os.path.abspath(args.long_reads)
@@ -253,11 +292,14 @@ def main(argv=None):
             with open(p) as f:
                 shutil.copyfileobj(f, o)
     final = os.path.join(outdir, "final_contigs.fa")
-    n_con = extend_con(all_con, tmp, final, threads=30, stageb_cmd=args.stageb_cmd)
-    if not args.stageb_cmd:
+    n_con = extend_con(all_con, tmp, final, threads=30, stageb_cmd=None if args.stop_after == "savage" else args.stageb_cmd)
+    if args.stop_after == "savage":
+        return 0
+    if not os.path.exists(final):
         sys.stderr.write(f"hylight-mi: {n_con} contigs, their overlaps are in tmp/stageb/sfoverlap.out.savage; the stage-b merge "
                          "(pipeline_per_stage.py / ViralQuasispecies, HyLight.py:320-324) is not built here, so "
-                         "final_contigs.fa was not written (pass --stageb_cmd to run the reference's)\n")
+                         f"final_contigs.fa was not written (pass --stageb_cmd to run the reference's): exit status {EXIT_NO_FINAL}\n")
+        return EXIT_NO_FINAL
     return 0
 
 

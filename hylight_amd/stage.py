@@ -124,6 +124,66 @@ class StageRunner:
         return rows
 
 
+class StagePool:
+    """Every split_reads2 call of a run on the N ranks of a node (the reference: `xargs -i -P threads` per call,
+    script/utils.py:65).  Rank 0 drives the pipeline and calls `stage()`; the other ranks sit in `serve()` and take part
+    in every stage call they are told about (the call's arguments are broadcast): each rank opens the same files, sketches
+    its slice of the reads, runs its chunks (chunk i -> rank i % N), rank 0 merges.  With one rank this is a plain call."""
+
+    def __init__(self, rank=0, world=1, group=None, job_factory=None, device="cuda"):
+        """`job_factory(reads_fa, ref_fa, nsplit, long_mode)` / `device` exist for the CPU (gloo) tests, as in
+        StageRunner: the product always runs api.Job on "cuda"."""
+        self.rank, self.world, self.group = rank, world, group
+        self.job_factory, self.device = job_factory, device
+        self.calls = 0
+        self.broken = False          # a stage call failed on this rank: the other ranks are inside collectives, not in serve()
+
+    def _tell(self, msg):
+        import torch.distributed as dist
+        obj = [msg]
+        dist.broadcast_object_list(obj, src=0, group=self.group)
+        return obj[0]
+
+    def _run(self, fa, ref, nsplit, out_file, len_over, mc, iden, long):
+        job = self.job_factory(fa, ref, nsplit, long) if self.job_factory else None
+        r = StageRunner(fa, ref, nsplit, long_mode=long, rank=self.rank, world=self.world, group=self.group, job=job,
+                        device=self.device)
+        try:
+            n = r.run(out_file, len_over, mc, iden)
+        except BaseException:
+            self.broken = True
+            raise
+        finally:
+            r.close()
+        self.calls += 1
+        return n
+
+    def stage(self, fa, ref, nsplit, out_file, len_over, mc, iden, long=True):
+        """split_reads2 on all ranks; called on rank 0 only.  Returns out_file."""
+        if self.rank != 0:
+            raise RuntimeError("StagePool.stage is called on rank 0; the other ranks run serve()")
+        args = (os.fspath(fa), os.fspath(ref), int(nsplit), os.fspath(out_file), int(len_over), int(mc), float(iden), bool(long))
+        if self.world > 1:
+            self._tell(("stage",) + args)
+        self._run(*args)
+        return out_file
+
+    def serve(self):
+        """Ranks 1..N-1: take part in the stage calls rank 0 announces until it says "exit".  Returns the number of
+        calls served."""
+        while True:
+            msg = self._tell(None)
+            if msg[0] == "exit":
+                return self.calls
+            self._run(*msg[1:])
+
+    def shutdown(self):
+        """Rank 0, at the end of the run: releases the other ranks.  After a failed stage call nothing is sent (the
+        other ranks are not listening): this process then exits non-zero and the launcher ends them."""
+        if self.world > 1 and self.rank == 0 and not self.broken:
+            self._tell(("exit",))
+
+
 def split_reads2(fa, ref, nsplit, out_dir, out_file, bin=None, threads=30, len_over=3000, mc=2, iden=0.95,
                  long=False):
     """Drop-in for utils.split_reads2 (script/utils.py:41): same arguments, same return value."""

@@ -50,3 +50,43 @@ def test_two_ranks_on_one_gpu_match_the_single_rank_result(tmp_path):
     two = tmp_path / "two.paf"
     mp.spawn(_worker, args=(2, port, str(fa), str(two)), nprocs=2, join=True)
     assert open(two).read() == open(one).read()
+
+
+def test_driver_with_two_self_started_ranks_matches_the_single_gpu_run(tmp_path):
+    """`python -m hylight_amd.driver --gpus 2`: the process starts its two ranks itself (hylight_amd/launch.py), rank 0
+    runs the pipeline, rank 1 serves the stage calls; both share this box's one card, so the exchange goes over gloo
+    (HL_BACKEND).  The output tree up to contigs1.fa must equal the --gpus 1 run byte for byte."""
+    import subprocess
+    from hylight_amd import simulate as S
+    reads, _ = S.simulate_reads(seed=81, n_strains=2, genome_len=40000, n_reads=110, mean_len=9000, min_len=7000,
+                                max_len=14000)
+    fq = tmp_path / "long.fq"
+    S.write_fastq(reads, fq)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    outs = {}
+    for n in (1, 2):
+        out = tmp_path / f"OUT{n}"
+        r = subprocess.run([sys.executable, "-m", "hylight_amd.driver", "-l", str(fq), "-o", str(out), "--corrected", "--nsplit", "3",
+                            "-t", "4", "--stop_after", "contigs1", "--gpus", str(n)], env=dict(env, HL_BACKEND="gloo"),
+                           capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[n] = out
+    for rel in ("1.split_fastx/s1.fa", "2.overlap/s1_s1.paf", "tmp/contigs1.gfa", "tmp/contigs1.fa"):
+        a, b = (outs[1] / rel).read_bytes(), (outs[2] / rel).read_bytes()
+        assert a == b and len(a) > 0, rel
+    assert (outs[2] / "2.overlap" / "s1_s1.paf").read_text().count("\n") > 50
+
+
+def test_bench_starts_two_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: two ranks on this one card over gloo, a tenth of C2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C2",
+                        "--scale", "0.1", "--no-cpu-baseline"], env=dict(env, HL_BACKEND="gloo", HL_BENCH_DIR=str(tmp_path)),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["launcher"] == "self" and line["backend"] == "gloo"
+    assert line["value"] > 0 and line["config"]["overlaps_out"] > 0
