@@ -53,6 +53,7 @@ hlmi_ava_opts ava_opts_long() {
     o.match = 2; o.mismatch = 4; o.gap_open = 4; o.gap_ext = 2; o.ambi = 1;
     o.min_dp_score = 80; o.end_bonus = 0; o.pair_once = 1;
     o.gap_open2 = 24; o.gap_ext2 = 1;          // -O4,24 -E2,1: the preset's two-piece gap cost
+    o.stub_oh = -1;                            // every piece extended (the stage sets the bound of its v4 filter)
     return o;
 }
 
@@ -67,6 +68,7 @@ hlmi_ava_opts ava_opts_short() {
     o.match = 4; o.mismatch = 2; o.gap_open = 12; o.gap_ext = 2; o.ambi = 1;
     o.min_dp_score = 60; o.end_bonus = 100; o.pair_once = 0;
     o.gap_open2 = 32; o.gap_ext2 = 1;          // --sr: -O12,32 -E2,1
+    o.stub_oh = -1;
     return o;
 }
 

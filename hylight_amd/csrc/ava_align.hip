@@ -65,7 +65,9 @@ struct TaskRef { uint32_t pk, fp; };       // piece | kind << 30; block k: fixed
 struct PieceGeom {                         // 32 B
     uint64_t qo, to;                       // first base of the query / target in the code arrays
     uint32_t ql, tl;
-    uint32_t strand, pad;
+    uint32_t strand;
+    uint32_t stub_cand;                    // 1: one end lies so far inside both sequences that no end extension can bring the
+                                           // piece's overhang down to the consumer's bound (stub rule, see align_span)
 };
 struct TaskGeom {
     const TaskRef *ref;
@@ -104,7 +106,7 @@ __device__ __forceinline__ Task build_task(const PieceGeom &p, uint32_t piece, u
 // references of the tasks of every piece and the piece's geometry (one wave per piece)
 __global__ __launch_bounds__(WG) void task_ref_kernel(const Piece *pieces, const uint32_t *task_off, size_t n, const uint32_t *qlen,
                                                        const uint32_t *tlen, const uint64_t *qoff, const uint64_t *toff,
-                                                       TaskRef *task_ref, PieceGeom *pg) {
+                                                       const FixPt *fps, int stub_oh, TaskRef *task_ref, PieceGeom *pg) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -116,7 +118,16 @@ __global__ __launch_bounds__(WG) void task_ref_kernel(const Piece *pieces, const
             const uint32_t kind = k == 0 ? 1u : (k == p.n_fp ? 2u : 0u);
             out[k] = TaskRef{(uint32_t)i | kind << 30, p.fp_off + (k == 0 ? 0u : k - 1)};
         }
-        if (lane == 0) pg[i] = PieceGeom{qoff[p.q], toff[p.t], qlen[p.q], tlen[p.t], p.strand, 0};
+        if (lane == 0) {
+            const uint32_t ql = qlen[p.q], tl = tlen[p.t];
+            uint32_t cand = 0;
+            if (stub_oh >= 0) {          // (oracle/ava_oracle.c:is_stub - the geometric half of the rule)
+                const FixPt a = fps[p.fp_off], b = fps[p.fp_off + p.n_fp - 1];
+                const uint32_t dq = (uint32_t)(EXT_MAX + stub_oh), dt = (uint32_t)(EXT_MAX + BAND_W + stub_oh);
+                cand = ((a.q > dq && a.t > dt) || (ql - b.q > dq && tl - b.t > dt)) ? 1u : 0u;
+            }
+            pg[i] = PieceGeom{qoff[p.q], toff[p.t], ql, tl, p.strand, cand};
+        }
     }
 }
 
@@ -217,7 +228,7 @@ __device__ __forceinline__ uint32_t load_window4p(const uint8_t *codes, long lon
 
 // stats[]: 0 bases (Lq + Lt) of all tasks, 1 of the square blocks compared here, 2 of the narrow DP tasks, 3 of the
 // wide DP tasks, 4 tasks finished on the diagonal fast path, 5 DP tasks, 6 DP rows
-enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, N_ALIGN_STATS };
+enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, N_ALIGN_STATS };
 constexpr int NR_SMALL = 64;                    // narrow tasks with fewer rows than this run in the instance with half the plane LDS
 
 // 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
-    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
+    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
     const size_t n_units = PASS == 1 ? a.n_tasks : (size_t)*a.defer_count;
     const size_t rounds = (n_units + n_thr - 1) / n_thr;              // uniform trip count: the allocation is per wave
     // the reference of a task (PASS 2: its index in the list) is fetched a round ahead
@@ -292,9 +303,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             else if (un < n_units) ti_n = a.defer_list[un];
         }
         Task tk{};
+        bool held = false;           // end extension of a stub candidate: decided after the piece's blocks are scored
         if (live) {
             const uint32_t pc = ref.pk & 0x3fffffffu, kind = ref.pk >> 30;
             const PieceGeom pg = a.geom.pg[pc];
+            held = PASS == 1 && kind != 0 && pg.stub_cand != 0;
             const FixPt f0 = a.geom.fps[ref.fp];
             FixPt f1{0, 0};
             if (kind == 0) f1 = a.geom.fps[ref.fp + 1];
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         uint8_t c = 2;
         bool try_fast = false;
         if (live) {
-            if (m <= 0 || n <= 0) c = 0;
+            if (m <= 0 || n <= 0 || held) c = 0;
             else if ((tk.kind & 3) == 0) { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
             if (c == 2 && (m < n - tk.dlo ? m : n - tk.dlo) <= WIDE_SHORT) c = 4;      // rows the 64-diagonal kernel really runs
         }
@@ -625,7 +638,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         if (live) {
             cls[ti] = c;
             if (c != 0) a.tasks[ti] = tk;                      // a DP kernel will want the record
-            if (m > 0 && n > 0) {
+            if (held) ++st[ST_STUB_EXT];
+            else if (m > 0 && n > 0) {
                 const uint32_t bases = (uint32_t)(m + n);
                 st[ST_BASES] += bases;
                 if ((tk.kind & 3) == 0 && m == n) st[ST_BASES_SQUARE] += bases;
@@ -1388,6 +1402,11 @@ struct AsmArgs {
     size_t n_pieces;
     const uint32_t *qlen, *tlen, *rank_q, *rank_t, *chunk_of_t;
     int min_dp_score, end_bonus;
+    // counting pass only -----------------------------------------------------------------------------------------------
+    const uint32_t *plist;      // pieces to count (n_pieces of them); null: all
+    const PieceGeom *pg;        // stub rule: with `late` set, a stub candidate (pg[i].stub_cand) whose blocks alone do not reach
+    uint8_t *late;              // stub_score is flagged here - its end extensions, held back so far, have to run after all
+    int stub_score;
 };
 
 // One wavefront per piece, one lane per task (64 tasks per step).  The row's CIGAR is the concatenation of the
@@ -1402,7 +1421,8 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t i = wave; i < a.n_pieces; i += n_waves) {
+    for (size_t idx = wave; idx < a.n_pieces; idx += n_waves) {
+        const size_t i = !WRITE && a.plist ? (size_t)a.plist[idx] : idx;
         if (WRITE && !valid[i]) continue;
         const Piece p = a.pieces[i];
         const FixPt *fp = a.fps + p.fp_off;
@@ -1466,6 +1486,8 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                 const bool ok = slots > 0 && score >= a.min_dp_score;
                 valid[i] = ok ? 1 : 0;
                 n_ops[i] = ok ? slots : 0;
+                // (the extensions of a stub candidate have not run: `score` is the score of its blocks)
+                if (a.late) a.late[i] = a.pg[i].stub_cand && !(slots > 0 && score >= a.stub_score) ? 1 : 0;
             }
             continue;
         }
@@ -1490,6 +1512,18 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
             ord_lo[i] = (uint64_t)p.t << 43 | (uint64_t)p.strand << 42 | (uint64_t)(p.chain & 0x3fffffu) << 20 | (p.piece & 0xfffffu);
         }
     }
+}
+
+// the two end extensions of every listed piece, as task ids (stub rule: pieces whose extensions were held back and are
+// needed after all)
+__global__ void late_tasks_kernel(const uint32_t *plist, size_t n, const Piece *pieces, const uint32_t *task_off, uint32_t *tasks,
+                                  uint32_t *count) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j == 0) *count = (uint32_t)(2 * n);
+    if (j >= n) return;
+    const uint32_t i = plist[j];
+    tasks[2 * j] = task_off[i];
+    tasks[2 * j + 1] = task_off[i] + pieces[i].n_fp;
 }
 
 __global__ void compact_rows_kernel(const uint32_t *idx, size_t n, const PafRec *recs, const uint64_t *hi,
@@ -1518,7 +1552,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     DBuf<TaskRef> task_ref(NT);
     DBuf<PieceGeom> pgeom(P);
     hipLaunchKernelGGL(task_ref_kernel, dim3((unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
-                       ch.pieces.p, toff.p, P, d_qlen, d_tlen, in.Q->off.p, in.T->off.p, task_ref.p, pgeom.p);
+                       ch.pieces.p, toff.p, P, d_qlen, d_tlen, in.Q->off.p, in.T->off.p, ch.fps.p, o.stub_oh, task_ref.p, pgeom.p);
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
     DBuf<uint32_t> counters(2);
@@ -1532,6 +1566,16 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                                (size_t)2 * 256 * 32 * 8 * PK_WAVES * RUN_CHUNK_SMALL;  // (two packed launches: 8 allocating lanes per wave)
     size_t run_share = std::max<size_t>(NT * 12, 1 << 16);
     DBuf<uint32_t> runs;
+    AsmArgs as{};
+    as.pieces = ch.pieces.p; as.fps = ch.fps.p; as.task_off = toff.p; as.tout = tout.p; as.n_pieces = P;
+    as.min_dp_score = o.min_dp_score; as.end_bonus = o.end_bonus;
+    as.qlen = d_qlen; as.tlen = d_tlen; as.rank_q = in.d_rank_q; as.rank_t = in.d_rank_t; as.chunk_of_t = in.d_chunk_of_t;
+    as.pg = pgeom.p; as.stub_score = o.min_dp_score + std::max(0, o.end_bonus);
+    DBuf<uint32_t> nops(P);
+    DBuf<uint8_t> valid(P), late(o.stub_oh >= 0 ? P : 0);
+    DBuf<uint32_t> late_idx(o.stub_oh >= 0 ? P : 0);
+    size_t n_late = 0;
+    const unsigned nba = (unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32);
     for (int attempt = 0;; ++attempt) {
         const size_t cap_runs = run_share + open_chunks;
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
@@ -1564,6 +1608,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         aa.trim_ok = getenv("HLMI_NO_SUFFIX_TRIM") ? 0 : 1;
         aa.one_ok = getenv("HLMI_NO_ONE_PIECE_CERT") ? 0 : 1;
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
+        as.runs = runs.p;
         aa.run_buf_cap = 0xffffffffu;
         if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
         // pass 1: classify every task, finish the diagonal fast path right away
@@ -1628,19 +1673,61 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             hipLaunchKernelGGL(align_narrow_kernel<BLOCK_MAX>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
         // pass 2b: the rest (wide blocks, end extensions) in the 64-diagonal band
-        if (n2) {
-            KTimer kt("align_wide");
-            aa.list = list2.p; aa.n_list = n2;
-            const unsigned nb = (unsigned)std::min<size_t>((n2 + WAVES - 1) / WAVES, 256 * 16);
-            hipLaunchKernelGGL(align_kernel<EXT_MAX>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+        auto run_wide = [&](size_t n_long, size_t n_short) {
+            if (n_long) {
+                KTimer kt("align_wide");
+                aa.list = list2.p; aa.n_list = n_long;
+                const unsigned nb = (unsigned)std::min<size_t>((n_long + WAVES - 1) / WAVES, 256 * 16);
+                hipLaunchKernelGGL(align_kernel<EXT_MAX>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+            }
+            if (n_short) {
+                KTimer kt("align_wide_short");
+                aa.list = list4.p; aa.n_list = n_short;
+                const unsigned nb = (unsigned)std::min<size_t>((n_short + WAVES - 1) / WAVES, 256 * 16);
+                hipLaunchKernelGGL(align_kernel<WIDE_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
+            }
+        };
+        run_wide(n2, n4);
+        size_t n_wide_late = 0;
+        if (o.stub_oh >= 0) {
+            // Stub rule (hlmi_ava_opts::stub_oh; proof at oracle/ava_oracle.c:is_stub).  The end extensions of the stub
+            // candidates were held back.  Their blocks are scored now: a candidate that is certain to be reported without them
+            // (blocks >= min_dp_score + end_bonus: an extension adds a positive score, or at least 1 - end_bonus when it
+            // reaches the query end) stays without - its row can only be dropped by the consumer's overhang test; the others
+            // get their extensions in a second round.
+            as.plist = nullptr; as.n_pieces = P; as.late = late.p;
+            {
+                KTimer kt("assemble_count");
+                hipLaunchKernelGGL(assemble_kernel<false>, dim3(nba), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
+                                   nullptr, nullptr, nullptr);
+            }
+            as.late = nullptr;
+            n_late = select_flagged_indices(late.p, late_idx.p, P);
+            if (n_late) {
+                hipLaunchKernelGGL(late_tasks_kernel, grid1(n_late), dim3(WG), 0, stream(), late_idx.p, n_late, ch.pieces.p, toff.p,
+                                   list1.p, list_n.p);
+                HIP_CHECK(hipMemsetAsync(cls.p, 0, NT, stream()));
+                {
+                    KTimer kt("align_classify");
+                    aa.defer_list = list1.p; aa.defer_count = list_n.p;
+                    const unsigned nb2 = (unsigned)std::min<size_t>(cdiv(2 * n_late, (size_t)WG), MAX_BLOCKS);
+                    hipLaunchKernelGGL(classify_kernel<2>, dim3(nb2 ? nb2 : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
+                }
+                select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
+                const std::vector<uint32_t> hl = list_n.download(4);
+                run_wide(hl[1], hl[3]);
+                n_wide_late = (size_t)hl[1] + hl[3];
+                as.plist = late_idx.p; as.n_pieces = n_late;
+                const unsigned nbl = (unsigned)std::min<size_t>(cdiv(n_late, (size_t)WAVES), 256 * 32);
+                {
+                    KTimer kt("assemble_count");
+                    hipLaunchKernelGGL(assemble_kernel<false>, dim3(nbl), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
+                                       nullptr, nullptr, nullptr);
+                }
+                as.plist = nullptr; as.n_pieces = P;
+            }
         }
-        if (n4) {
-            KTimer kt("align_wide_short");
-            aa.list = list4.p; aa.n_list = n4;
-            const unsigned nb = (unsigned)std::min<size_t>((n4 + WAVES - 1) / WAVES, 256 * 16);
-            hipLaunchKernelGGL(align_kernel<WIDE_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
-        }
-        if (attempt == 0) { stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)(n2 + n4)); }
+        if (attempt == 0) { stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)(n2 + n4 + n_wide_late)); }
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> hc = counters.download(2);
         if (!hc[1]) break;
@@ -1658,16 +1745,11 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         stat_add("align_bases_narrow", (double)h[ST_BASES_NARROW]);
         stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
         stat_add("align_tasks_wide_one_piece", (double)h[ST_WIDE_ONE]);
+        stat_add("align_ext_held", (double)h[ST_STUB_EXT]);            // end extensions of stub candidates ...
+        stat_add("align_ext_late", (double)(2 * n_late));              // ... of which these had to run after all
     }
     // assemble
-    AsmArgs as{};
-    as.pieces = ch.pieces.p; as.fps = ch.fps.p; as.task_off = toff.p; as.tout = tout.p; as.runs = runs.p; as.n_pieces = P;
-    as.min_dp_score = o.min_dp_score; as.end_bonus = o.end_bonus;
-    as.qlen = d_qlen; as.tlen = d_tlen; as.rank_q = in.d_rank_q; as.rank_t = in.d_rank_t; as.chunk_of_t = in.d_chunk_of_t;
-    DBuf<uint32_t> nops(P);
-    DBuf<uint8_t> valid(P);
-    const unsigned nba = (unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32);
-    {
+    if (o.stub_oh < 0) {
         KTimer kt("assemble_count");
         hipLaunchKernelGGL(assemble_kernel<false>, dim3(nba), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
                            nullptr, nullptr, nullptr);

@@ -43,6 +43,9 @@ Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode)
     Impl &m = *impl_;
     m.long_mode = long_mode;
     m.opts = long_mode ? ava_opts_long() : ava_opts_short();   // filter_overlap_slr2.py:51 / :55
+    // both command lines pipe the rows into `filter_trans_ovlp_inline_v4.py -len 30 -oh 3`: pieces that are certain to
+    // fail its overhang test are reported without end extensions (hlmi_ava_opts::stub_oh; HLMI_NO_STUB: test hook)
+    m.opts.stub_oh = getenv("HLMI_NO_STUB") ? -1 : FilterCfg().v4_min_o;
     read_seqs(reads_fa, m.Q);
     const bool same = std::string(reads_fa) == ref_fa;
     if (!same) read_seqs(ref_fa, m.T);

@@ -113,6 +113,13 @@ typedef struct {
                                   gap_ext2 L): 24, 1 (long: the preset's -O4,24 -E2,1), 32, 1 (short: --sr's -O12,32 -E2,1);
                                   gap_open2 <= 0: one piece.  The second piece must not be the cheaper one for gaps of
                                   fewer than 16 bases (the 16-diagonal kernels work with the first piece alone). */
+    int stub_oh;           /* >= 0: the rows go to a consumer that drops internal matches with this overhang bound
+                              (filter_trans_ovlp_inline_v4.py:52-64 with -oh 3, slr2:51,55).  An alignment piece that is
+                              certain to be reported (block score >= min_dp_score + end_bonus) and certain to fail that test
+                              whatever its end extensions find (an end more than 256 + stub_oh query and 320 + stub_oh target
+                              bases inside both sequences) is then reported WITHOUT end extensions: the consumer only counts
+                              it as a line of its 1000-line windows.  < 0: every piece is extended (hlmi_ava's default; the
+                              stage entry points use 3). */
 } hlmi_ava_opts;
 void hlmi_ava_opts_long(hlmi_ava_opts *o);    /* the constants of slr2:51 (ava-pb -Hk19 -m100 -g10000) */
 void hlmi_ava_opts_short(hlmi_ava_opts *o);   /* the constants of slr2:55 (--sr -k21 -w11 -s60 -m30 -n2 -A4 -B2 --end-bonus=100) */

@@ -24,6 +24,9 @@ typedef struct {
     int match, mismatch, gap_open, gap_ext, ambi;
     int min_dp_score, end_bonus, pair_once;
     int gap_open2, gap_ext2;   /* second piece of the gap cost: a gap of L bases costs min(open + ext L, open2 + ext2 L); open2 <= 0: one piece */
+    int stub_oh;               /* >= 0: the rows go to a consumer that drops internal matches with this overhang bound
+                                * (filter_trans_ovlp_inline_v4.py:64, -oh 3): pieces that are certain to be reported and certain
+                                * to be dropped there are written without their end extensions; < 0: off */
 } ava_opts_t;   /* same layout as hlmi_ava_opts (include/hylight_mi.h) */
 
 /* ---- fixed constants of the spec -------------------------------------------- */
@@ -38,6 +41,24 @@ typedef struct {
 #define EXT_MAX      256     /* max rows of an end extension                                */
 #define MAX_MID_OCC  1000000
 #define NEG_INF      (-(1 << 29))
+
+/* MEASUREMENT switches (tests/test_deviation_effects.py only; the specification is the defaults): how many final rows do
+ * the bounded blocks and extensions change on divergent reads?  minimap2 fills gaps between anchors and extends chain
+ * ends with a band derived from -r and stops at a z-drop; the specification bounds both so that a task fits LDS.
+ *   ORACLE_BLOCK_MAX   rows / cols of one alignment block (256)
+ *   ORACLE_SHIFT_MAX   diagonal shift of one block (BAND_W - 2 BAND_PAD - 1 = 39); wider blocks get a band of shift + 2 pad + 1
+ *   ORACLE_EXT_MAX     rows of an end extension (256)
+ *   ORACLE_EXT_BAND    diagonals of an end extension (64)
+ */
+static int g_block_max = BLOCK_MAX, g_shift_max = BAND_W - 2 * BAND_PAD - 1, g_ext_max = EXT_MAX, g_ext_band = BAND_W;
+static long g_n_pieces, g_n_stubs;      /* pieces reported / of them as stubs (oracle_last_counts) */
+static void read_switches(void) {
+    const char *e;
+    g_block_max = (e = getenv("ORACLE_BLOCK_MAX")) ? atoi(e) : BLOCK_MAX;
+    g_shift_max = (e = getenv("ORACLE_SHIFT_MAX")) ? atoi(e) : BAND_W - 2 * BAND_PAD - 1;
+    g_ext_max = (e = getenv("ORACLE_EXT_MAX")) ? atoi(e) : EXT_MAX;
+    g_ext_band = (e = getenv("ORACLE_EXT_BAND")) ? atoi(e) : BAND_W;
+}
 
 /* ---- sequences ---------------------------------------------------------------------------- */
 typedef struct {
@@ -404,8 +425,8 @@ typedef struct {
 /* global block between fixed points (q0,t0) -> (q1,t1); returns 0 if it violates the block limits */
 static int block_ok(int q0, int t0, int q1, int t1) {
     int m = q1 - q0, n = t1 - t0, delta = n - m;
-    if (m < 0 || n < 0 || m > BLOCK_MAX || n > BLOCK_MAX) return 0;
-    if ((delta < 0 ? -delta : delta) + 2 * BAND_PAD + 1 > BAND_W) return 0;
+    if (m < 0 || n < 0 || m > g_block_max || n > g_block_max) return 0;
+    if ((delta < 0 ? -delta : delta) > g_shift_max) return 0;
     return 1;
 }
 
@@ -415,6 +436,7 @@ static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t,
     /* band rule: near-diagonal blocks get the narrow band, the rest the wide one */
     int narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
     int W = narrow ? NARROW_W : BAND_W;
+    if (!narrow && (delta < 0 ? -delta : delta) + 2 * BAND_PAD + 1 > W) W = (delta < 0 ? -delta : delta) + 2 * BAND_PAD + 1;   /* measurement only */
     int dlo = (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD);
     p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, W, 0, -1, 0, 0, scratch, &nr);
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
@@ -444,9 +466,9 @@ static void emit_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi
 }
 
 static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, piece_t *p, uint32_t *scratch) {
-    int m = p->qs < EXT_MAX ? p->qs : EXT_MAX, n = p->ts < EXT_MAX + BAND_W ? p->ts : EXT_MAX + BAND_W, bi, bj, nr;
+    int m = p->qs < g_ext_max ? p->qs : g_ext_max, n = p->ts < g_ext_max + g_ext_band ? p->ts : g_ext_max + g_ext_band, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(BAND_W / 2 - 1), BAND_W, 1, p->qs <= EXT_MAX ? p->qs : -1,
+    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(g_ext_band / 2 - 1), g_ext_band, 1, p->qs <= g_ext_max ? p->qs : -1,
                      &bi, &bj, scratch, &nr);
     if (g_last_rank <= 0 || nr == 0) return;   /* nothing gained (the end bonus counts here, not in the score) */
     /* rev_ops run from the far end towards the fixed point on reversed sequences = forward order */
@@ -460,21 +482,47 @@ static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t,
 
 static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const uint8_t *t, int tl, piece_t *p,
                          uint32_t *scratch) {
-    int m = ql - p->qe < EXT_MAX ? ql - p->qe : EXT_MAX;
-    int n = tl - p->te < EXT_MAX + BAND_W ? tl - p->te : EXT_MAX + BAND_W, bi, bj, nr;
+    int m = ql - p->qe < g_ext_max ? ql - p->qe : g_ext_max;
+    int n = tl - p->te < g_ext_max + g_ext_band ? tl - p->te : g_ext_max + g_ext_band, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(BAND_W / 2 - 1), BAND_W, 1, ql - p->qe <= EXT_MAX ? ql - p->qe : -1,
+    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(g_ext_band / 2 - 1), g_ext_band, 1, ql - p->qe <= g_ext_max ? ql - p->qe : -1,
                      &bi, &bj, scratch, &nr);
     if (g_last_rank <= 0 || nr == 0) return;   /* nothing gained (the end bonus counts here, not in the score) */
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
     p->qe += bi; p->te += bj; p->score += sc;
 }
 
+/* Stub rule (ava_opts_t::stub_oh = h >= 0).  An end extension moves a piece end by at most EXT_MAX query and
+ * EXT_MAX + BAND_W target bases.  A piece whose left end has qs > EXT_MAX + h and ts > EXT_MAX + BAND_W + h (or the same on
+ * its right end, measured from the sequence ends) therefore keeps an overhang > h whatever the extensions find, and the
+ * consumer's test `overhang > min(h, 0.8 maplen)` drops the row before it touches any state.  The row still counts as a
+ * line of the consumer's 1000-line windows, so it has to be written exactly when the full specification writes it:
+ * score >= min_dp_score.  Extensions only add a positive score, except that one reaching the query end may be taken
+ * with a score down to 1 - end_bonus; such an end is not an interior end, so blocks >= min_dp_score + end_bonus
+ * decides "reported" before any extension has run.  Such a piece is written without its end extensions. */
+static int is_stub(const ava_opts_t *o, const piece_t *p, int ql, int tl) {
+    if (o->stub_oh < 0 || g_ext_max != EXT_MAX || g_ext_band != BAND_W) return 0;
+    const int h = o->stub_oh, bonus = o->end_bonus > 0 ? o->end_bonus : 0;
+    if (!p->cg.n || p->score < o->min_dp_score + bonus) return 0;
+    return (p->qs > EXT_MAX + h && p->ts > EXT_MAX + BAND_W + h) || (ql - p->qe > EXT_MAX + h && tl - p->te > EXT_MAX + BAND_W + h);
+}
+
+static void close_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa, const seqset_t *T, int ti,
+                        int strand, piece_t *p, uint32_t *scratch) {
+    const int ql = Q->len[qi], tl = T->len[ti];
+    const int stub = is_stub(o, p, ql, tl);
+    if (!stub) {
+        extend_left(o, qa, T->code[ti], p, scratch);
+        extend_right(o, qa, ql, T->code[ti], tl, p, scratch);
+    }
+    if (p->cg.n && p->score >= o->min_dp_score) { ++g_n_pieces; g_n_stubs += stub; }
+    emit_piece(out, o, Q, qi, T, ti, strand, p);
+}
+
 static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa /* aligned orientation */,
                         const seqset_t *T, int ti, int strand, const anchor_t *a, const int *chain, int m) {
     const uint8_t *t = T->code[ti];
-    int ql = Q->len[qi], tl = T->len[ti];
-    uint32_t *scratch = (uint32_t *)malloc((size_t)(2 * (EXT_MAX + BLOCK_MAX) + 2 * BAND_W + 8) * 4);
+    uint32_t *scratch = (uint32_t *)malloc((size_t)(2 * (g_ext_max + g_block_max) + 2 * (g_ext_band + g_shift_max + BAND_W) + 8) * 4);
     piece_t p;
     memset(&p, 0, sizeof p);
     int open = 0, cq = 0, ct = 0;   /* current fixed point */
@@ -500,18 +548,14 @@ static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
             cq = qe; ct = te;
         } else {        /* split: close the piece here, reopen at this anchor */
             p.qe = cq; p.te = ct;
-            extend_left(o, qa, t, &p, scratch);
-            extend_right(o, qa, ql, t, tl, &p, scratch);
-            emit_piece(out, o, Q, qi, T, ti, strand, &p);
+            close_piece(out, o, Q, qi, qa, T, ti, strand, &p, scratch);
             open = 0;
             --x;        /* revisit this anchor as the start of a new piece */
         }
     }
     if (open) {
         p.qe = cq; p.te = ct;
-        extend_left(o, qa, t, &p, scratch);
-        extend_right(o, qa, ql, t, tl, &p, scratch);
-        emit_piece(out, o, Q, qi, T, ti, strand, &p);
+        close_piece(out, o, Q, qi, qa, T, ti, strand, &p, scratch);
     }
     free(p.cg.op);
     free(scratch);
@@ -601,12 +645,16 @@ static void assign_ranks(seqset_t *T, seqset_t *Q) {
     free(all);
 }
 
+void oracle_last_counts(long *pieces, long *stubs) { *pieces = g_n_pieces; *stubs = g_n_stubs; }
+
 int oracle_ava(const char *target_fa, const char *query_fa, const ava_opts_t *o, const char *out_paf) {
     seqset_t Ts, Qs, *T = &Ts, *Q = &Qs;
     if (seqset_read(target_fa, T) != 0) return -2;
     if (seqset_read(query_fa, Q) != 0) { seqset_free(T); return -2; }
     if (!(o->k & 1) || o->k > 28 || o->w < 1 || o->w > 64) { seqset_free(T); seqset_free(Q); return -1; }
     assign_ranks(T, Q);
+    read_switches();
+    g_n_pieces = g_n_stubs = 0;
     FILE *out = fopen(out_paf, "w");
     if (!out) { seqset_free(T); seqset_free(Q); return -2; }
     index_t ix;

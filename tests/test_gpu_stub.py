@@ -1,0 +1,68 @@
+"""GPU: the stub rule (hlmi_ava_opts::stub_oh; proof at oracle/ava_oracle.c:is_stub).  On divergent reads most alignment
+pieces are fragments of a chain that was cut at a long gap between anchors; a fragment that ends deep inside both reads
+fails the overhang test of filter_trans_ovlp_inline_v4.py:52-64 whatever its end extensions find.  With stub_oh >= 0 such a
+piece is reported without its extensions (it only occupies a line of the filter's 1000-line windows).
+
+  * rows with the rule on == the oracle's rows with the rule on, bit for bit (stubs materialised on both sides)
+  * the stage's final rows do not depend on the rule (HLMI_NO_STUB switches it off): that is its correctness statement
+"""
+import os
+
+import pytest
+
+from hylight_amd import api
+from hylight_amd import simulate as S
+from hylight_amd import workloads as W
+from oracle import ava as OA
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def divergent(tmp_path_factory):
+    """A small C5-like set: C5's strain divergence and read errors on 6 strains x 30 kb."""
+    d = tmp_path_factory.mktemp("stub")
+    sim = dict(W.CONFIGS["C5"]["sim"], n_strains=6, genome_len=30_000, n_reads=260, mean_len=7_000)
+    reads, _ = S.simulate_reads(seed=411, min_len=2_000, max_len=20_000, **sim)
+    fa = d / "r.fa"
+    S.write_fasta(reads, fa)
+    return d, fa
+
+
+@pytest.mark.parametrize("mode", ["long", "short_constants"])
+def test_rows_with_stubs_match_the_oracle(divergent, mode):
+    d, fa = divergent
+    if mode == "long":
+        og, oo = api.ava_opts_long(), OA.opts_long()
+    else:                              # the end bonus enters the rule's score bound: blocks >= min_dp_score + end_bonus
+        og, oo = api.ava_opts_short(), OA.opts_short()
+        for o in (og, oo):
+            o.pair_once = 1
+    og.stub_oh = oo.stub_oh = 3
+    api.ava(fa, fa, d / f"g_{mode}.paf", og)
+    st = api.last_stats()
+    OA.ava(fa, fa, d / f"o_{mode}.paf", oo)
+    pieces, stubs = OA.last_counts()
+    got, want = open(d / f"g_{mode}.paf").read(), open(d / f"o_{mode}.paf").read()
+    assert got == want and want.count("\n") == pieces
+    if mode == "long":
+        assert stubs > 0.3 * pieces > 300                       # the rule bites on this input ...
+        assert st["align_ext_held"] > st["align_ext_late"] > 0  # ... and some held-back extensions had to run after all
+        # and the rows differ from the fully extended ones (the stubs are visible here, by design)
+        OA.ava(fa, fa, d / "o_full.paf")
+        assert open(d / "o_full.paf").read() != want
+
+
+def test_stage_output_does_not_depend_on_the_rule(divergent, monkeypatch):
+    d, fa = divergent
+    stage = dict(len_over=1500, mc=2, iden=0.90)
+    on, off = d / "on.paf", d / "off.paf"
+    api.split_reads2(fa, fa, 4, d, on, long=True, **stage)
+    st_on = api.last_stats()
+    monkeypatch.setenv("HLMI_NO_STUB", "1")
+    api.split_reads2(fa, fa, 4, d, off, long=True, **stage)
+    st_off = api.last_stats()
+    assert open(on).read() == open(off).read() and os.path.getsize(on) > 0
+    assert st_on["ava_rows"] == st_off["ava_rows"] and st_on["rows_after_v4"] == st_off["rows_after_v4"]
+    assert st_on["align_ext_held"] > 0 and st_off.get("align_ext_held", 0) == 0
+    assert st_on["align_tasks_wide"] < st_off["align_tasks_wide"]
