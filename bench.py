@@ -85,9 +85,15 @@ def cpu_baseline(fa, cfg, budget_s=25.0):
     """The reference's CPU path timed beside the GPU number, on a bounded sample of the same workload.
     (1) minimap2 on $PATH: the exact command line of script/filter_overlap_slr2.py:51 on sampled --nsplit chunks, one
         process per chunk under a pool as wide as `xargs -P` (utils.py:65) -> kind "reference";
-    (2) otherwise the oracle (this repo's CPU restatement, kind "port"): sampled target reads of as many --nsplit
-        chunks as fit the budget, each against a fixed prefix of the query file, oracle overlapper + oracle filters,
-        one process per host core."""
+    (2) otherwise the oracle (this repo's CPU restatement, kind "port"): oracle overlapper + oracle filters, one process
+        per host core.
+    Sample: the first N_T target reads of as many --nsplit chunks (spread over the file) as fit the budget, each against
+    ALL query reads - every sampled target sees the pile-up depth it has in the real run, which the support filter
+    (mc) depends on, and every process sketches the whole read file as each per-chunk minimap2 process of the
+    reference does.  `candidate_rows_per_s` (rows out of the overlapper) is the figure to hold against the GPU line's
+    config.candidate_rows_per_s; `value` counts the rows the filter chain keeps of those candidates - the query-side
+    pile-up of a chunk is thinner with a few targets than with all of them, so it is an indication, not the same
+    quantity as the GPU `value`."""
     import multiprocessing as mp
     from oracle import filters as F
     stage = cfg["stage"]
@@ -96,39 +102,40 @@ def cpu_baseline(fa, cfg, budget_s=25.0):
     cores = min(len(os.sched_getaffinity(0)), 32, len(ranges))
     tmp = tempfile.mkdtemp(prefix="hl_cpu_")
     mm2 = shutil.which("minimap2")
-    # query sample: the first 10 000 reads (C2: all of them); target sample: the first 8 reads of a chunk
-    q_reads = min(cfg["sim"]["n_reads"], 10_000)
-    qfa = os.path.join(tmp, "q.fa")
-    with open(fa) as src, open(qfa, "w") as dst:
-        for _ in range(2 * q_reads):
-            dst.write(src.readline())
-    n_t = 8
+    n_t = 2
+    order = [(i * len(ranges)) // cores + k for k in range(max(1, len(ranges) // cores)) for i in range(cores)]
+    order = [c for c in dict.fromkeys(order) if c < len(ranges)]          # round k takes chunk k of every core's stripe
     want = {}
-    for i, (lo, hi) in enumerate(ranges):
+    for i in order:
+        lo, hi = ranges[i]
         for l in range(lo, min(hi, lo + 2 * n_t)):
             want[l] = i
-    tl = [[] for _ in ranges]
+    tl = {i: [] for i in order}
     with open(fa) as f:
         for l, text in enumerate(f):
             if l in want:
                 tl[want[l]].append(text.rstrip("\n"))
     t0 = time.time()
-    done, rows = 0, 0
-    jobs = [(qfa, tl[i], os.path.join(tmp, f"c{i}"), stage, mm2) for i in range(len(ranges))]
+    done, rows, cand = 0, 0, 0
+    jobs = [(fa, tl[i], os.path.join(tmp, f"c{i}"), stage, mm2) for i in order]
     with mp.get_context("fork").Pool(cores) as pool:
         nxt = 0
         while nxt < len(jobs) and (done == 0 or (time.time() - t0) * (1 + cores / max(done, 1)) < budget_s):
             batch = jobs[nxt:nxt + cores]
-            rows += sum(pool.map(_cpu_chunk, batch))
+            for r, c in pool.map(_cpu_chunk, batch):
+                rows += r
+                cand += c
             done += len(batch)
             nxt += len(batch)
     dt = time.time() - t0
     shutil.rmtree(tmp, ignore_errors=True)
     what = ("minimap2 (the command of filter_overlap_slr2.py:51, -t 1 per process) + oracle filters for the count"
             if mm2 else "oracle overlapper + oracle filters")
-    return dict(value=rows / dt, unit="overlaps/s", cores=cores, kind="reference" if mm2 else "port",
-                sample=f"first {n_t} target reads of {done} of the {len(ranges)} --nsplit chunks x first {q_reads} queries, {what}, "
-                       f"one process per core, {dt:.1f} s wall")
+    return dict(value=rows / dt, unit="overlaps/s", candidate_rows_per_s=cand / dt, cores=cores, kind="reference" if mm2 else "port",
+                sample=f"first {n_t} target reads of {done} of the {len(ranges)} --nsplit chunks x all {cfg['sim']['n_reads']} queries "
+                       f"(full pile-up depth per sampled target), {what}, one process per core, {dt:.1f} s wall; compare "
+                       f"candidate_rows_per_s with config.candidate_rows_per_s - `value` is the filter's keep on this sample, "
+                       f"not the same quantity as the GPU value")
 
 
 def _cpu_chunk(args):
@@ -144,7 +151,7 @@ def _cpu_chunk(args):
         from oracle import ava as OA
         OA.ava(base + ".fa", qfa, base + ".paf")
     raw = open(base + ".paf").read().split("\n")[:-1]
-    return len(F.worker(raw, True, stage["len_over"], stage["mc"], stage["iden"]))
+    return len(F.worker(raw, True, stage["len_over"], stage["mc"], stage["iden"])), len(raw)
 
 
 # ---- algorithmic bytes of the whole stage from the counts of one step -------------------------------

@@ -182,6 +182,9 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         size_t q_floor = 8192;
         if (const char *e = getenv("HLMI_QCAP_MIN")) q_floor = (size_t)std::max(1, atoi(e));      // tuning hook
         q_cap = std::min<size_t>(q_cap, std::max<size_t>(q_floor, (size_t)1 << std::max(0, std::min(spare, 16))));
+        // the widest anchor form (key + value) still keeps query, target, strand and target position in one 64-bit key
+        const int key_spare = 64 - (bits_for(nT > 1 ? nT - 1 : 1) + 1 + bits_for(max_tlen));
+        q_cap = std::min<size_t>(q_cap, (size_t)1 << std::max(0, std::min(key_spare, 16)));
     }
     size_t q = 0;
     while (q < nQ) {

@@ -1563,7 +1563,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     // (a pool that overflows costs a second run of every DP kernel: 12 runs per task cover read sets with a few per cent
     // of errors, where the average is 8)
     const size_t open_chunks = MAX_BLOCKS * (4 * WAVES * RUN_CHUNK + 2 * 4 * WAVES * RUN_CHUNK_SMALL) +
-                               (size_t)2 * 256 * 32 * 8 * PK_WAVES * RUN_CHUNK_SMALL;  // (two packed launches: 8 allocating lanes per wave)
+                               (size_t)3 * 256 * 32 * 8 * PK_WAVES * RUN_CHUNK_SMALL;  // (three packed launches: 8 allocating lanes per wave)
     size_t run_share = std::max<size_t>(NT * 12, 1 << 16);
     DBuf<uint32_t> runs;
     AsmArgs as{};
@@ -1666,7 +1666,14 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
             hipLaunchKernelGGL(align_narrow_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
-        if (n3) {
+        if (n3 && packed && !getenv("HLMI_NARROW_LONG_UNPACKED")) {
+            // blocks of more than NR_SHORT rows (divergent reads: C5 has as many of these as of the short ones) in the packed
+            // form as well: eight tasks per wave at twice the plane LDS (25 KB per wave) instead of four
+            KTimer kt("align_narrow_long");
+            aa.list = list3.p; aa.n_list = n3;
+            const unsigned nb = (unsigned)std::min<size_t>(((n3 + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
+            hipLaunchKernelGGL(align_narrow_pk_kernel<BLOCK_MAX>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
+        } else if (n3) {
             KTimer kt("align_narrow_long");
             aa.list = list3.p; aa.n_list = n3;
             const unsigned nb = (unsigned)std::min<size_t>(((n3 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);

@@ -461,63 +461,54 @@ __global__ void vertex_index_kernel(const Arc *arc, size_t n, uint64_t *idx) {
 // v -> w (the reference keeps one mark per vertex, so of several arcs to one w only the first is ever deleted).  The
 // outer walk over v's arcs stays in arc order - a neighbour already marked 2 is not expanded, exactly as in the
 // reference - while the lanes stream the neighbour's own arc list through the table.
-constexpr int TR_SLOTS = 2048;              // per wave; vertices with more than TR_SLOTS / 2 arcs take the global-memory path
+constexpr int TR_SLOTS = 2048;              // per wave; vertices with more than TR_SLOTS / 2 arcs take the global-memory table
+constexpr int TR_BITS = 11;
 constexpr uint32_t TR_EMPTY = 0xffffffffu;
 constexpr int TR_WAVES = 4;
-__device__ __forceinline__ uint32_t tr_hash(uint32_t w) { return (w * 0x9e3779b1u) >> (32 - 11); }
-static_assert(TR_SLOTS == 1 << 11, "tr_hash yields 11 bits");
+static_assert(TR_SLOTS == 1 << TR_BITS, "table size and hash bits");
+__device__ __forceinline__ uint32_t tr_hash(uint32_t w, int bits) { return (w * 0x9e3779b1u) >> (32 - bits); }
 
-__global__ __launch_bounds__(64 * TR_WAVES) void reduce_kernel(const Arc *arc, const uint32_t *seq, const uint64_t *idx, uint32_t n_vtx,
-                                                                uint32_t fuzz, uint8_t *del, uint32_t *n_reduced, uint32_t *big_list,
-                                                                uint32_t *n_big) {
-    __shared__ uint32_t s_key[TR_WAVES][TR_SLOTS];
-    __shared__ uint32_t s_val[TR_WAVES][TR_SLOTS];      // mark << 30 | first arc index
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t v = blockIdx.x * TR_WAVES + wv;
-    if (v >= n_vtx) return;
-    const uint32_t nv = (uint32_t)idx[v];
-    if (!nv) return;
+// Table access.  The LDS table is plain memory of the wave.  The global-memory table of a big vertex is touched by one wave
+// only as well, but through the vector L1, which does not see the wave's own atomics: its reads are agent-scope atomic
+// loads (served by L2, where the atomics happen).
+template <bool BIG> __device__ __forceinline__ uint32_t tr_load(const uint32_t *p) {
+    if constexpr (BIG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+// one wave, one vertex: key / val = its table of (1 << bits) slots, already holding TR_EMPTY / (1 << 30 | 0x3fffffff)
+template <bool BIG>
+__device__ void reduce_vertex(const Arc *arc, const uint64_t *idx, uint32_t v, uint32_t fuzz, uint8_t *del, uint32_t *n_reduced,
+                              uint32_t *key, uint32_t *val, int bits, int lane) {
+    const uint32_t nv = (uint32_t)idx[v], mask = (1u << bits) - 1u;
     const uint64_t b = idx[v] >> 32;
     const Arc *av = arc + b;
-    if (seq[v >> 1] >> 31) {                            // arcs of a deleted read (asg.c:157-160)
-        for (uint32_t i = lane; i < nv; i += 64) del[b + i] = 1;
-        if (lane == 0) atomicAdd(n_reduced, nv);
-        return;
-    }
-    if (nv > TR_SLOTS / 2) {
-        if (lane == 0) big_list[atomicAdd(n_big, 1u)] = v;
-        return;
-    }
-    uint32_t *key = s_key[wv], *val = s_val[wv];
-    for (int k = lane; k < TR_SLOTS; k += 64) { key[k] = TR_EMPTY; val[k] = 1u << 30 | 0x3fffffffu; }     // mark 1, no arc yet
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
     for (uint32_t i = lane; i < nv; i += 64) {         // duplicates of a neighbour share one slot: smallest arc index wins
         const uint32_t w = av[i].v;
-        uint32_t h = tr_hash(w);
+        uint32_t h = tr_hash(w, bits);
         for (;;) {
             const uint32_t old = atomicCAS(&key[h], TR_EMPTY, w);
             if (old == TR_EMPTY || old == w) break;
-            h = (h + 1) & (TR_SLOTS - 1);
+            h = (h + 1) & mask;
         }
         atomicMin(&val[h], 1u << 30 | i);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     auto slot_of = [&](uint32_t w) -> int {            // -1: not a neighbour of v
-        uint32_t h = tr_hash(w);
+        uint32_t h = tr_hash(w, bits);
         for (;;) {
-            const uint32_t k = key[h];
+            const uint32_t k = tr_load<BIG>(&key[h]);
             if (k == w) return (int)h;
             if (k == TR_EMPTY) return -1;
-            h = (h + 1) & (TR_SLOTS - 1);
+            h = (h + 1) & mask;
         }
     };
     const uint32_t L = (uint32_t)av[nv - 1].ul + fuzz;
     for (uint32_t i = 0; i < nv; ++i) {
         const uint32_t w = av[i].v, li = (uint32_t)av[i].ul;
         const int sw = slot_of(w);                      // uniform across the wave
-        if ((val[sw] >> 30) != 1u) continue;
+        if ((tr_load<BIG>(&val[sw]) >> 30) != 1u) continue;
         const uint32_t nw = (uint32_t)idx[w];
         const Arc *aw = arc + (idx[w] >> 32);
         for (uint32_t j0 = 0; j0 < nw; j0 += 64) {
@@ -538,39 +529,61 @@ __global__ __launch_bounds__(64 * TR_WAVES) void reduce_kernel(const Arc *arc, c
     uint32_t red = 0;
     for (uint32_t i = lane; i < nv; i += 64) {
         const int s = slot_of(av[i].v);
-        const uint32_t m = val[s];
+        const uint32_t m = tr_load<BIG>(&val[s]);
         if ((m >> 30) != 1u && (m & 0x3fffffffu) == i) { del[b + i] = 1; ++red; }
     }
     red = (uint32_t)wave_incl_sum_i32((int)red, lane);
     if (lane == 63 && red) atomicAdd(n_reduced, red);
 }
 
-// vertices with more arcs than the LDS table holds: same procedure, one thread per vertex, marks in a strip of global
-// memory parallel to the vertex's arcs (mark of w = state of the first arc v -> w)
-__global__ void reduce_big_kernel(const Arc *arc, const uint64_t *idx, const uint32_t *big_list, uint32_t n_big, uint32_t fuzz,
-                                  uint8_t *state, uint8_t *del, uint32_t *n_reduced) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_big) return;
-    const uint32_t v = big_list[k], nv = (uint32_t)idx[v];
+__global__ __launch_bounds__(64 * TR_WAVES) void reduce_kernel(const Arc *arc, const uint32_t *seq, const uint64_t *idx, uint32_t n_vtx,
+                                                                uint32_t fuzz, uint8_t *del, uint32_t *n_reduced, uint32_t *big_list,
+                                                                uint32_t *n_big) {
+    __shared__ uint32_t s_key[TR_WAVES][TR_SLOTS];
+    __shared__ uint32_t s_val[TR_WAVES][TR_SLOTS];      // mark << 30 | first arc index
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t v = blockIdx.x * TR_WAVES + wv;
+    if (v >= n_vtx) return;
+    const uint32_t nv = (uint32_t)idx[v];
+    if (!nv) return;
     const uint64_t b = idx[v] >> 32;
-    const Arc *av = arc + b;
-    uint8_t *st = state + b;
-    auto first_arc = [&](uint32_t w, uint32_t upto) { for (uint32_t i = 0; i < upto; ++i) if (av[i].v == w) return i; return upto; };
-    for (uint32_t i = 0; i < nv; ++i) st[i] = 1;
-    const uint32_t L = (uint32_t)av[nv - 1].ul + fuzz;
-    for (uint32_t i = 0; i < nv; ++i) {
-        if (st[first_arc(av[i].v, i)] != 1) continue;
-        const uint32_t w = av[i].v, nw = (uint32_t)idx[w], li = (uint32_t)av[i].ul;
-        const Arc *aw = arc + (idx[w] >> 32);
-        for (uint32_t j = 0; j < nw && (uint32_t)aw[j].ul + li <= L; ++j) {
-            const uint32_t f = first_arc(aw[j].v, nv);
-            if (f < nv) st[f] = 2;
-        }
+    if (seq[v >> 1] >> 31) {                            // arcs of a deleted read (asg.c:157-160)
+        for (uint32_t i = lane; i < nv; i += 64) del[b + i] = 1;
+        if (lane == 0) atomicAdd(n_reduced, nv);
+        return;
     }
-    uint32_t red = 0;
-    for (uint32_t i = 0; i < nv; ++i)
-        if (first_arc(av[i].v, i) == i && st[i] == 2) { del[b + i] = 1; ++red; }
-    if (red) atomicAdd(n_reduced, red);
+    if (nv > TR_SLOTS / 2) {
+        if (lane == 0) big_list[atomicAdd(n_big, 1u)] = v;
+        return;
+    }
+    uint32_t *key = s_key[wv], *val = s_val[wv];
+    for (int k = lane; k < TR_SLOTS; k += 64) { key[k] = TR_EMPTY; val[k] = 1u << 30 | 0x3fffffffu; }     // mark 1, no arc yet
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    reduce_vertex<false>(arc, idx, v, fuzz, del, n_reduced, key, val, TR_BITS, lane);
+}
+
+// Vertices with more arcs than the LDS table holds (a read end overlapped by more than a thousand reads none of which is
+// contained in another: deep equal-length layouts, or the union of many --nsplit chunks' 60 rows per query): the same
+// procedure, one wave per vertex, with a table of >= 4 slots per arc in global memory.
+__device__ __forceinline__ int big_bits(uint32_t nv) { int b = TR_BITS + 1; while ((1u << b) < 4u * nv && b < 31) ++b; return b; }
+__global__ void big_table_size_kernel(const uint64_t *idx, const uint32_t *big_list, uint32_t n_big, uint32_t *slots) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_big) slots[k] = 1u << big_bits((uint32_t)idx[big_list[k]]);
+}
+__global__ __launch_bounds__(64 * TR_WAVES) void reduce_big_kernel(const Arc *arc, const uint64_t *idx, const uint32_t *big_list,
+                                                                    uint32_t n_big, const uint64_t *tab_off, uint32_t fuzz, uint32_t *keys,
+                                                                    uint32_t *vals, uint8_t *del, uint32_t *n_reduced) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * TR_WAVES + (threadIdx.x >> 6);
+    if (k >= n_big) return;
+    const uint32_t v = big_list[k];
+    const int bits = big_bits((uint32_t)idx[v]);
+    uint32_t *key = keys + tab_off[k], *val = vals + tab_off[k];      // keys: filled with TR_EMPTY by the host
+    for (uint32_t s = lane; s < (1u << bits); s += 64) val[s] = 1u << 30 | 0x3fffffffu;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    reduce_vertex<true>(arc, idx, v, fuzz, del, n_reduced, key, val, bits, lane);
 }
 
 __global__ void apply_del_kernel(Arc *arc, const uint8_t *del, size_t n) {
@@ -863,10 +876,18 @@ void graph_device(const char *paf_path, const GraphOpt &o, const std::string &un
         HIP_CHECK(hipGetLastError());
         const uint32_t n_big = download_one(counters.p + 1);
         if (n_big) {
-            DBuf<uint8_t> state(g.n_arc);
-            hipLaunchKernelGGL(reduce_big_kernel, grid1(n_big), dim3(WG), 0, stream(), g.arc.p, g.idx.p, big.p, n_big,
-                               (uint32_t)o.gap_fuzz, state.p, del.p, counters.p);
+            KTimer kt("graph_reduce_big");
+            DBuf<uint32_t> slots(n_big);
+            DBuf<uint64_t> tab_off(n_big);
+            hipLaunchKernelGGL(big_table_size_kernel, grid1(n_big), dim3(WG), 0, stream(), g.idx.p, big.p, n_big, slots.p);
+            exclusive_scan_u32_to_u64(slots.p, tab_off.p, n_big);
+            const uint64_t total = download_one(tab_off.p + (n_big - 1)) + download_one(slots.p + (n_big - 1));
+            DBuf<uint32_t> keys(total), vals(total);
+            keys.fill_ff();
+            hipLaunchKernelGGL(reduce_big_kernel, dim3(cdiv(n_big, (size_t)TR_WAVES)), dim3(64 * TR_WAVES), 0, stream(), g.arc.p, g.idx.p,
+                               big.p, n_big, tab_off.p, (uint32_t)o.gap_fuzz, keys.p, vals.p, del.p, counters.p);
             HIP_CHECK(hipGetLastError());
+            stat_set("graph_big_table_slots", (double)total);
         }
         n_reduced = download_one(counters.p);
         stat_set("graph_arcs_reduced", (double)n_reduced);

@@ -36,6 +36,13 @@ CONFIGS = {
 }
 
 
+def c1_reads():
+    """C1 (BASELINE.json configs[0]; the example files it names are not in the reference tree): C2's
+    recipe at a tenth of its size - 1 000 long reads on 5 strains x 40 kb.  Run as `--corrected --nsplit 100 -t 8`."""
+    reads, _ = S.simulate_reads(seed=S.SEED_DEFAULT, min_len=1_000, max_len=40_000, **config("C2", 0.1)["sim"])
+    return reads
+
+
 def config(name, scale=1.0):
     """The recipe `name`, optionally shrunk: reads and genome length times `scale` (depth unchanged)."""
     c = CONFIGS[name]

@@ -16,7 +16,11 @@ the files of the path up to contigs1.fa exist by then and are what is captured:
     fxF_contigs1.gfa.gz  OUT/tmp/contigs1.gfa           (miniasm -d 10000 -n 1 -e 1 -c 1 -f, HyLight.py:140)
     fxF_contigs1.fa.gz   OUT/tmp/contigs1.fa            (HyLight.gfa2fa)
 
-Usage: python tests/golden/make_goldens_driver.py      (LC_ALL=C, as for the other goldens)
+The same at the size SURVEY.md 8d names for C1 (the example data set is not in the reference tree: C2's recipe at a tenth
+of its size, 1 000 long reads, `--corrected --nsplit 100 -t 8`): fxG_*.  Its input is not stored - the seeded simulator
+makes it again (hylight_amd.workloads.c1_reads) and fxG_meta.json holds the SHA-256 of the FASTQ the goldens belong to.
+
+Usage: python tests/golden/make_goldens_driver.py [fxF] [fxG]      (LC_ALL=C, as for the other goldens)
 """
 import gzip
 import os
@@ -62,6 +66,41 @@ def fixture_reads():
     return reads
 
 
+def main_c1():
+    import hashlib
+    import json
+    from hylight_amd import workloads as W
+    tmp = tempfile.mkdtemp(prefix="hl_golden_c1_")
+    shim_dir = os.path.join(tmp, "shim")
+    os.makedirs(shim_dir)
+    with open(os.path.join(shim_dir, "minimap2"), "w") as f:
+        f.write(SHIM)
+    os.chmod(os.path.join(shim_dir, "minimap2"), 0o755)
+    env = dict(os.environ, LC_ALL="C", PATH=shim_dir + ":" + os.environ["PATH"], HL_REPO=ROOT)
+    fq = os.path.join(tmp, "fxG_long.fq")
+    S.write_fastq(W.c1_reads(), fq)
+    short = os.path.join(tmp, "fxG_short.fq")
+    with open(short, "w") as f:
+        f.write("@s0/1\nACGTACGTAC\n+\nIIIIIIIIII\n")
+    out = os.path.join(tmp, "OUT")
+    r = subprocess.run([sys.executable, REF_DRIVER, "-l", fq, "-s", short, "--corrected", "--nsplit", "100", "-t", "8", "-o", out],
+                       cwd=tmp, env=env, capture_output=True, text=True, timeout=7200)
+    print("reference driver exit code:", r.returncode)
+    meta = dict(cmd="HyLight.py -l fxG_long.fq -s fxG_short.fq --corrected --nsplit 100 -t 8 -o OUT", fastq_sha256=hashlib.sha256(open(fq, "rb").read()).hexdigest())
+    for name, rel in {"fxG_s1_s1.paf.gz": "2.overlap/s1_s1.paf", "fxG_contigs1.gfa.gz": "tmp/contigs1.gfa", "fxG_contigs1.fa.gz": "tmp/contigs1.fa"}.items():
+        src = os.path.join(out, rel)
+        if not os.path.exists(src) or os.path.getsize(src) == 0:
+            print(r.stdout[-2000:], r.stderr[-2000:])
+            raise SystemExit(f"the reference run did not produce {rel}")
+        gz(src, os.path.join(HERE, name))
+        print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+    meta["s1_fa_sha256"] = hashlib.sha256(open(os.path.join(out, "1.split_fastx/s1.fa"), "rb").read()).hexdigest()
+    meta["paf_rows"] = sum(1 for _ in open(os.path.join(out, "2.overlap/s1_s1.paf")))
+    with open(os.path.join(HERE, "fxG_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="hl_golden_drv_")
     shim_dir = os.path.join(tmp, "shim")
@@ -96,4 +135,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1:] or ["fxF", "fxG"]
+    if "fxF" in which:
+        main()
+    if "fxG" in which:
+        main_c1()
