@@ -121,3 +121,24 @@ def test_extend_con_files_match_the_oracle_chain(tmp_path):
     sfo = F.window_filter(raw.split("\n")[:-1], variant=3, min_len=90, min_iden=0.99, min_o=2, sfo=True)
     assert (tmp / "stageb" / "sfoverlaps.out").read_text().split("\n")[:-1] == sfo and len(sfo) >= 5
     assert (tmp / "stageb" / "sfoverlap.out.savage").read_text().split("\n")[:-1] == F.sfo2overlaps(sfo)
+
+
+def test_driver_at_c1_size_reproduces_the_reference_drivers_files(tmp_path, golden):
+    """BASELINE.json configs[0] as SURVEY.md 8d specifies it (the example files are not in the reference tree: C2's recipe
+    at a tenth of its size): 1 000 long reads, `--corrected --nsplit 100 -t 8`.  Goldens = the reference's own HyLight.py
+    run on the same FASTQ (tests/golden/make_goldens_driver.py fxG); the input is made again by the seeded simulator and
+    checked against the recorded SHA-256."""
+    import hashlib
+    import json
+    from hylight_amd import workloads as W
+    meta = json.loads(golden.text("fxG_meta.json"))
+    fq = tmp_path / "fxG_long.fq"
+    S.write_fastq(W.c1_reads(), fq)
+    assert hashlib.sha256(fq.read_bytes()).hexdigest() == meta["fastq_sha256"]
+    out = tmp_path / "OUT"
+    assert driver.main(["-l", str(fq), "-o", str(out), "--corrected", "--nsplit", "100", "-t", "8", "--stop_after", "contigs1"]) == 0
+    assert hashlib.sha256((out / "1.split_fastx" / "s1.fa").read_bytes()).hexdigest() == meta["s1_fa_sha256"]
+    paf = (out / "2.overlap" / "s1_s1.paf").read_text()
+    assert paf == golden.text("fxG_s1_s1.paf") and paf.count("\n") == meta["paf_rows"] > 1000
+    assert (out / "tmp" / "contigs1.gfa").read_text() == golden.text("fxG_contigs1.gfa")
+    assert (out / "tmp" / "contigs1.fa").read_text() == golden.text("fxG_contigs1.fa")
