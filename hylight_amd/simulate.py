@@ -63,52 +63,113 @@ def make_strains(rng, n_strains, genome_len, snp_rate, indel_rate=0.0):
     return strains
 
 
+def _draw_read(rng, g, L, err_sub, err_ins, err_del, rev_frac, keep_gpos):
+    """One read of length L (before errors) from strain sequence g: (bases, gpos or None, start, reverse?)."""
+    s = int(rng.integers(0, len(g) - L + 1))
+    frag = g[s:s + L]
+    # errors
+    u = rng.random(L)
+    is_del = u < err_del
+    is_sub = (u >= err_del) & (u < err_del + err_sub)
+    frag2 = frag.copy()
+    nsub = int(is_sub.sum())
+    if nsub:
+        code = np.searchsorted(_BASES, frag2[is_sub])
+        frag2[is_sub] = _BASES[(code + rng.integers(1, 4, size=nsub)) % 4]
+    keep = ~is_del
+    # never delete the first/last base (keeps start/end exact)
+    keep[0] = keep[-1] = True
+    base = frag2[keep]
+    gp = (np.arange(s, s + L, dtype=np.int64))[keep] if keep_gpos else None
+    n_ins = rng.binomial(len(base), err_ins)
+    if n_ins:
+        ipos = np.sort(rng.integers(1, len(base), size=n_ins))  # insert before index ipos (never at 0)
+        ibase = _BASES[rng.integers(0, 4, size=n_ins)]
+        base = np.insert(base, ipos, ibase)
+        if keep_gpos:
+            gp = np.insert(gp, ipos, -1)
+    rev = bool(rng.random() < rev_frac)
+    if rev:
+        base = _COMP[base[::-1]]
+        if keep_gpos:
+            gp = gp[::-1].copy()
+    return np.ascontiguousarray(base), (np.ascontiguousarray(gp) if keep_gpos else None), s, rev
+
+
+def _population(seed, n_strains, genome_len, n_reads, mean_len, min_len, max_len, snp_rate, strain_indel_rate):
+    rng = np.random.default_rng(seed)
+    strains = make_strains(rng, n_strains, genome_len, snp_rate, strain_indel_rate)
+    ab = 10.0 ** rng.uniform(0.0, 1.0, size=n_strains)
+    ab = ab / ab.sum()
+    strain_of = rng.choice(n_strains, size=n_reads, p=ab)
+    lens = np.clip(rng.gamma(4.0, mean_len / 4.0, size=n_reads).astype(np.int64), min_len, max_len)
+    return rng, strains, strain_of, lens
+
+
 def simulate_reads(seed=SEED_DEFAULT, n_strains=5, genome_len=400_000, n_reads=10_000,
                    mean_len=8_000, min_len=1_000, max_len=40_000,
                    snp_rate=0.01, strain_indel_rate=0.0,
                    err_sub=0.003, err_ins=0.001, err_del=0.001,
                    rev_frac=0.5, name_prefix="r", keep_gpos=False):
     """Generate reads.  Returns (reads, strains)."""
-    rng = np.random.default_rng(seed)
-    strains = make_strains(rng, n_strains, genome_len, snp_rate, strain_indel_rate)
-    ab = 10.0 ** rng.uniform(0.0, 1.0, size=n_strains)
-    ab = ab / ab.sum()
+    rng, strains, strain_of, lens = _population(seed, n_strains, genome_len, n_reads, mean_len, min_len, max_len, snp_rate,
+                                                strain_indel_rate)
     reads = []
-    strain_of = rng.choice(n_strains, size=n_reads, p=ab)
-    lens = np.clip(rng.gamma(4.0, mean_len / 4.0, size=n_reads).astype(np.int64), min_len, max_len)
     for i in range(n_reads):
         st = int(strain_of[i])
         g = strains[st]
         L = int(min(lens[i], len(g)))
-        s = int(rng.integers(0, len(g) - L + 1))
-        frag = g[s:s + L]
-        # errors
-        u = rng.random(L)
-        is_del = u < err_del
-        is_sub = (u >= err_del) & (u < err_del + err_sub)
-        frag2 = frag.copy()
-        nsub = int(is_sub.sum())
-        if nsub:
-            code = np.searchsorted(_BASES, frag2[is_sub])
-            frag2[is_sub] = _BASES[(code + rng.integers(1, 4, size=nsub)) % 4]
-        keep = ~is_del
-        # never delete the first/last base (keeps start/end exact)
-        keep[0] = keep[-1] = True
-        base = frag2[keep]
-        gp = (np.arange(s, s + L, dtype=np.int64))[keep]
-        n_ins = rng.binomial(len(base), err_ins)
-        if n_ins:
-            ipos = np.sort(rng.integers(1, len(base), size=n_ins))  # insert before index ipos (never at 0)
-            ibase = _BASES[rng.integers(0, 4, size=n_ins)]
-            base = np.insert(base, ipos, ibase)
-            gp = np.insert(gp, ipos, -1)
-        rev = bool(rng.random() < rev_frac)
-        if rev:
-            base = _COMP[base[::-1]]
-            gp = gp[::-1].copy()
-        reads.append(Read(f"{name_prefix}{i}", np.ascontiguousarray(base),
-                          np.ascontiguousarray(gp) if keep_gpos else None, st, s, s + L, rev))
+        base, gp, s, rev = _draw_read(rng, g, L, err_sub, err_ins, err_del, rev_frac, True)
+        reads.append(Read(f"{name_prefix}{i}", base, gp if keep_gpos else None, st, s, s + L, rev))
     return reads, strains
+
+
+_BLOCK_CTX = None          # (strains, strain_of, lens, recipe): inherited by the forked block workers
+
+
+def _fasta_block(job):
+    b, lo, hi, seed, part = job
+    strains, strain_of, lens, (err_sub, err_ins, err_del, rev_frac, name_prefix) = _BLOCK_CTX
+    rng = np.random.default_rng([seed, b + 1])
+    bases = 0
+    with open(part, "wb") as f:
+        for i in range(lo, hi):
+            g = strains[int(strain_of[i])]
+            L = int(min(lens[i], len(g)))
+            base, _, _, _ = _draw_read(rng, g, L, err_sub, err_ins, err_del, rev_frac, False)
+            f.write(b">" + f"{name_prefix}{i}".encode() + b"\n" + base.tobytes() + b"\n")
+            bases += len(base)
+    return bases
+
+
+def simulate_reads_to_fasta(path, seed=SEED_DEFAULT, n_strains=5, genome_len=400_000, n_reads=10_000,
+                            mean_len=8_000, min_len=1_000, max_len=40_000, snp_rate=0.01, strain_indel_rate=0.0,
+                            err_sub=0.003, err_ins=0.001, err_del=0.001, rev_frac=0.5, name_prefix="r", block=25_000,
+                            workers=None):
+    """The recipe of simulate_reads for read sets of hundreds of thousands of reads (the full C4 / C5), written straight
+    to a 2-line FASTA by a pool of processes: strains, abundances, strain and length of every read come from the same
+    seeded stream as in simulate_reads; the per-read draws (position, errors, orientation) of block b of `block` reads
+    come from the stream seeded [seed, b + 1].  Deterministic for a given (seed, block).  Returns (n_reads, bases, strains)."""
+    import multiprocessing as mp
+    import os
+    import shutil
+    global _BLOCK_CTX
+    _, strains, strain_of, lens = _population(seed, n_strains, genome_len, n_reads, mean_len, min_len, max_len, snp_rate,
+                                              strain_indel_rate)
+    _BLOCK_CTX = (strains, strain_of, lens, (err_sub, err_ins, err_del, rev_frac, name_prefix))
+    jobs = [(b, lo, min(lo + block, n_reads), seed, f"{path}.part{b}") for b, lo in enumerate(range(0, n_reads, block))]
+    workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))
+    try:
+        with mp.get_context("fork").Pool(workers) as pool:
+            bases = sum(pool.map(_fasta_block, jobs, chunksize=1))
+    finally:
+        _BLOCK_CTX = None
+    with open(path, "wb") as out:
+        for _, _, _, _, part in jobs:
+            with open(part, "rb") as f:
+                shutil.copyfileobj(f, out, 16 << 20)
+            os.remove(part)
+    return n_reads, int(bases), strains
 
 
 def write_fasta(reads, path):

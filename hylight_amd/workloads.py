@@ -36,6 +36,9 @@ CONFIGS = {
 }
 
 
+PARALLEL_FROM = 200_000          # read sets from this size on are written by simulate_reads_to_fasta (per-block seeds)
+
+
 def c1_reads():
     """C1 (BASELINE.json configs[0]; the example files it names are not in the reference tree): C2's
     recipe at a tenth of its size - 1 000 long reads on 5 strains x 40 kb.  Run as `--corrected --nsplit 100 -t 8`."""
@@ -71,6 +74,10 @@ def describe(cfg):
 def make_long(cfg, path, seed=S.SEED_DEFAULT):
     """Writes the long reads as 2-line FASTA (what filter_non_atcg leaves, utils.py:81-114); returns
     (n_reads, n_bases, strains)."""
+    if cfg["sim"]["n_reads"] >= PARALLEL_FROM:      # the full C4 / C5: drawn by a pool of processes, never held in memory
+        n, bases, strains = S.simulate_reads_to_fasta(path + ".tmp", seed=seed, min_len=1_000, max_len=40_000, **cfg["sim"])
+        os.replace(path + ".tmp", path)
+        return n, bases, strains
     reads, strains = S.simulate_reads(seed=seed, min_len=1_000, max_len=40_000, **cfg["sim"])
     S.write_fasta(reads, path + ".tmp")
     os.replace(path + ".tmp", path)
