@@ -37,7 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-SLICES = {"C3": 8, "C5": 8, "C4": 64}            # slices of the --nsplit chunks a full pass is cut into (default 1)
+# slices of the --nsplit chunks a full pass is cut into (default 1).  C5: its 60 chunks one by one (slices 60..63 are empty;
+# a chunk of the full 500 000-read set is ~half a minute), C4: 1000 chunks in 64 slices, C4s: the two short-read calls of
+# the hybrid pipeline (script/HyLight.py:200,207) over C4's short reads, 8 slices each
+SLICES = {"C3": 8, "C5": 64, "C4": 64, "C4s": 8}
 
 KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_narrow", "align_wide": "hlmi::align_kernel",
                    "align_classify": "hlmi::classify_kernel", "seed_fill": "hlmi::seed_kernel<true>",
@@ -172,8 +175,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C3", choices=sorted(W.CONFIGS))
-    ap.add_argument("--scale", type=float, default=1.0, help="shrink reads and genomes together (quick checks; not a bench line)")
+    ap.add_argument("--workload", default="C3", choices=sorted(W.CONFIGS) + ["C4s"])
+    ap.add_argument("--scale", type=float, default=None,
+                    help="shrink reads and genomes together (quick checks; not a bench line).  Default 1, C4s: 0.1")
     ap.add_argument("--slices", type=int, default=0, help="slices of the --nsplit chunks per pass (0: workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -205,30 +209,53 @@ def main():
     rccl_ranks = dist.get_world_size() if world > 1 else 1
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    cfg = W.config(args.workload, args.scale)
+    short_calls = args.workload == "C4s"
+    if args.scale is None:
+        args.scale = 0.1 if short_calls else 1.0
+    cfg = W.config("C4" if short_calls else args.workload, args.scale)
     slices = args.slices or SLICES.get(args.workload, 1)
     if slices % world and slices > 1:
         raise SystemExit(f"--slices {slices} must be a multiple of the rank count {world}")
     shares = max(1, slices // world)                 # steps per complete pass
     work = os.environ.get("HL_BENCH_DIR") or tempfile.mkdtemp(prefix="hl_bench_")
     fa = os.path.join(work, f"{cfg['name']}.fa")
+    short_fa, con_fa, remain_fa = (os.path.join(work, f"{cfg['name']}.{x}.fa") for x in ("short", "contigs", "remain"))
     if rank == 0 and not os.path.exists(fa):
-        W.make_long(cfg, fa)
+        _, _, strains = W.make_long(cfg, fa)
+        if short_calls:
+            from hylight_amd import simulate as S
+            W.make_short(cfg, strains, short_fa)
+            # "polished long contigs" (HyLight.py:200): 40 kb pieces of every strain; "remaining short reads" (:207): the
+            # reads pick_up leaves over - here every fifth pair
+            contigs = [S.Read(f"longr_con_{k}_{a}", g[a:a + 40_000].copy(), None, k, a, a + 40_000, False)
+                       for k, g in enumerate(strains) for a in range(0, len(g) - 10_000, 40_000)]
+            S.write_fasta(contigs, con_fa)
+            with open(short_fa) as f, open(remain_fa, "w") as o:
+                for i, text in enumerate(f):
+                    if (i // 4) % 5 == 0:
+                        o.write(text)
     if world > 1:
         obj = [fa]
         dist.broadcast_object_list(obj, src=0)
         fa = obj[0]
         work = os.path.dirname(fa)          # every rank writes its part next to rank 0's files: rank 0 merges them
+        short_fa, con_fa, remain_fa = (os.path.join(work, f"{cfg['name']}.{x}.fa") for x in ("short", "contigs", "remain"))
         dist.barrier()
 
     from hylight_amd.stage import StageRunner
     t_open = time.time()
-    runner = StageRunner(fa, fa, cfg["nsplit"], long_mode=True, rank=rank, world=world)
+    if short_calls:
+        runners = [(StageRunner(short_fa, con_fa, cfg["nsplit"], long_mode=False, rank=rank, world=world), cfg["stage_short"]),
+                   (StageRunner(short_fa, remain_fa, cfg["nsplit"], long_mode=False, rank=rank, world=world), cfg["stage_short"])]
+    else:
+        runners = [(StageRunner(fa, fa, cfg["nsplit"], long_mode=True, rank=rank, world=world), cfg["stage"])]
+    runner = runners[0][0]
     torch.cuda.synchronize()
     t_open = time.time() - t_open           # FASTA parse + name ranks + host-to-device upload of the reads
     out_paf = os.path.join(work, "out.paf")         # N > 1: ranks write out.paf.part<rank>, rank 0 merges into out.paf
-    stage = cfg["stage"]
+    stage = runners[0][1]
     t_prepare = []
+    step_stats = {}
 
     def slice_paf(k):                       # every slice of a pass keeps its own file: together they are the stage output
         return out_paf if shares == 1 else f"{out_paf}.slice{k}"
@@ -236,9 +263,16 @@ def main():
     def step(i):
         if i % shares == 0:                 # a new pass over the read set: sketch + exchange are part of it
             t = time.time()
-            runner.prepare(force=True)
+            for rn, _ in runners:
+                rn.prepare(force=True)
             t_prepare.append(time.time() - t)
-        return runner.run(slice_paf(i % shares), share=(i % shares, shares), **stage)
+        n = 0
+        step_stats.clear()
+        for k, (rn, st) in enumerate(runners):
+            n += rn.run(slice_paf(i % shares) + (f".call{k}" if k else ""), share=(i % shares, shares), **st)
+            for key, v in api.last_stats().items():          # (C4s: the counts and kernel times of both calls of the step)
+                step_stats[key] = step_stats.get(key, 0.0) + v
+        return n
 
     def fence():
         if world > 1:
@@ -259,7 +293,7 @@ def main():
         step_s.append(time.time() - ts)
         step_rows.append(r)
         rows += r
-        stats = api.last_stats()
+        stats = dict(step_stats)
     fence()
     dt = time.time() - t0
     if world > 1:
@@ -323,7 +357,9 @@ def main():
                 launcher=(os.environ.get("HL_LAUNCHER", "external") if world > 1 else None),
                 steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                 scaling="weak" if slices > 1 else "strong", vs_baseline=None, dtype="u8/int32", data="synthetic",
-                config=dict(workload=W.describe(cfg), nsplit=cfg["nsplit"],
+                config=dict(workload=W.describe(cfg) + (" - the two short-read calls of script/HyLight.py:200,207 (short mode: reads vs 40 kb "
+                                                            "contig pieces, reads vs every fifth pair)" if short_calls else ""),
+                            nsplit=cfg["nsplit"],
                             step=(f"slice {slices} of the --nsplit chunks per pass; one step = {world} slice(s) "
                                   f"(chunk c: slice c % {slices}) x all queries; {shares} steps = one full pass"
                                   if slices > 1 else "one full pass"),
@@ -337,7 +373,7 @@ def main():
                          sketch_exchange_s=[round(x, 4) for x in t_prepare]),
                 stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})
     # second half of the BASELINE metric: overlap-graph build seconds (PAF on disk -> GFA on disk), not part of `value`
-    if not args.no_graph:
+    if not args.no_graph and not short_calls:
         try:
             if shares > 1:                  # the pass's output = the merge of its slices (utils.py:69)
                 have = [slice_paf(k) for k in range(shares) if os.path.exists(slice_paf(k))]
@@ -353,10 +389,11 @@ def main():
             line["graph_error"] = str(e)[:200]
     if os.environ.get("HL_BENCH_STATS"):
         sys.stderr.write("STATS " + json.dumps({k: round(v, 4) for k, v in sorted(stats.items())}) + "\n")
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not short_calls:
         line["cpu_baseline"] = cpu_baseline(fa, cfg)
     print(json.dumps(line), flush=True)
-    runner.close()
+    for rn, _ in runners:
+        rn.close()
     if world > 1:
         dist.destroy_process_group()
 

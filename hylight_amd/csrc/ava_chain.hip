@@ -350,7 +350,7 @@ struct ChainArgs {
     Piece *pieces;
     FixPt *fps;
     uint32_t cap_pieces, cap_fps;
-    uint32_t *counters;               // [0] pieces, [1] groups through the full DP, [2] overflow flag, [3] fixed points written, [4] linear groups
+    uint32_t *counters;               // [0] pieces, [1] groups through the full DP, [2] overflow flag, [3] fixed points written
     unsigned long long *prof;         // HLMI_CHAIN_PROF: wave cycles per phase [0] block loop [1] candidates + member lists [2] fixed points
     const uint8_t *check_ok;          // self-check (HLMI_CHAIN_DP16_CHECK): per group, 1 = chain_dp16_kernel claims equality;
     unsigned long long *check_bad;    //   the full DP then compares its scores / predecessors with fp and counts differences
@@ -398,8 +398,6 @@ __device__ __forceinline__ void flush_pieces(const ChainArgs &a, int lane, const
 // that hold another chain's anchor are masked and carry the coordinates of the member before them, which keeps the
 // coordinates monotone along the window for the successor search.  Returns false (nothing written) when the chain has
 // fewer than min_cnt members.
-// ALL: every anchor s .. peak belongs to the chain (a group that is one linear chain): no chain ids are read.
-template <bool ALL = false>
 __device__ bool emit_chain(const ChainArgs &a, size_t b, size_t g_first, long long g_step, int lane, int s, int peak_i,
                            uint32_t q, uint32_t t, uint32_t strand, uint32_t &n_pieces, uint32_t &n_fps, uint32_t fp_base,
                            Piece *buf, int &n_buf) {
@@ -427,7 +425,7 @@ __device__ bool emit_chain(const ChainArgs &a, size_t b, size_t g_first, long lo
     auto load_window = [&](int x0, int &te, int &qe, int &sp, int &rt) {
         te = qe = sp = 0; rt = -1;
         if (x0 + lane < end) {
-            rt = ALL ? s : a.root[b + (size_t)(x0 + lane)];
+            rt = a.root[b + (size_t)(x0 + lane)];
             anchor_fields(a, (size_t)((long long)g_first + g_step * (x0 + lane)), te, qe, sp);
             ++te; ++qe;
         }
@@ -450,7 +448,7 @@ __device__ bool emit_chain(const ChainArgs &a, size_t b, size_t g_first, long lo
         if (cnt < a.min_cnt) {                                 // (rare) the first window does not settle it: count on
             if (s + 64 < end) cnt += __popcll(__ballot(rt_n == s));
             for (int w0 = s + 128; w0 < end && cnt < a.min_cnt; w0 += 64)
-                cnt += __popcll(__ballot(w0 + lane < end && (ALL || a.root[b + (size_t)(w0 + lane)] == s)));
+                cnt += __popcll(__ballot(w0 + lane < end && a.root[b + (size_t)(w0 + lane)] == s));
             if (cnt < a.min_cnt) return false;
         }
     }
@@ -614,13 +612,10 @@ __device__ __forceinline__ void dp16_steps(Dp16State &z, const int *pen_tab, uin
 
 // the wave's four groups gorder[gi0 .. gi0 + 3], one per row of 16 lanes; pen_tab = the packed DP's table ((1 - cost) << 8,
 // entry bw + 1 rejecting).  Returns the row's verdict (the same in its 16 lanes).
-// Verdict per row (the same in its 16 lanes): 0 the full DP decides; 1 proven; 2 proven, and no chain of the group can reach
-// the minimum score (a chain scores at most its largest f): nobody needs to look at it again; 3 proven and LINEAR - every
-// anchor but the first has the anchor before it as its predecessor, so the group is one chain, cut at `peak` (first anchor
-// with the largest score): its bookkeeping (best children, chain ids, start records, peaks) is known without computing it.
-// STORE = false leaves fp alone (only the bookkeeping of a verdict-1 group reads it: the caller then runs the pass again).
-template <bool STORE>
-__device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, uint32_t *fp, int &peak) {
+// (Round 3, tried and dropped: a group in which every anchor's predecessor is the anchor before it is one chain and needs no
+// bookkeeping at all; with the scores kept out of memory for such groups the pass had to run twice for the others - and on C3
+// only 10 % of the groups are linear, a single stray anchor among ~390 breaks it: chain 190 -> 256 ms.)
+__device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, uint32_t *fp) {
     const int lane = threadIdx.x & 63, rl = lane & 15, row = lane >> 4;
     const size_t gi = gi0 + (size_t)row;
     // geometry of the row's group (uniform inside the row)
@@ -657,8 +652,7 @@ __device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, u
     const uint32_t lim4 = 4u * (uint32_t)a.max_gap, bw4 = 4u * (uint32_t)(a.bw + 1);
     int F1 = 0, F2 = 0, F3 = 0, F4 = 0, R1 = 0, R2 = 0, R3 = 0;    // scores of the four blocks before / their row maxima
     int gmax = 0;                                                  // largest score of the group
-    unsigned long long bad = 0, nonlin = 0;
-    peak = 0;
+    unsigned long long bad = 0;
     for (int i0 = 0; i0 < n_max; i0 += 16) {
         // every lane l holds anchor i0 + l here; N = the block after it, P = the one after that
         load_block(i0 + 32, P_t, P_q, P_s);                        // in flight during the block
@@ -671,10 +665,9 @@ __device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, u
         z.M_pk -= (z.M_pk & 255) != PK_NONE ? 16 : 0;
         const bool live = i0 + rl < n;
         const int O_f = live ? z.O_pk >> 8 : 0, O_st = z.O_pk & 255;
-        {
+        if (live) {
             const uint32_t off = O_st == PK_NONE ? 0u : (uint32_t)(rl + 16 - O_st);
-            if (STORE && live) fp[(size_t)((long long)g_first + g_step * (i0 + rl))] = (uint32_t)O_f << 5 | off;
-            nonlin |= __ballot(live && off != (i0 + rl ? 1u : 0u));
+            fp[(size_t)((long long)g_first + g_step * (i0 + rl))] = (uint32_t)O_f << 5 | off;
         }
         // far predecessors of lane l: block -4 lanes >= l, blocks -3 and -2, block -1 lanes < l
         {
@@ -686,19 +679,15 @@ __device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, u
             bad |= __ballot(live && far + cur_span > O_f);
             F4 = F3; F3 = F2; F2 = F1; F1 = O_f;
             R3 = R2; R2 = R1; R1 = row_lane<15>(row_max_u_incl_prefix(O_f));
-            if (R1 > gmax) {                                       // (first anchor of the row reaching the new maximum)
-                const uint32_t at = (uint32_t)(__ballot(live && O_f == R1) >> (16 * row)) & 0xffffu;
-                peak = i0 + __ffs((int)at) - 1;
-            }
             gmax = gmax > R1 ? gmax : R1;
         }
         // the block after next moves up
         z.N_t = P_t; z.N_q = P_q; z.N_s = P_s;
     }
     const unsigned long long mine = (bad >> (16 * row)) & 0xffffull;
-    if (mine) return 0;
-    if (gmax < a.min_score || n == 0) return 2;
-    return ((nonlin >> (16 * row)) & 0xffffull) ? 1 : 3;
+    // 1: proven.  2: proven, and no chain of the group can reach the minimum score (a chain scores at most its largest
+    // f): nobody needs to look at it again.  0: the full DP decides.
+    return mine ? 0 : (gmax < a.min_score || n == 0 ? 2 : 1);
 }
 
 
@@ -711,9 +700,7 @@ __global__ __launch_bounds__(64 * D16_WAVES) void chain_dp16_kernel(ChainArgs a,
     }
     __syncthreads();
     const size_t gi0 = ((size_t)blockIdx.x * D16_WAVES + (threadIdx.x >> 6)) * 4;
-    int peak;
-    int verdict = dp16_groups<true>(a, pen_tab, gi0, fp, peak);
-    verdict = verdict == 3 ? 1 : verdict;
+    const int verdict = dp16_groups(a, pen_tab, gi0, fp);
     const int lane = threadIdx.x & 63;
     if ((lane & 15) == 0 && gi0 + (size_t)(lane >> 4) < a.n_list) gok[gi0 + (size_t)(lane >> 4)] = (uint8_t)verdict;
 }
@@ -743,57 +730,30 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     const size_t g_lo = ((size_t)blockIdx.x * CHAIN_WAVES + (threadIdx.x >> 6)) * CHAIN_GROUPS;
     const size_t g_hi = g_lo + CHAIN_GROUPS < a.n_list ? g_lo + CHAIN_GROUPS : a.n_list;
     uint32_t wave_fps = 0;                                 // fixed points actually written by this wave (statistics)
-    int verdict16 = 0, peak16 = 0;
+    int verdict16 = 0;
     if constexpr (MODE == 2) {
         static_assert(CHAIN_GROUPS == 4, "one group per row of 16 lanes");
-        if (g_lo < a.n_list) {
-            // first without storing scores and predecessors: a linear group (verdict 3) needs neither, and on read sets
-            // nearly every group is one; a wave that holds a proven group with more structure runs the pass again, storing
-            verdict16 = dp16_groups<false>(a, (const int *)pen_tab, g_lo, a.fp, peak16);
-            if (__ballot(verdict16 == 1)) {
-                int again;
-                const int v2 = dp16_groups<true>(a, (const int *)pen_tab, g_lo, a.fp, again);
-                (void)v2;
-                __builtin_amdgcn_s_waitcnt(0);             // fp is read back by this wave below
-                __threadfence_block();
-            }
-        } else verdict16 = 2;
+        verdict16 = g_lo < a.n_list ? dp16_groups(a, (const int *)pen_tab, g_lo, a.fp) : 2;
+        __builtin_amdgcn_s_waitcnt(0);                     // fp is read back by this wave below
+        __threadfence_block();
         if (lane == 0) {
-            uint32_t n_full = 0, n_lin = 0;
-            for (int r = 0; r < 4; ++r) {
-                const int vd = __builtin_amdgcn_readlane(verdict16, 16 * r);
-                n_full += g_lo + (size_t)r < g_hi && vd == 0 ? 1u : 0u;
-                n_lin += g_lo + (size_t)r < g_hi && vd == 3 ? 1u : 0u;
-            }
+            uint32_t n_full = 0;
+            for (int r = 0; r < 4; ++r) n_full += g_lo + (size_t)r < g_hi && __builtin_amdgcn_readlane(verdict16, 16 * r) == 0 ? 1u : 0u;
             if (n_full) atomicAdd(&a.counters[1], n_full);
-            if (n_lin) atomicAdd(&a.counters[4], n_lin);
         }
     }
     for (size_t gi = g_lo; gi < g_hi; ++gi) {
-        bool use_pre = false, linear = false;
+        bool use_pre = false;
         if constexpr (MODE == 2) {
             const int vd = __builtin_amdgcn_readlane(verdict16, 16 * (int)(gi - g_lo));
             if (vd == 2) continue;
             use_pre = vd == 1;
-            linear = vd == 3;
         }
         const size_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gorder[gi]);
         const size_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g]);
         const size_t e = g + 1 < a.n_groups ? (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g + 1]) : a.n_anchors;
         const int n = (int)(e - b);
         if (n < a.min_cnt) continue;
-        if (MODE == 2 && linear) {
-            // one chain: starts at anchor 0 (no parent: base score 0; its largest score reaches the minimum, or the verdict
-            // would be 2), every anchor is the best - the only - child of the one before, the chain is cut at the peak
-            const uint64_t key0 = group_word(a, b);
-            const uint32_t strand = (uint32_t)key0 & 1u;
-            uint32_t np = 0, nf = 0;
-            emit_chain<true>(a, b, strand ? b + (size_t)n - 1 : b, strand ? -1 : 1, lane, 0,
-                             __builtin_amdgcn_readlane(peak16, 16 * (int)(gi - g_lo)), a.q_lo + (uint32_t)(key0 >> (a.tb + 1)),
-                             (uint32_t)(key0 >> 1) & ((1u << a.tb) - 1), strand, np, nf, 2u * (uint32_t)b, pbuf, n_pbuf);
-            wave_fps += nf;
-            continue;
-        }
         // ---- DP ---------------------------------------------------------------------------------------------------
         // "Push" form of the recurrence: lane l holds the anchor with index = l mod 64 among the 64 that FOLLOW the
         // anchor j being finished (M_*: position, span, best score so far + 1 / best predecessor).  Step j reads the
@@ -1348,7 +1308,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     out.n_pieces = hc[0];
     out.n_fp = hc[3];
     stat_add("chain_groups_full_dp", (double)hc[1]);
-    stat_add("chain_groups_linear", (double)hc[4]);
+
 }
 
 }  // namespace hlmi
