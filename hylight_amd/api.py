@@ -67,6 +67,7 @@ SYMBOLS = {
     "hlmi_job_sketch_bound": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64]),
     "hlmi_job_sketch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.POINTER(C.c_int64)]),
+    "hlmi_job_sketch_own": (C.c_int, [C.c_void_p]),
     "hlmi_job_set_query_sketch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hlmi_job_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_char_p]),
     "hlmi_last_stats_json": (C.c_int, [C.c_char_p, C.c_int64]),
@@ -262,6 +263,9 @@ class Job:
         n = C.c_int64(0)
         _check(load().hlmi_job_sketch(self._h, lo, hi, dev_mz_ptr, cap, dev_counts_ptr, C.byref(n)))
         return n.value
+
+    def sketch_own(self):
+        _check(load().hlmi_job_sketch_own(self._h))
 
     def set_query_sketch(self, dev_mz_ptr, n, dev_counts_ptr):
         _check(load().hlmi_job_set_query_sketch(self._h, dev_mz_ptr, n, dev_counts_ptr))

@@ -1459,16 +1459,35 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
             uint32_t tot_runs, tot_mrg;
             const uint32_t S = wave_excl_sum_u32(nr, lane, tot_runs);
             const uint32_t Mx = wave_excl_sum_u32(mrg ? 1u : 0u, lane, tot_mrg);
-            if (WRITE && nr) {
+            if (WRITE && tot_runs) {
+                // The runs of the step's 64 tasks are copied by all lanes together, flat index f = 0 .. tot_runs - 1 (a lane per
+                // task ran as long as the task with the most runs, every lane on its own cache lines): the owner of f is the
+                // last lane whose first run is at or before f (tasks without runs share their successor's start), found
+                // by a 6-step search over the lanes' prefix sums; run x of a task goes to slot base + x, where base already
+                // points at the previous task's last slot when the first run merges with it.
                 const uint32_t base = slots + S - (Mx + (mrg ? 1u : 0u));
-                for (uint32_t x = 0; x < nr; ++x) {
-                    const uint32_t run = x == 0 ? first : (x == nr - 1 ? last : a.runs[r.runs_off + x]);
-                    const uint32_t len = run >> 4;
-                    blen += len;
-                    if ((run & 15u) == OP_EQ) nmatch += len;
-                    if (x == 0 && mrg) atomicAdd(&w[base], len << 4);
-                    else if (x == 0 || x == nr - 1) atomicAdd(&w[base + x], run);
-                    else w[base + x] = run;
+                for (uint32_t f0 = 0; f0 < tot_runs; f0 += 64) {
+                    const uint32_t f = f0 + (uint32_t)lane;
+                    int lo_l = 0, hi_l = 63;                   // largest lane with S <= f
+#pragma unroll
+                    for (int rd = 0; rd < 6; ++rd) {
+                        const int mid = (lo_l + hi_l + 1) >> 1;
+                        const uint32_t sm = (uint32_t)__shfl((int)S, mid, 64);
+                        if (sm <= f) lo_l = mid; else hi_l = mid - 1;
+                    }
+                    const uint32_t oS = (uint32_t)__shfl((int)S, lo_l, 64), onr = (uint32_t)__shfl((int)nr, lo_l, 64);
+                    const uint32_t osrc = (uint32_t)__shfl((int)r.runs_off, lo_l, 64), obase = (uint32_t)__shfl((int)base, lo_l, 64);
+                    const bool omrg = __shfl((int)mrg, lo_l, 64) != 0;
+                    if (f < tot_runs) {
+                        const uint32_t x = f - oS;
+                        const uint32_t run = a.runs[osrc + x];
+                        const uint32_t len = run >> 4;
+                        blen += len;
+                        if ((run & 15u) == OP_EQ) nmatch += len;
+                        if (x == 0 && omrg) atomicAdd(&w[obase], len << 4);
+                        else if (x == 0 || x == onr - 1) atomicAdd(&w[obase + x], run);
+                        else w[obase + x] = run;
+                    }
                 }
             }
             slots += tot_runs - tot_mrg;

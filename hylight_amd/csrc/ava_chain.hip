@@ -206,7 +206,39 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
                 return l;
             };
             uint32_t c = 0;
-            if (a.pair_once) {                                   // only partners that rank above the query
+            constexpr int BK = 16;                               // a bucket of up to BK words is fetched whole
+            if (a.rb && b_hi - b_lo <= (size_t)BK) {
+                // The searches below are chains of dependent 8-byte loads into the same one or two cache lines (the
+                // kernel waited on them 96 % of its time).  The bucket's words are requested together instead and
+                // counted in registers: entries below (key, r) = words below key << rb | r.
+                const int nb = (int)(b_hi - b_lo);
+                uint64_t w[BK];
+#pragma unroll
+                for (int k = 0; k < BK; ++k) w[k] = k < nb ? a.ick[b_lo + (size_t)k] : ~0ull;
+                auto below = [&](uint64_t want) {
+                    int n = 0;
+#pragma unroll
+                    for (int k = 0; k < BK; ++k) n += (k < nb && w[k] < want) ? 1 : 0;
+                    return (size_t)n;
+                };
+                auto upto_key = [&]() {                          // entries with hash <= key (no key + 1: it may not fit)
+                    int n = 0;
+#pragma unroll
+                    for (int k = 0; k < BK; ++k) n += (k < nb && (w[k] >> a.rb) <= key) ? 1 : 0;
+                    return (size_t)n;
+                };
+                hi = b_lo + upto_key();
+                if (a.pair_once) {
+                    lo = b_lo + below(key << a.rb | (uint64_t)(rq + 2));
+                    lo = lo < hi ? lo : hi;
+                    c = (uint32_t)(hi - lo);
+                } else {
+                    lo = b_lo + below(key << a.rb | 1u);
+                    size_t e0 = b_lo + below(key << a.rb | (uint64_t)(rq + 1)), e1 = b_lo + below(key << a.rb | (uint64_t)(rq + 2));
+                    lo = lo < hi ? lo : hi; e0 = e0 < hi ? e0 : hi; e1 = e1 < hi ? e1 : hi;
+                    c = (uint32_t)((hi - lo) - (e1 - e0));
+                }
+            } else if (a.pair_once) {                            // only partners that rank above the query
                 lo = first_ge(b_lo, key, rq + 2);
                 hi = first_ge(lo, key + 1, 0u);
                 c = (uint32_t)(hi - lo);

@@ -328,6 +328,12 @@ int hlmi_job_sketch(hlmi_job *j, int64_t lo, int64_t hi, void *dev_mz, int64_t c
         *n_out = reinterpret_cast<Job *>(j)->sketch_range(lo, hi, dev_mz, cap, dev_counts);
     });
 }
+int hlmi_job_sketch_own(hlmi_job *j) {
+    return guarded([&] {
+        if (!j) fail(HLMI_EINVAL, "hlmi_job_sketch_own: NULL job");
+        reinterpret_cast<Job *>(j)->sketch_all_queries();
+    });
+}
 int hlmi_job_set_query_sketch(hlmi_job *j, const void *dev_mz, int64_t n, const void *dev_counts) {
     return guarded([&] {
         if (!j || !dev_mz || !dev_counts) fail(HLMI_EINVAL, "hlmi_job_set_query_sketch: NULL argument");

@@ -123,8 +123,10 @@ void *dev_alloc(size_t bytes) {
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {                                // out of memory: drop the cache and retry once
-        dev_pool_trim();
+        (void)hipGetLastError();                          // (the failed call stays "the last error" until it is read: a later
+        dev_pool_trim();                                  //  HIP_CHECK(hipGetLastError()) after a kernel launch would report it)
         e = hipMalloc(&p, want);
+        if (e != hipSuccess) (void)hipGetLastError();
     }
     if (e != hipSuccess) fail(HLMI_ENOMEM, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
     g_block_size[p] = want;

@@ -42,8 +42,14 @@ class StageRunner:
         later passes (`run`) reuse it unless `force`."""
         if self._keep is not None and not force:
             return
-        import torch
         job, world, rank, dev = self.job, self.world, self.rank, self.device
+        if world == 1 and hasattr(job, "sketch_own"):
+            # one rank: nothing to exchange - the job sketches into buffers of its own, sized exactly (a caller buffer needs
+            # room for the bound, one 16-byte entry per base: 80 GB for C5's 5 Gbases)
+            job.sketch_own()
+            self._keep = ()
+            return
+        import torch
         nq = job.num_queries
         lo, hi = rank * nq // world, (rank + 1) * nq // world
         cap = max(job.sketch_bound(lo, hi), 1)

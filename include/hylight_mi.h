@@ -185,6 +185,9 @@ int64_t   hlmi_job_sketch_bound(const hlmi_job *j, int64_t lo, int64_t hi);
 int       hlmi_job_sketch(hlmi_job *j, int64_t lo, int64_t hi, void *dev_mz, int64_t cap,
                           void *dev_counts, int64_t *n_out);
 /* install the complete query sketch (all reads, read-major): dev_mz[n] + dev_counts[nq] */
+/* single-GPU form of the two calls around it: sketches ALL query reads into buffers of the job's own, sized exactly
+ * (hlmi_job_sketch needs room for the bound - one entry per base - which is 80 GB for 5 Gbases of reads), and installs them */
+int       hlmi_job_sketch_own(hlmi_job *j);
 int       hlmi_job_set_query_sketch(hlmi_job *j, const void *dev_mz, int64_t n, const void *dev_counts);
 /* overlap + filter the chunks {c : c % world == rank}; writes the rank's score-sorted PAF */
 int       hlmi_job_run(hlmi_job *j, int rank, int world, int len_over, int mc, double iden,
