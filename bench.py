@@ -100,50 +100,65 @@ def cpu_baseline(fa, cfg, budget_s=25.0):
     import multiprocessing as mp
     from oracle import filters as F
     stage = cfg["stage"]
-    n_lines = 2 * cfg["sim"]["n_reads"]
-    ranges = F.chunk_ranges(n_lines, cfg["nsplit"])
-    cores = min(len(os.sched_getaffinity(0)), 32, len(ranges))
+    n_reads = cfg["sim"]["n_reads"]
+    ranges = F.chunk_ranges(2 * n_reads, cfg["nsplit"])
+    cores = min(len(os.sched_getaffinity(0)), 32)
     tmp = tempfile.mkdtemp(prefix="hl_cpu_")
     mm2 = shutil.which("minimap2")
     n_t = 2
-    order = [(i * len(ranges)) // cores + k for k in range(max(1, len(ranges) // cores)) for i in range(cores)]
-    order = [c for c in dict.fromkeys(order) if c < len(ranges)]          # round k takes chunk k of every core's stripe
+    # A process per (sampled chunk, slice of the query file): the rows of a chunk against a slice of the queries do not
+    # depend on the other slices, so the chunk's candidate rows are the slices' rows in file order - and one sketch pass
+    # over the 100 000 queries (which every per-chunk process of the reference repeats) is spread over PARTS cores.
+    parts = max(1, min(8, cores, n_reads // 2000))
+    per_round = max(1, cores // parts)                 # chunks worked on at a time
+    qparts = []
+    with open(fa) as src:
+        for p in range(parts):
+            qp = os.path.join(tmp, f"q{p}.fa")
+            with open(qp, "w") as dst:
+                for _ in range(2 * (n_reads * (p + 1) // parts - n_reads * p // parts)):
+                    dst.write(src.readline())
+            qparts.append(qp)
+    order = [(i * len(ranges)) // per_round + k for k in range(max(1, len(ranges) // per_round)) for i in range(per_round)]
+    order = [c for c in dict.fromkeys(order) if c < len(ranges)]          # round k takes chunk k of every stripe of the file
     want = {}
-    for i in order:
+    for i in order[:64 * per_round]:
         lo, hi = ranges[i]
         for l in range(lo, min(hi, lo + 2 * n_t)):
             want[l] = i
-    tl = {i: [] for i in order}
+    tl = {}
     with open(fa) as f:
         for l, text in enumerate(f):
             if l in want:
-                tl[want[l]].append(text.rstrip("\n"))
+                tl.setdefault(want[l], []).append(text.rstrip("\n"))
     t0 = time.time()
     done, rows, cand = 0, 0, 0
-    jobs = [(fa, tl[i], os.path.join(tmp, f"c{i}"), stage, mm2) for i in order]
-    with mp.get_context("fork").Pool(cores) as pool:
+    with mp.get_context("fork").Pool(per_round * parts) as pool:
         nxt = 0
-        while nxt < len(jobs) and (done == 0 or (time.time() - t0) * (1 + cores / max(done, 1)) < budget_s):
-            batch = jobs[nxt:nxt + cores]
-            for r, c in pool.map(_cpu_chunk, batch):
-                rows += r
-                cand += c
+        while nxt < len(order) and order[nxt] in tl and (done == 0 or (time.time() - t0) * (1 + per_round / max(done, 1)) < budget_s):
+            batch = [c for c in order[nxt:nxt + per_round] if c in tl]
+            jobs = [(qparts[p], tl[c], os.path.join(tmp, f"c{c}_{p}"), mm2) for c in batch for p in range(parts)]
+            raw = pool.map(_cpu_chunk_part, jobs)
+            for k, c in enumerate(batch):
+                chunk_rows = [r for part in raw[k * parts:(k + 1) * parts] for r in part]
+                cand += len(chunk_rows)
+                rows += len(F.worker(chunk_rows, True, stage["len_over"], stage["mc"], stage["iden"]))
             done += len(batch)
-            nxt += len(batch)
+            nxt += per_round
     dt = time.time() - t0
     shutil.rmtree(tmp, ignore_errors=True)
     what = ("minimap2 (the command of filter_overlap_slr2.py:51, -t 1 per process) + oracle filters for the count"
             if mm2 else "oracle overlapper + oracle filters")
-    return dict(value=rows / dt, unit="overlaps/s", candidate_rows_per_s=cand / dt, cores=cores, kind="reference" if mm2 else "port",
-                sample=f"first {n_t} target reads of {done} of the {len(ranges)} --nsplit chunks x all {cfg['sim']['n_reads']} queries "
-                       f"(full pile-up depth per sampled target), {what}, one process per core, {dt:.1f} s wall; compare "
-                       f"candidate_rows_per_s with config.candidate_rows_per_s - `value` is the filter's keep on this sample, "
-                       f"not the same quantity as the GPU value")
+    return dict(value=rows / dt, unit="overlaps/s", candidate_rows_per_s=cand / dt, cores=min(cores, per_round * parts),
+                kind="reference" if mm2 else "port",
+                sample=f"first {n_t} target reads of {done} of the {len(ranges)} --nsplit chunks x all {n_reads} queries "
+                       f"(full pile-up depth per sampled target; a chunk's queries in {parts} slices, one process each), {what}, "
+                       f"{dt:.1f} s wall; compare candidate_rows_per_s with config.candidate_rows_per_s - `value` is the filter's "
+                       f"keep on this sample, not the same quantity as the GPU value")
 
 
-def _cpu_chunk(args):
-    qfa, tlines, base, stage, mm2 = args
-    from oracle import filters as F
+def _cpu_chunk_part(args):
+    qfa, tlines, base, mm2 = args
     with open(base + ".fa", "w") as f:
         f.write("\n".join(tlines) + "\n")
     if mm2:        # script/filter_overlap_slr2.py:51
@@ -153,8 +168,7 @@ def _cpu_chunk(args):
     else:
         from oracle import ava as OA
         OA.ava(base + ".fa", qfa, base + ".paf")
-    raw = open(base + ".paf").read().split("\n")[:-1]
-    return len(F.worker(raw, True, stage["len_over"], stage["mc"], stage["iden"])), len(raw)
+    return open(base + ".paf").read().split("\n")[:-1]
 
 
 # ---- algorithmic bytes of the whole stage from the counts of one step -------------------------------

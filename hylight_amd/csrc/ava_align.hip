@@ -49,8 +49,10 @@ struct TaskOut {            // 24 B
     int32_t score;
     int32_t bi, bj;         // extension: rows / cols consumed
     uint32_t runs_off, n_runs;
-    uint32_t pad;
+    uint32_t pad;           // bits 0-3 / 4-7: CIGAR code of the first / last run (the assembly decides the merges of neighbouring
+                            // tasks from these without touching the runs); bit 31: extension that reached the query end
 };
+__device__ __forceinline__ uint32_t end_codes(uint32_t first_run, uint32_t last_run) { return (first_run & 15u) | (last_run & 15u) << 4; }
 
 __global__ void piece_task_count_kernel(const Piece *pieces, size_t n, uint32_t *cnt) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             if (ok) for (uint32_t q = 0; q < nr; ++q) a.runs[base + mine + q] = runs[q];
             const bool ext = (tk.kind & 3) != 0;              // extensions report the cell they stop in
             const int L = m < n ? m : n;
-            a.out[ti] = TaskOut{fast_score, ext ? L : m, ext ? L : n, base + mine, ok ? nr : 0, 1u | ext_flag};
+            a.out[ti] = TaskOut{fast_score, ext ? L : m, ext ? L : n, base + mine, ok ? nr : 0, (nr ? end_codes(runs[0], runs[nr - 1]) : 0u) | ext_flag};
         } else if (live && c == 0) {
             a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
         }
@@ -727,11 +729,14 @@ struct WalkScore {                          // score of the walked path from its
 // runs copied out by the whole group; with `out` (second walk of a longer task) they are written to
 // out[total-1 .. 0].  Every iteration consumes at least one row or column, so m + n + 1 bounds the trip count; the
 // cap only guards a corrupted plane.
+// `ends` receives end_codes(first run, last run) of the forward order.
 __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t total, uint32_t *buf = nullptr, uint32_t cap = 0,
-                                WalkScore *ws = nullptr) {
+                                WalkScore *ws = nullptr, uint32_t *ends = nullptr) {
     int i = w.m, j = w.n, state = 0;
-    uint32_t cur_op = OP_EQ, cur_len = (uint32_t)w.trim, n_runs = 0;
+    uint32_t cur_op = OP_EQ, cur_len = (uint32_t)w.trim, n_runs = 0, e_first = 0, e_last = 0;
     auto put = [&]() {
+        if (!n_runs) e_first = cur_op;
+        e_last = cur_op;
         if (out) out[w.keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op;
         else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
         ++n_runs;
@@ -783,6 +788,7 @@ __device__ uint32_t narrow_walk(const NarrowWalk &w, uint32_t *out, uint32_t tot
         else { if (cur_len) put(); cur_op = op; cur_len = len; }
     }
     if (cur_len) put();
+    if (ends) *ends = w.keep_order ? end_codes(e_first, e_last) : end_codes(e_last, e_first);
     return n_runs;
 }
 constexpr int RUN_BUF_NARROW = 48, RUN_BUF_WIDE = 128;   // runs kept in LDS by the first walk (per task)
@@ -904,7 +910,8 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
         uint32_t cp_n = 0, cp_off = 0;                          // runs the group copies out of LDS
         if (live && l == 0) {
             const NarrowWalk w{&pl[0][0][0], NR_CHUNKS, g * 16, m, n, dlo, NARROW_W - 1, false, tk.trim};
-            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap);
+            uint32_t ends = 0;
+            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap, nullptr, &ends);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
@@ -912,7 +919,7 @@ __global__ __launch_bounds__(WG) void align_narrow_kernel(AlignArgs a) {
                 if (n_runs <= rcap) { cp_n = n_runs; cp_off = off; }
                 else narrow_walk(w, a.runs + off, n_runs);
             }
-            a.out[ti] = TaskOut{score, m, n, off, ok ? n_runs : 0, 2u | (uint32_t)m << 2};
+            a.out[ti] = TaskOut{score, m, n, off, ok ? n_runs : 0, ends};
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -1106,7 +1113,8 @@ __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArg
         if (walker) {
             const NarrowWalk w{&s_pl[wv][0][0][0][0] + hf * (N_PLANES * NR_CHUNKS * 64), NR_CHUNKS, g * 16, wm, wn, wd, NARROW_W - 1, false, wtrim};
             WalkScore ws{a.match, a.mismatch, a.go, a.ge, 0};
-            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap, &ws);
+            uint32_t ends = 0;
+            const uint32_t n_runs = narrow_walk(w, nullptr, 0, rbuf, rcap, &ws, &ends);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok, RUN_CHUNK_SMALL);
@@ -1115,7 +1123,7 @@ __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArg
                 else narrow_walk(w, a.runs + off, n_runs);
             }
             const int score = amb ? (hf ? endB : endA) + a.match * wtrim : ws.total;
-            a.out[hf ? tiB : tiA] = TaskOut{score, wm, wn, off, ok ? n_runs : 0, 2u | (uint32_t)wm << 2};
+            a.out[hf ? tiB : tiA] = TaskOut{score, wm, wn, off, ok ? n_runs : 0, ends};
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -1226,11 +1234,13 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
 // reverse, the first `cap` kept in `buf`, with `out` written to out[total-1 .. 0] (left extensions in emission order).
 template <bool TWO>
 __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, int dlo, bool keep_order, uint32_t *out, uint32_t total,
-                              uint32_t *buf, uint32_t cap) {
+                              uint32_t *buf, uint32_t cap, uint32_t *ends = nullptr) {
     auto word = [&](int plane, int c, int lane) { return pl[(plane * chunks + c) * 64 + lane]; };
     int i = m0, j = n0, state = 0;                    // state: 0 H, 1 E1, 2 F1, 3 E2, 4 F2
-    uint32_t cur_op = 0, cur_len = 0, n_runs = 0;
+    uint32_t cur_op = 0, cur_len = 0, n_runs = 0, e_first = 0, e_last = 0;
     auto put = [&]() {
+        if (!n_runs) e_first = cur_op;
+        e_last = cur_op;
         if (out) out[keep_order ? n_runs : total - 1 - n_runs] = cur_len << 4 | cur_op;
         else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
         ++n_runs;
@@ -1281,6 +1291,7 @@ __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, in
         else { if (cur_len) put(); cur_op = op; cur_len = len; }
     }
     if (cur_len) put();
+    if (ends) *ends = keep_order ? end_codes(e_first, e_last) : end_codes(e_last, e_first);
     return n_runs;
 }
 
@@ -1370,8 +1381,9 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         uint32_t cp_n = 0, cp_off = 0;
         if (lane == 0) {
             const uint32_t *planes = &pl[0][0][0];
-            const uint32_t n_runs = two ? wide_walk<true>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, nullptr, 0, rbuf, rcap)
-                                        : wide_walk<false>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, nullptr, 0, rbuf, rcap);
+            uint32_t ends = 0;
+            const uint32_t n_runs = two ? wide_walk<true>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, nullptr, 0, rbuf, rcap, &ends)
+                                        : wide_walk<false>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, nullptr, 0, rbuf, rcap, &ends);
             uint32_t off = 0;
             bool ok = true;
             if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
@@ -1380,8 +1392,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
                 else if (two) wide_walk<true>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, a.runs + off, n_runs, nullptr, 0);
                 else wide_walk<false>(planes, W_CHUNKS, ei, ej, dlo, kind == 1, a.runs + off, n_runs, nullptr, 0);
             }
-            a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0,
-                                2u | ((uint32_t)m & 0xfffffu) << 2 | (kind != 0 && ei == end_row ? 0x80000000u : 0u)};
+            a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0, ends | (kind != 0 && ei == end_row ? 0x80000000u : 0u)};
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -1448,8 +1459,7 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
             if (keep && t == n_tasks - 1 && t != 0) { ext_r_i = r.bi; ext_r_j = r.bj; }
             long long sc = keep ? r.score : 0;
             const uint32_t nr = keep ? r.n_runs : 0;
-            uint32_t first = 0, last = 0;
-            if (nr) { first = a.runs[r.runs_off]; last = nr > 1 ? a.runs[r.runs_off + nr - 1] : first; }
+            const uint32_t first = r.pad & 15u, last = (r.pad >> 4) & 15u;     // codes of the first / last run (TaskOut::pad)
             const unsigned long long ne_mask = __ballot(nr != 0);
             const unsigned long long below = ne_mask & ((1ull << lane) - 1ull);
             const int prev_lane = below ? 63 - __clzll((long long)below) : 0;
@@ -1459,35 +1469,18 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
             uint32_t tot_runs, tot_mrg;
             const uint32_t S = wave_excl_sum_u32(nr, lane, tot_runs);
             const uint32_t Mx = wave_excl_sum_u32(mrg ? 1u : 0u, lane, tot_mrg);
-            if (WRITE && tot_runs) {
-                // The runs of the step's 64 tasks are copied by all lanes together, flat index f = 0 .. tot_runs - 1 (a lane per
-                // task ran as long as the task with the most runs, every lane on its own cache lines): the owner of f is the
-                // last lane whose first run is at or before f (tasks without runs share their successor's start), found
-                // by a 6-step search over the lanes' prefix sums; run x of a task goes to slot base + x, where base already
-                // points at the previous task's last slot when the first run merges with it.
+            if (WRITE && nr) {
+                // (tried in round 3: all lanes copying the step's runs together by flat index, owner found by a search over the
+                //  prefix sums - 59 -> 134 ms: most tasks have one to three runs, the search costs more than the loop it removes)
                 const uint32_t base = slots + S - (Mx + (mrg ? 1u : 0u));
-                for (uint32_t f0 = 0; f0 < tot_runs; f0 += 64) {
-                    const uint32_t f = f0 + (uint32_t)lane;
-                    int lo_l = 0, hi_l = 63;                   // largest lane with S <= f
-#pragma unroll
-                    for (int rd = 0; rd < 6; ++rd) {
-                        const int mid = (lo_l + hi_l + 1) >> 1;
-                        const uint32_t sm = (uint32_t)__shfl((int)S, mid, 64);
-                        if (sm <= f) lo_l = mid; else hi_l = mid - 1;
-                    }
-                    const uint32_t oS = (uint32_t)__shfl((int)S, lo_l, 64), onr = (uint32_t)__shfl((int)nr, lo_l, 64);
-                    const uint32_t osrc = (uint32_t)__shfl((int)r.runs_off, lo_l, 64), obase = (uint32_t)__shfl((int)base, lo_l, 64);
-                    const bool omrg = __shfl((int)mrg, lo_l, 64) != 0;
-                    if (f < tot_runs) {
-                        const uint32_t x = f - oS;
-                        const uint32_t run = a.runs[osrc + x];
-                        const uint32_t len = run >> 4;
-                        blen += len;
-                        if ((run & 15u) == OP_EQ) nmatch += len;
-                        if (x == 0 && omrg) atomicAdd(&w[obase], len << 4);
-                        else if (x == 0 || x == onr - 1) atomicAdd(&w[obase + x], run);
-                        else w[obase + x] = run;
-                    }
+                for (uint32_t x = 0; x < nr; ++x) {
+                    const uint32_t run = a.runs[r.runs_off + x];
+                    const uint32_t len = run >> 4;
+                    blen += len;
+                    if ((run & 15u) == OP_EQ) nmatch += len;
+                    if (x == 0 && mrg) atomicAdd(&w[base], len << 4);
+                    else if (x == 0 || x == nr - 1) atomicAdd(&w[base + x], run);
+                    else w[base + x] = run;
                 }
             }
             slots += tot_runs - tot_mrg;
