@@ -383,6 +383,7 @@ def main():
                 roofline=roof,
                 # the drop-in call's view: FASTA parsing + upload of the reads + sketch/exchange + one full pass
                 value_e2e=pass_rows / (t_open + pass_s) if pass_s > 0 else None,
+                step_ms=[round(1e3 * x, 1) for x in step_s],
                 e2e=dict(open_parse_upload_s=round(t_open, 3), pass_s=round(pass_s, 3), pass_overlaps=int(pass_rows),
                          sketch_exchange_s=[round(x, 4) for x in t_prepare]),
                 stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})

@@ -1822,7 +1822,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     DBuf<uint32_t> tcnt(P), toff(P);
     hipLaunchKernelGGL(piece_task_count_kernel, dim3((unsigned)cdiv(P, (size_t)256)), dim3(256), 0, stream(), ch.pieces.p, P, tcnt.p);
     exclusive_scan_u32(tcnt.p, toff.p, P);
-    const size_t n_spans = cdiv(NT, span_tasks);
+    const size_t n_spans = (NT + span_tasks - 1) / span_tasks;
     size_t p0 = 0, t0 = 0;                       // first piece / first task of the span
     for (size_t k = 1; k <= n_spans && p0 < P; ++k) {
         size_t p1 = P, t1 = NT;

@@ -152,7 +152,13 @@ T download_one(const T *dev) {
     return *slot;
 }
 
-inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+// blocks of b work-items for a items.  A launch holds fewer than 2^32 work-items per dimension: callers with more than that
+// many items launch in slabs (sketch.hip:finish_upload); anything else here is a bug, reported instead of wrapped.
+inline unsigned cdiv(size_t a, size_t b) {
+    const size_t n = (a + b - 1) / b;
+    if (n * b >= (1ull << 32) && b > 1) fail(HLMI_EINVAL, "kernel grid of %zu x %zu work-items (2^32 and more wrap)", n, b);
+    return (unsigned)n;
+}
 
 // ------------------------------------------------------------------------------------------
 // PAF row as the kernels see it (one 64-byte record; rows keep stream order by index)

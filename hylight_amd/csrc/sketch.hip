@@ -197,7 +197,13 @@ static void finish_upload(const char *bases, const std::vector<uint64_t> &off, D
     out.alloc_codes();
     if (out.total) {
         HIP_CHECK(hipMemcpyAsync(out.codes(), bases, out.total, hipMemcpyHostToDevice, stream()));
-        hipLaunchKernelGGL(encode_kernel, grid1(out.total), dim3(WG), 0, stream(), out.codes(), out.total);
+        // (a launch holds fewer than 2^32 work-items per dimension: a grid for 5 Gbases wraps silently and leaves the
+        //  tail as ASCII - found by the full-size C5 run, round 3)
+        for (uint64_t o = 0; o < out.total; o += 1ull << 30) {
+            const uint64_t len = std::min<uint64_t>(1ull << 30, out.total - o);
+            hipLaunchKernelGGL(encode_kernel, grid1(len), dim3(WG), 0, stream(), out.codes() + o, len);
+        }
+        HIP_CHECK(hipGetLastError());
     }
     out.off.upload(off);
     sync();
