@@ -765,7 +765,9 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
     int verdict16 = 0;
     if constexpr (MODE == 2) {
         static_assert(CHAIN_GROUPS == 4, "one group per row of 16 lanes");
+        const long long td0 = (INSTR && a.prof) ? (long long)__builtin_readcyclecounter() : 0;
         verdict16 = g_lo < a.n_list ? dp16_groups(a, (const int *)pen_tab, g_lo, a.fp) : 2;
+        if (INSTR && a.prof && lane == 0) atomicAdd(&a.prof[4], (unsigned long long)((long long)__builtin_readcyclecounter() - td0));
         __builtin_amdgcn_s_waitcnt(0);                     // fp is read back by this wave below
         __threadfence_block();
         if (lane == 0) {
@@ -1312,7 +1314,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
             if (hb[0]) fprintf(stderr, "dp16 check: group %llu anchor %llu of %llu: dp16 f %llu p %d, full f %llu p %d\n", hb[1], hb[2], hb[3],
                                hb[4] >> 32, (int)(uint32_t)hb[4], hb[5] >> 32, (int)(uint32_t)hb[5]);
         } else {
-            DBuf<unsigned long long> prof(4);
+            DBuf<unsigned long long> prof(8);
             if (INSTR && getenv("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
             {
                 KTimer kt("chain");
@@ -1321,7 +1323,8 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
             HIP_CHECK(hipGetLastError());
             sync();                                   // fp goes out of scope
             if (INSTR && ca.prof) {
-                const std::vector<unsigned long long> hp = prof.download(4);
+                const std::vector<unsigned long long> hp = prof.download(8);
+                stat_add("chain_prof_dp16_cyc", (double)hp[4]);
                 stat_add("chain_prof_blocks_cyc", (double)hp[0]); stat_add("chain_prof_members_cyc", (double)hp[1]);
                 stat_add("chain_prof_fixed_cyc", (double)hp[2]); stat_add("chain_prof_groups", (double)hp[3]);
             }

@@ -163,3 +163,44 @@ def test_c5_stub_rule_changes_no_final_row(c5_sample):
     # the window filter sees the same lines in the same places: equal survivors of v4 itself
     v4 = lambda rows: F.window_filter(rows, variant=4, min_len=30, min_iden=0.6, min_o=3)
     assert v4(stub) == v4(full)
+
+
+def test_extend_con_against_minimap2_when_one_is_installed(tmp_path):
+    """Opportunistic, like the stage comparison above: HyLight.extend_con's contig-vs-contig call (`minimap2 --sr -X -c -k 21
+    -w 11 -s 60 -m 30 -n 2 -r 0 -A 4 -B 2 --end-bonus=100`, script/HyLight.py:309-311) on overlapping contig pieces, through
+    the v3 window filter with -sfo: which contig pairs reach sfoverlaps.out with minimap2 and which with the specification
+    (whose -r 0 constrains the chaining band only: DESIGN.md section 5).  Without a minimap2 on $PATH this is skipped and the
+    chain stays pinned to the oracle alone."""
+    import shutil
+    import numpy as np
+    mm2 = shutil.which("minimap2")
+    if not mm2:
+        pytest.skip("no minimap2 on PATH: extend_con's overlapper call stays unpinned")
+    from hylight_amd import simulate as S
+    from oracle import ava as OA
+    from oracle import filters as F
+    rng = np.random.default_rng(7)
+    _, strains = S.simulate_reads(seed=7, n_strains=2, genome_len=60_000, n_reads=1, snp_rate=0.004)
+    fq = tmp_path / "contigs_b.fastq"
+    with open(fq, "w") as f:
+        for k in range(14):
+            g = strains[k % 2]
+            a = int(rng.integers(0, 60_000 - 9000))
+            seq = g[a:a + int(rng.integers(4000, 9000))].copy()
+            if k % 3 == 0:
+                seq = S.revcomp(seq)
+            f.write(f"@{k + 1}\n{seq.tobytes().decode()}\n+\n{'=' * len(seq)}\n")
+    o = OA.opts_short()
+    o.pair_once, o.bandwidth = 1, 0
+    OA.ava(fq, fq, tmp_path / "spec.paf", o)
+    with open(tmp_path / "real.paf", "w") as out:
+        subprocess.run([mm2, "-t", "1", "--sr", "-X", "-c", "-k", "21", "-w", "11", "-s", "60", "-m", "30", "-n", "2", "-r", "0",
+                        "-A", "4", "-B", "2", "--end-bonus=100", str(fq), str(fq)], stdout=out, stderr=subprocess.DEVNULL, check=True)
+    sfo = {}
+    for tag in ("spec", "real"):
+        rows = open(tmp_path / f"{tag}.paf").read().split("\n")[:-1]
+        kept = F.window_filter(rows, variant=3, min_len=90, min_iden=0.99, min_o=2, sfo=True)
+        sfo[tag] = {tuple(sorted(l.split("\t")[:2])) for l in kept}
+    print("contig pairs in sfoverlaps.out: minimap2 %d, specification %d, common %d" %
+          (len(sfo["real"]), len(sfo["spec"]), len(sfo["real"] & sfo["spec"])))
+    assert len(sfo["real"] & sfo["spec"]) >= 0.9 * len(sfo["real"])
