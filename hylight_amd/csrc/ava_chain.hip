@@ -372,6 +372,9 @@ struct ChainArgs {
     size_t n_groups, n_anchors;
     uint32_t *fp;                     // MODE 2: score << 5 | distance to the predecessor (0: none) of every anchor, from chain_dp16_kernel
     uint32_t *sbase;                  // per chain start: f(parent of the start) | has a child << 31
+    uint32_t *starts;                 // per group, in its range [first anchor, ...): the chain starts that can become a chain
+                                      // (a child, or min_cnt <= 1), ascending - the candidate scan reads these few instead of
+                                      // the chain id of every anchor
     int *root;                        // chain id of every anchor (index of the chain's start inside the group)
     unsigned long long *peak;         // per chain, at its root: best f << 32 | ~(first index reaching it)
     int k, max_gap, bw, min_score, min_cnt;
@@ -845,6 +848,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         long long tp0 = (INSTR && a.prof) ? (long long)__builtin_readcyclecounter() : 0, tpc = 0;
         int P1_f = 0, P1_p = -1, P2_f = 0;                 // f / p of the block before, f of the one before that
         int prev_root = 0;                                 // roots of the last resolved block (lane = index mod 64)
+        int n_starts = 0;                                  // chain starts listed so far (a.starts[b ..])
         auto resolve = [&](int w0, int Rf, int Rp, int Bf) {
             const int i = w0 + lane;
             const bool live = i < n;
@@ -870,6 +874,12 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
                     a.sbase[b + i] = (uint32_t)(pi < 0 ? 0 : (pi >= w0 ? f_same : f_before)) | (has_child ? 0x80000000u : 0u);
                     a.peak[b + i] = 0;                     // a chain's peak word starts here: every vote for it comes later,
                 }                                          // from this wave (no memset of the whole array per batch)
+            }
+            {   // a childless start is a one-anchor chain: it can only survive when min_cnt <= 1
+                const bool st = live && val == i && (a.min_cnt <= 1 || has_child);
+                const unsigned long long sm = __ballot(st);
+                if (st) a.starts[b + (size_t)n_starts + (size_t)__popcll(sm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                n_starts += __popcll(sm);
             }
             __builtin_amdgcn_s_waitcnt(0);                 // the zeros are out before the first votes (same wave, same address)
             prev_root = val;
@@ -1007,24 +1017,21 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
         __threadfence_block();
         if (INSTR && a.prof) { const long long t = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&a.prof[0], (unsigned long long)(t - tp0)); tp0 = t; }
         uint32_t fcur = 2u * (uint32_t)b;                  // next free fixed-point slot of the group
-        for (int s0 = 0; s0 < n; s0 += 64) {
-            int pk_i = 0;
+        for (int k0 = 0; k0 < n_starts; k0 += 64) {
+            int pk_i = 0, s_mine = 0;
             bool cand = false;
-            if (s0 + lane < n) {
-                const int s = s0 + lane;
-                if (a.root[b + s] == s) {
-                    const uint32_t sb = a.sbase[b + s];     // f(parent of the start) | has a child << 31
-                    const unsigned long long pk = a.peak[b + s];
-                    pk_i = (int)(0xffffffffu - (uint32_t)(pk & 0xffffffffull));
-                    // a childless start is a one-anchor chain: it can only survive when min_cnt <= 1
-                    cand = (int)(pk >> 32) - (int)(sb & 0x7fffffffu) >= a.min_score && (a.min_cnt <= 1 || (sb >> 31));
-                }
+            if (k0 + lane < n_starts) {
+                s_mine = (int)a.starts[b + (size_t)(k0 + lane)];
+                const uint32_t sb = a.sbase[b + s_mine];    // f(parent of the start) | has a child << 31
+                const unsigned long long pk = a.peak[b + s_mine];
+                pk_i = (int)(0xffffffffu - (uint32_t)(pk & 0xffffffffull));
+                cand = (int)(pk >> 32) - (int)(sb & 0x7fffffffu) >= a.min_score;
             }
             unsigned long long cm = __ballot(cand);
             while (cm) {
                 const int l = __ffsll((long long)cm) - 1;
                 cm &= cm - 1;
-                const int s = s0 + l;
+                const int s = __builtin_amdgcn_readlane(s_mine, l);
                 const int peak_i = __builtin_amdgcn_readlane(pk_i, l);
                 // fixed points of this chain: at most 2 per member, and the chains of a group have disjoint members -
                 // the group's range of the array (twice its anchors) is handed out chain after chain, no counter needed
@@ -1276,8 +1283,8 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     ca.key = akey.p; ca.val = aval.p; ca.skey = skey; ca.sk = sk; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
     DBuf<int> root(A);
     DBuf<unsigned long long> peak(A);             // written by the kernel at every chain start before it is voted on
-    DBuf<uint32_t> sbase(A);
-    ca.sbase = sbase.p; ca.root = root.p; ca.peak = peak.p;
+    DBuf<uint32_t> sbase(A), starts(A);
+    ca.sbase = sbase.p; ca.root = root.p; ca.peak = peak.p; ca.starts = starts.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
     ca.q_lo = (uint32_t)q_lo;
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
