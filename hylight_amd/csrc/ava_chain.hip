@@ -864,6 +864,13 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
             const int from_prev = __shfl(prev_root, (pi - w0 + 64) & 63, 64);
             const int f_same = __shfl(Rf, pi & 63, 64), f_before = __shfl(Bf, pi & 63, 64);
             if (child && pi < w0) val = from_prev;
+            const unsigned long long open_m = __ballot(val < 0);
+            if (open_m && !__ballot(val < 0 && ~val != lane - 1)) {
+                // every unresolved anchor hangs on the anchor right before it (the usual block: one chain, no stray anchor in
+                // between): its root is the value of the nearest resolved lane below - one shuffle instead of six rounds
+                const unsigned long long res = ~open_m & ((2ull << lane) - 1ull);          // (lane 0 is never unresolved here:
+                val = __shfl(val, 63 - __clzll((long long)res), 64);                       //  its parent lies in the block before)
+            } else
             while (__ballot(val < 0)) {
                 const int up = __shfl(val, val < 0 ? ~val : lane, 64);
                 if (val < 0) val = up;                     // parent resolved: its root; else jump to the parent's parent
