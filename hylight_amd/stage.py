@@ -23,10 +23,12 @@ SLAB = 32 << 20          # minimizers per rank and round (16 B each: 512 MiB per
 
 class StageRunner:
     def __init__(self, reads_fa, ref_fa, nsplit, long_mode=True, rank=0, world=1, group=None, job=None,
-                 device="cuda", slab=SLAB):
+                 device="cuda", slab=SLAB, force_exchange=False):
         """`job` / `device` exist for the CPU (gloo) tests of the exchange logic: the product always uses
-        api.Job on "cuda"."""
+        api.Job on "cuda".  `force_exchange` takes the all-gather path with one rank as well (the RCCL calls of the N > 1
+        flow on a single card: tests/test_gpu_multirank.py)."""
         self.rank, self.world, self.group, self.device = rank, world, group, device
+        self.force_exchange = force_exchange
         self.slab = max(1, int(slab))
         self.job = job if job is not None else api.Job(reads_fa, ref_fa, nsplit, long_mode)
         self._keep = None
@@ -43,7 +45,7 @@ class StageRunner:
         if self._keep is not None and not force:
             return
         job, world, rank, dev = self.job, self.world, self.rank, self.device
-        if world == 1 and hasattr(job, "sketch_own"):
+        if world == 1 and hasattr(job, "sketch_own") and not self.force_exchange:
             # one rank: nothing to exchange - the job sketches into buffers of its own, sized exactly (a caller buffer needs
             # room for the bound, one 16-byte entry per base: 80 GB for C5's 5 Gbases)
             job.sketch_own()
@@ -58,7 +60,7 @@ class StageRunner:
         if dev == "cuda":
             torch.cuda.current_stream().synchronize()      # the library works on its own stream: torch's fills first
         n = job.sketch(lo, hi, mz.data_ptr(), cap, cnt.data_ptr()) if hi > lo else 0
-        if world == 1:
+        if world == 1 and not self.force_exchange:
             all_mz, all_cnt, total = mz[:max(n, 1)], cnt, n
         else:
             import torch.distributed as dist

@@ -90,3 +90,49 @@ def test_bench_starts_two_ranks_itself(tmp_path):
     line = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["launcher"] == "self" and line["backend"] == "gloo"
     assert line["value"] > 0 and line["config"]["overlaps_out"] > 0
+
+
+def _rccl_rank(rank, world, port, fa, out):
+    import torch
+    import torch.distributed as dist
+    from hylight_amd import api, launch
+    from hylight_amd.stage import StageRunner
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    api.init(0, 0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=rank, world_size=world)
+    assert dist.get_backend() == "nccl"
+    # the collectives bench.py and the driver issue besides the sketch exchange
+    obj = [fa]
+    dist.broadcast_object_list(obj, src=0)
+    dist.barrier()
+    t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t[0]) == 1.5
+    r = StageRunner(obj[0], obj[0], 12, long_mode=True, rank=rank, world=world, slab=5000, force_exchange=True)
+    r.run(out, **STAGE)
+    assert r.exchange_rounds > 3                  # the streamed all-gather went through several ragged rounds
+    r.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_rccl_calls_of_the_exchange_on_one_rank(tmp_path):
+    """The N > 1 tests above carry the exchange over gloo (two ranks on one card; RCCL wants a device per rank).  This
+    one runs the same code path - counts all-gather, slab rounds of all_gather_into_tensor on device buffers, counts
+    again, install - over the real backend ("nccl" = RCCL) with a communicator of ONE rank, plus the other collectives
+    of bench.py / the driver: dtype, shape, device and stream handling are what an 8-GPU run will meet."""
+    from hylight_amd import api
+    from hylight_amd import simulate as S
+    reads, _ = S.simulate_reads(seed=78, n_strains=3, genome_len=30_000, n_reads=200, mean_len=6000, min_len=1500,
+                                max_len=20_000)
+    fa = tmp_path / "r.fa"
+    S.write_fasta(reads, fa)
+    one = tmp_path / "one.paf"
+    api.split_reads2(fa, fa, 12, tmp_path, one, long=True, **STAGE)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "rccl.paf"
+    mp.spawn(_rccl_rank, args=(1, port, str(fa), str(out)), nprocs=1, join=True)
+    assert open(out).read() == open(one).read() and os.path.getsize(one) > 0
