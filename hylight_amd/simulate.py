@@ -375,6 +375,75 @@ def simulate_short_pairs(seed, strains, n_pairs, read_len=250, insert_mean=450.0
     return out
 
 
+_SHORT_CTX = None          # (strains, strain_of, ins, start, flip, recipe): inherited by the forked block workers
+
+
+def _short_block(job):
+    b, lo, hi, seed, part = job
+    strains, strain_of, ins, start, flip, (read_len, err_sub, name_prefix) = _SHORT_CTX
+    rng = np.random.default_rng([seed, b + 1])
+    idx = np.arange(read_len, dtype=np.int64)
+    n = hi - lo
+    r1 = np.empty((n, read_len), dtype=np.uint8)
+    r2 = np.empty((n, read_len), dtype=np.uint8)
+    so = strain_of[lo:hi]
+    for st in np.unique(so):
+        sel = np.nonzero(so == st)[0]
+        g = strains[int(st)]
+        a = start[lo:hi][sel]
+        left = g[a[:, None] + idx[None, :]]
+        right = _COMP[g[(a + ins[lo:hi][sel])[:, None] - 1 - idx[None, :]]]
+        for block in (left, right):
+            e = rng.random(block.shape) < err_sub
+            n_e = int(e.sum())
+            if n_e:
+                code = np.searchsorted(_BASES, block[e])
+                block[e] = _BASES[(code + rng.integers(1, 4, size=n_e)) % 4]
+        f = flip[lo:hi][sel]
+        r1[sel] = np.where(f[:, None], right, left)
+        r2[sel] = np.where(f[:, None], left, right)
+    with open(part, "wb") as out:
+        for k in range(n):
+            i = lo + k
+            out.write(b">%s%d/1\n" % (name_prefix, i) + r1[k].tobytes() + b"\n>%s%d/2\n" % (name_prefix, i) + r2[k].tobytes() + b"\n")
+    return 2 * n
+
+
+def simulate_short_pairs_to_fasta(path, seed, strains, n_pairs, read_len=250, insert_mean=450.0, insert_sd=27.0, err_sub=0.001,
+                                  name_prefix="p", block=250_000, workers=None):
+    """The recipe of simulate_short_pairs for millions of pairs (C4: 5 M pairs), written straight to an interleaved 2-line
+    FASTA by a pool of processes: strain, insert size, position and strand of every fragment come from the same seeded
+    stream as in simulate_short_pairs, the substitution errors of block b of `block` pairs from the stream seeded
+    [seed, b + 1].  Returns the number of reads written."""
+    import multiprocessing as mp
+    import os
+    import shutil
+    global _SHORT_CTX
+    rng = np.random.default_rng(seed)
+    ns = len(strains)
+    ab = 10.0 ** rng.uniform(0.0, 1.0, size=ns)
+    ab /= ab.sum()
+    strain_of = rng.choice(ns, size=n_pairs, p=ab)
+    ins = np.maximum(np.rint(rng.normal(insert_mean, insert_sd, size=n_pairs)).astype(np.int64), read_len)
+    glen = np.array([len(g) for g in strains], dtype=np.int64)
+    start = (rng.random(n_pairs) * (glen[strain_of] - ins + 1)).astype(np.int64)
+    flip = rng.random(n_pairs) < 0.5
+    _SHORT_CTX = (strains, strain_of, ins, start, flip, (read_len, err_sub, name_prefix.encode()))
+    jobs = [(b, lo, min(lo + block, n_pairs), seed, f"{path}.part{b}") for b, lo in enumerate(range(0, n_pairs, block))]
+    workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))
+    try:
+        with mp.get_context("fork").Pool(workers) as pool:
+            n = sum(pool.map(_short_block, jobs, chunksize=1))
+    finally:
+        _SHORT_CTX = None
+    with open(path, "wb") as out:
+        for _, _, _, _, part in jobs:
+            with open(part, "rb") as f:
+                shutil.copyfileobj(f, out, 16 << 20)
+            os.remove(part)
+    return n
+
+
 def layout_paf(seed, n_reads=20_000, genome=2_000_000, mean_len=10_000, min_ovl=2_500, jitter=30, dup_frac=0.01,
                fake_frac=0.002, drop=0.05, name_prefix="L"):
     """A large tag-less PAF straight from a read layout (no alignment is computed): every pair of reads whose genome

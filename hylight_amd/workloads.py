@@ -85,6 +85,10 @@ def make_long(cfg, path, seed=S.SEED_DEFAULT):
 
 
 def make_short(cfg, strains, path, seed=S.SEED_DEFAULT + 1):
+    if 2 * cfg["short"]["n_pairs"] >= 4 * PARALLEL_FROM:        # the full C4: 10 M reads, written by a pool of processes
+        n = S.simulate_short_pairs_to_fasta(path + ".tmp", seed, strains, **cfg["short"])
+        os.replace(path + ".tmp", path)
+        return n
     reads = S.simulate_short_pairs(seed, strains, **cfg["short"])
     S.write_fasta(reads, path + ".tmp")
     os.replace(path + ".tmp", path)

@@ -101,3 +101,47 @@ def test_c4_full_size_long_reads_four_chunks(tmp_path):
     # (at 5 000x pooled depth the mc = 2 support filter leaves next to nothing of four chunks' 1.9e7 candidate rows)
     check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 0)
     assert t_run < 240
+
+
+def test_c4_full_size_short_reads_one_rank_share(tmp_path):
+    """configs[3]'s short-read side at full size: all 10 000 000 short reads (5 M pairs 2 x 250, 2.5 Gbases) resident and
+    sketched, against the "polished long contigs" of HyLight.py:200 (40 kb pieces of the 100 strains x 2 Mb: 5 000
+    contigs, 625 --nsplit chunks of 8) - the share one rank of an 8-rank job computes (78 chunks), short mode
+    (len_over 70, mc 3)."""
+    if _free_gb(tmp_path) < 12 or _host_gb() < 48:
+        pytest.skip("needs 12 GB of scratch space and 48 GB of host memory")
+    from hylight_amd import simulate as S
+    cfg = W.config("C4")
+    t0 = time.time()
+    _, strains, _, _ = S._population(S.SEED_DEFAULT, cfg["sim"]["n_strains"], cfg["sim"]["genome_len"], 1, cfg["sim"]["mean_len"], 1000,
+                                     40000, cfg["sim"]["snp_rate"], cfg["sim"]["strain_indel_rate"])
+    short_fa, con_fa = str(tmp_path / "short.fa"), str(tmp_path / "long_con_polished.fa")
+    n_short = W.make_short(cfg, strains, short_fa)
+    contigs = [S.Read(f"longr_con_{k}_{a}", g[a:a + 40_000].copy(), None, k, a, a + 40_000, False)
+               for k, g in enumerate(strains) for a in range(0, len(g) - 10_000, 40_000)]
+    S.write_fasta(contigs, con_fa)
+    t_sim = time.time() - t0
+    assert n_short == 10_000_000 and len(contigs) == 5_000
+    st_short = cfg["stage_short"]
+    t0 = time.time()
+    r = StageRunner(short_fa, con_fa, cfg["nsplit"], long_mode=False)
+    try:
+        t_open = time.time() - t0
+        assert r.job.num_queries == 10_000_000 and r.job.num_chunks == 625
+        out = str(tmp_path / "shortr1_r0.paf")
+        t0 = time.time()
+        r.prepare()
+        t_sketch = time.time() - t0
+        t0 = time.time()
+        rows = r.run(out, share=(0, 8), **st_short)
+        t_run = time.time() - t0
+        st = api.last_stats()
+    finally:
+        r.close()
+    os.remove(short_fa)
+    print(f"C4 full size (short reads vs contigs): simulate {t_sim:.1f} s, parse + upload {t_open:.1f} s, sketch of 2.5 Gbases {t_sketch:.2f} s, "
+          f"one rank's share (79 of 625 chunks) {t_run:.1f} s -> {rows} overlaps; anchors {st['anchors']:.3g}, candidate rows {st['ava_rows']:.3g}")
+    assert st["queries"] == 10_000_000 and 620 < st["targets"] < 640 and st["anchors"] > 1e9
+    assert rows == sum(1 for _ in open(out)) == st["rows_out"] and rows > 100_000
+    check_rows(out, st_short["len_over"], st_short["iden"], 100_000)
+    assert t_run < 240
