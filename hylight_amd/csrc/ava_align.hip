@@ -147,6 +147,8 @@ struct AlignArgs {
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     int kgap1;              // 1: blocks with |n - m| = 1 and one substitution finish in the classifier (fifth certificate)
     int one_ok;             // 1: extensions may be certified for the one-piece rows (HLMI_NO_ONE_PIECE_CERT: test hook)
+    int kext_plain;         // 1: an extension with ONE substitution and no bonus row finishes in the classifier (sixth certificate)
+    int kext_bonus;         // extensions whose end cell lies in the bonus row finish there with up to this many substitutions
     int trim_ok;            // 1: near-diagonal DP tasks lose their exactly matching suffix (HLMI_NO_SUFFIX_TRIM: test hook)
     int kshift;             // 1: a square block with kmax + 1 substitutions also finishes here when the one-base shift
                             // that could avoid them all does not match (fourth certificate, see classify_kernel)
@@ -230,7 +232,7 @@ __device__ __forceinline__ uint32_t load_window4p(const uint8_t *codes, long lon
 
 // stats[]: 0 bases (Lq + Lt) of all tasks, 1 of the square blocks compared here, 2 of the narrow DP tasks, 3 of the
 // wide DP tasks, 4 tasks finished on the diagonal fast path, 5 DP tasks, 6 DP rows
-enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, N_ALIGN_STATS };
+enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, ST_EXT_CERT, N_ALIGN_STATS };
 constexpr int NR_SMALL = 64;                    // narrow tasks with fewer rows than this run in the instance with half the plane LDS
 
 // 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
-    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
+    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
     const size_t n_units = PASS == 1 ? a.n_tasks : (size_t)*a.defer_count;
     const size_t rounds = (n_units + n_thr - 1) / n_thr;              // uniform trip count: the allocation is per wave
     // the reference of a task (PASS 2: its index in the list) is fetched a round ahead
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         // it is the unique best cell and the alignment is L matches.  With an end bonus in play (short mode) a cell of
         // the bonus row could outrank it, so the certificate then needs (L, L) to lie in that row itself.
         uint32_t ext_flag = 0;
+        int ext_take = -1;                   // sixth certificate: rows = columns of the cell the extension stops in
         if (PASS == 2 && live && c != 0 && (tk.kind & 3) != 0 && a.kmax >= 0) {
             const bool rev = (tk.kind & TASK_REV) != 0, left = (tk.kind & 3) == 1;
             const int L = m < n ? m : n;
@@ -492,7 +495,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 g = g < 1 ? 1 : g;
                 allow = (a.go2 + a.ge2 * g - 1) / (a.match + a.mismatch);      // (match + mismatch) * k < cost*
             }
-            for (int x = 0; x < L && (same || (k_ext <= allow && !amb_ext)); x += 8) {
+            // (the first two substitutions' places: sixth certificate below)
+            const bool bonus_row = a.end_bonus != 0 && end_row >= 0;          // some row earns the end bonus
+            const int k_want = bonus_row ? (L == end_row ? a.kext_bonus : 0) : a.kext_plain;
+            int x1 = -1, x2 = -1;
+            for (int x = 0; x < L && (same || (!amb_ext && (k_ext <= allow || k_ext <= k_want))); x += 8) {
                 const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, left != rev, rev, x);
                 const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, left, false, x);
                 const int rest = L - x;
@@ -500,6 +507,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 uint64_t d = (q8 ^ t8) & keep;
                 amb_ext |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
                 d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
+                if (d && x2 < 0) {
+                    const int y1 = (__ffsll((long long)d) - 1) >> 3;
+                    if (x1 < 0) { x1 = x + y1; const uint64_t d2 = d & (d - 1); if (d2) x2 = x + ((__ffsll((long long)d2) - 1) >> 3); }
+                    else x2 = x + y1;
+                }
                 k_ext += __popcll(d);
                 same = same && d == 0 && !amb_ext;
             }
@@ -511,6 +523,46 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 ext_flag = L == end_row ? 0x80000000u : 0u;
                 fast = true;
                 c = 0;
+            } else if (!amb_ext && k_ext >= 1 && k_ext <= k_want) {
+                // Sixth certificate: an extension whose first L = min(m, n) pairs differ in k places and hold no ambiguous base.
+                // U = match + mismatch, G = the cheapest one-base gap (open + ext of the cheaper piece); the host admits the
+                // certificate only when the inequalities used here hold for the scoring constants.
+                // * Any cell (i, j) reached with a gap scores at most match min(i, j) - G; cell (i, i) of the main diagonal
+                //   scores D(i) = match i - U (substitutions before i).  A path into a diagonal cell that leaves the diagonal
+                //   needs an insertion AND a deletion: at most match (i - 1) - 2 G < D(i) for k U < 2 G + match, so the
+                //   diagonal is the unique best path into its own cells.
+                // * No bonus row (long mode, or the query end out of reach), k = 1 at x: the candidates are (x, x) with match x
+                //   - every pair before the substitution matches - and (L, L) with match (L - 1) - mismatch; gapped cells stay
+                //   at or below match L - G <= D(L) (G >= U), and where they tie they hold more bases (i + j > 2 L), which the
+                //   best-cell rule ranks behind; the same bound keeps them at or below (x, x) when that is the larger one.  Ties
+                //   between the two go to (x, x): fewer bases.
+                // * The end cell (L, L) lies in the bonus row (L = end_row, short mode), k <= kext_bonus: it ranks D(L) + bonus;
+                //   the other cells of that row need a gap - at most match L - G + bonus, below it for k U < G - and every cell
+                //   of another row ranks at most match (L - 1) < D(L) + bonus for k U < bonus + match.
+                int take = L;                                     // rows (= columns) of the chosen cell
+                if (!bonus_row && a.match * x1 >= a.match * (L - 1) - a.mismatch) take = x1;
+                const int subs = take == L ? k_ext : 0;
+                int prev = 0;
+                if (take > 0) {
+                    if (subs >= 1) {
+                        if (x1 > 0) runs[nr++] = (uint32_t)x1 << 4 | OP_EQ;
+                        if (subs == 2 && x2 == x1 + 1) { runs[nr++] = 2u << 4 | OP_X; prev = x2 + 1; }
+                        else {
+                            runs[nr++] = 1u << 4 | OP_X; prev = x1 + 1;
+                            if (subs == 2) {
+                                runs[nr++] = (uint32_t)(x2 - prev) << 4 | OP_EQ;
+                                runs[nr++] = 1u << 4 | OP_X; prev = x2 + 1;
+                            }
+                        }
+                    }
+                    if (take > prev) runs[nr++] = (uint32_t)(take - prev) << 4 | OP_EQ;
+                }
+                fast_score = a.match * (take - subs) - a.mismatch * subs;
+                ext_flag = bonus_row && take == end_row ? 0x80000000u : 0u;
+                ext_take = take;
+                fast = true;
+                c = 0;
+                ++st[ST_EXT_CERT];
             }
         } else if (PASS == 2 && live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
             const bool rev = (tk.kind & TASK_REV) != 0;
@@ -612,7 +664,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         if (fast) {
             if (ok) for (uint32_t q = 0; q < nr; ++q) a.runs[base + mine + q] = runs[q];
             const bool ext = (tk.kind & 3) != 0;              // extensions report the cell they stop in
-            const int L = m < n ? m : n;
+            const int L = ext_take >= 0 ? ext_take : (m < n ? m : n);
             a.out[ti] = TaskOut{fast_score, ext ? L : m, ext ? L : n, base + mine, ok ? nr : 0, (nr ? end_codes(runs[0], runs[nr - 1]) : 0u) | ext_flag};
         } else if (live && c == 0) {
             a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
@@ -1619,6 +1671,16 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         }
         aa.trim_ok = getenv("HLMI_NO_SUFFIX_TRIM") ? 0 : 1;
         aa.one_ok = getenv("HLMI_NO_ONE_PIECE_CERT") ? 0 : 1;
+        {   // sixth certificate (classify_kernel: extensions with one or two substitutions); G = cheapest one-base gap
+            const int U = o.match + o.mismatch;
+            int G = o.gap_open + o.gap_ext;
+            if (aa.go2 > 0) G = std::min(G, aa.go2 + aa.ge2);
+            const bool sane = aa.kmax >= 0 && o.match > 0 && o.mismatch >= 0 && !getenv("HLMI_NO_EXT_CERT");
+            aa.kext_plain = sane && G >= U && U < 2 * G + o.match ? 1 : 0;
+            aa.kext_bonus = 0;
+            for (int k = 1; k <= 2; ++k)
+                if (sane && o.end_bonus > 0 && k * U < G && k * U < o.end_bonus + o.match && k * U < 2 * G + o.match) aa.kext_bonus = k;
+        }
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         as.runs = runs.p;
         aa.run_buf_cap = 0xffffffffu;
@@ -1764,6 +1826,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         stat_add("align_bases_narrow", (double)h[ST_BASES_NARROW]);
         stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
         stat_add("align_tasks_wide_one_piece", (double)h[ST_WIDE_ONE]);
+        stat_add("align_ext_certified", (double)h[ST_EXT_CERT]);
         stat_add("align_ext_held", (double)h[ST_STUB_EXT]);            // end extensions of stub candidates ...
         stat_add("align_ext_late", (double)(2 * n_late));              // ... of which these had to run after all
     }
