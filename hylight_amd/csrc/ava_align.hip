@@ -557,6 +557,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                     }
                     if (take > prev) runs[nr++] = (uint32_t)(take - prev) << 4 | OP_EQ;
                 }
+                // element 0 of a left extension is the base next to the fixed point: the runs above are in element order,
+                // the row wants them in sequence order
+                if (left) for (uint32_t i = 0; i < nr / 2; ++i) { const uint32_t v = runs[i]; runs[i] = runs[nr - 1 - i]; runs[nr - 1 - i] = v; }
                 fast_score = a.match * (take - subs) - a.mismatch * subs;
                 ext_flag = bonus_row && take == end_row ? 0x80000000u : 0u;
                 ext_take = take;
