@@ -232,7 +232,7 @@ __device__ __forceinline__ uint32_t load_window4p(const uint8_t *codes, long lon
 
 // stats[]: 0 bases (Lq + Lt) of all tasks, 1 of the square blocks compared here, 2 of the narrow DP tasks, 3 of the
 // wide DP tasks, 4 tasks finished on the diagonal fast path, 5 DP tasks, 6 DP rows
-enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, ST_EXT_CERT, N_ALIGN_STATS };
+enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, ST_EXT_CERT, ST_EXT_DP_ROW, ST_EXT_DP_K, N_ALIGN_STATS };
 constexpr int NR_SMALL = 64;                    // narrow tasks with fewer rows than this run in the instance with half the plane LDS
 
 // 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
-    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
+    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
     const size_t n_units = PASS == 1 ? a.n_tasks : (size_t)*a.defer_count;
     const size_t rounds = (n_units + n_thr - 1) / n_thr;              // uniform trip count: the allocation is per wave
     // the reference of a task (PASS 2: its index in the list) is fetched a round ahead
@@ -480,7 +480,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             const bool rev = (tk.kind & TASK_REV) != 0, left = (tk.kind & 3) == 1;
             const int L = m < n ? m : n;
             const int end_row = (int)(tk.narrow >> 1) - 1;
-            bool same = a.end_bonus == 0 || end_row < 0 || L == end_row;
+            // the row that earns the end bonus exists in this task's band: the band holds the cells with j - i >= -(BAND_W / 2 - 1),
+            // so a query end more than that many rows below the last target base is out of reach (a short read running off the end
+            // of its target: the usual right end of a read-to-read overlap) and the task is an extension without a bonus
+            const bool bonus_row = a.end_bonus != 0 && end_row >= 0 && end_row <= n + (BAND_W / 2 - 1);
+            bool same = !bonus_row || L == end_row;
             // One-piece certificate for the extensions the DP will get.  The second piece of the gap cost prices a gap at or
             // below the first from g* = ceil((open2 - open) / (ext - ext2)) bases on; a path with such a gap ends in a cell
             // (i, j) with at most match * min(i, j) - (open2 + ext2 g*) <= match * L - cost*, L = min(m, n).  The main diagonal alone reaches
@@ -496,7 +500,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 allow = (a.go2 + a.ge2 * g - 1) / (a.match + a.mismatch);      // (match + mismatch) * k < cost*
             }
             // (the first two substitutions' places: sixth certificate below)
-            const bool bonus_row = a.end_bonus != 0 && end_row >= 0;          // some row earns the end bonus
             const int k_want = bonus_row ? (L == end_row ? a.kext_bonus : 0) : a.kext_plain;
             int x1 = -1, x2 = -1;
             for (int x = 0; x < L && (same || (!amb_ext && (k_ext <= allow || k_ext <= k_want))); x += 8) {
@@ -566,7 +569,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 fast = true;
                 c = 0;
                 ++st[ST_EXT_CERT];
-            }
+            } else if (bonus_row && L != end_row) ++st[ST_EXT_DP_ROW];       // (why an extension goes to the DP: statistics)
+            else ++st[ST_EXT_DP_K];
         } else if (PASS == 2 && live && c != 0 && (tk.kind & 3) == 0 && m != n && a.kmax >= 0) {
             const bool rev = (tk.kind & TASK_REV) != 0;
             const int mn = m < n ? m : n, gap = n > m ? n - m : m - n;
@@ -1830,6 +1834,8 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
         stat_add("align_tasks_wide_one_piece", (double)h[ST_WIDE_ONE]);
         stat_add("align_ext_certified", (double)h[ST_EXT_CERT]);
+        stat_add("align_ext_dp_bonus_row_elsewhere", (double)h[ST_EXT_DP_ROW]);
+        stat_add("align_ext_dp_substitutions", (double)h[ST_EXT_DP_K]);
         stat_add("align_ext_held", (double)h[ST_STUB_EXT]);            // end extensions of stub candidates ...
         stat_add("align_ext_late", (double)(2 * n_late));              // ... of which these had to run after all
     }
