@@ -60,6 +60,8 @@ SYMBOLS = {
                                          C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hlmi_vq_transitive_edges": (C.c_int, [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]),
+    "hlmi_vq_overlap_scores": (C.c_int, [C.c_char_p, C.POINTER(VqOverlap), C.c_uint64, C.c_double, C.c_uint32, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "hlmi_job_open": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "hlmi_job_close": (None, [C.c_void_p]),
     "hlmi_job_num_queries": (C.c_int64, [C.c_void_p]),
@@ -216,6 +218,22 @@ def vq_parse_overlaps(savage_path, min_len=150, min_perc=0, relax_pe=False, max_
                          ori2=o.ori2.decode(), perc1=o.perc1, perc2=o.perc2, len1=o.len1, len2=o.len2,
                          type1=o.type1.decode(), type2=o.type2.decode()))
     return rows, ne.value, sk.value
+
+
+def vq_overlap_scores(fastq_singles, overlaps, mismatch=0.0, min_read_len=0):
+    """EdgeCalculator::overlap_score for single-single overlaps (dicts as vq_parse_overlaps returns them) ->
+    list of (score, mismatch_rate, pos3)."""
+    n = len(overlaps)
+    buf = (VqOverlap * max(n, 1))()
+    for k, o in enumerate(overlaps):
+        b = buf[k]
+        b.id1, b.id2, b.pos1, b.pos2 = o["id1"], o["id2"], o["pos1"], o.get("pos2", 0)
+        b.perc1, b.perc2, b.len1, b.len2 = o.get("perc1", 0), o.get("perc2", 0), o.get("len1", 0), o.get("len2", 0)
+        b.ord, b.ori1, b.ori2 = o.get("ord", "-").encode(), o["ori1"].encode(), o["ori2"].encode()
+        b.type1, b.type2 = o.get("type1", "s").encode(), o.get("type2", "s").encode()
+    sc, mr, p3 = (C.c_double * max(n, 1))(), (C.c_double * max(n, 1))(), (C.c_int64 * max(n, 1))()
+    _check(load().hlmi_vq_overlap_scores(_b(fastq_singles), buf, n, mismatch, min_read_len, sc, mr, p3))
+    return [(sc[k], mr[k], p3[k]) for k in range(n)]
 
 
 def vq_transitive_edges(n_vertices, src, dst, ovlen=None, remove_trans=1):

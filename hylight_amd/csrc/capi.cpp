@@ -305,6 +305,15 @@ int hlmi_vq_transitive_edges(uint32_t n_vertices, uint64_t n_edges, const uint32
     });
 }
 
+int hlmi_vq_overlap_scores(const char *fastq_singles, const hlmi_vq_overlap *ov, uint64_t n, double mismatch,
+                           uint32_t min_read_len, double *score, double *mismatch_rate, int64_t *pos3) {
+    return guarded([&] {
+        if (!fastq_singles || (n && (!ov || !score || !mismatch_rate || !pos3))) fail(HLMI_EINVAL, "hlmi_vq_overlap_scores: NULL argument");
+        require_device();
+        vq_overlap_scores(fastq_singles, ov, n, mismatch, min_read_len, score, mismatch_rate, pos3);
+    });
+}
+
 hlmi_job *hlmi_job_open(const char *reads_fa, const char *ref_fa, int nsplit, int long_mode) {
     hlmi_job *j = nullptr;
     guarded([&] {

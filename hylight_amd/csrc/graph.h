@@ -81,6 +81,8 @@ void sfo2overlaps_run(const char *in_sfo, const char *out_savage, int num_single
 // vq_front.hip: SURVEY 8f rank 3 (started)
 void vq_parse_overlaps(const char *path, uint32_t min_len, uint32_t min_perc, int relax_pe, uint64_t max_overlaps,
                        hlmi_vq_overlap *out, uint64_t cap, uint64_t *n_out, uint64_t *n_nonedge, uint64_t *n_skipped);
+void vq_overlap_scores(const char *fastq, const hlmi_vq_overlap *ov, uint64_t n, double mismatch, uint32_t min_read_len,
+                       double *score, double *mismatch_rate, int64_t *pos3);
 void vq_transitive_edges(uint32_t n_vertices, uint64_t n_edges, const uint32_t *src, const uint32_t *dst, const uint32_t *ovlen,
                          int remove_trans, uint8_t *flags, uint64_t *n_transitive);
 

@@ -8,7 +8,10 @@
 // this image, so both pieces are checked against oracle/vq.py only: PARITY UNPINNED.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
+#include <unordered_map>
+#include <string_view>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -286,6 +289,150 @@ void vq_transitive_edges(uint32_t n_vertices, uint64_t n_edges, const uint32_t *
     const std::vector<uint8_t> h = result.download(E);
     memcpy(flags, h.data(), E);
     *n_transitive = found;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// quality-aware overlap score of single-single overlaps (EdgeCalculator.cpp:26-139, :186-222)
+// ---------------------------------------------------------------------------------------------
+// The score of one overlap is exp(mean over the overlapping positions of log p), p = probability that the two bases are
+// copies of one base given their phred qualities; the sum runs over the positions in sequence order in double precision.
+// log and pow come from the HOST's libm, as in the reference: p depends on the two qualities and on match / mismatch only,
+// so the host tabulates log p per (quality, quality) pair and the kernel - one thread per overlap, positions in order -
+// adds table entries: the same doubles in the same order as the reference's loop.  exp and the final division are done on
+// the host again.
+namespace {
+constexpr int NQ = 94;                         // phred characters '!' .. '~'
+struct VqReadRef { uint64_t off; uint32_t len; uint32_t pad; };
+struct VqScoreOut { double total; uint32_t len; uint32_t mismatches; uint32_t status; uint32_t pad; };   // status 1: zero score
+__device__ __forceinline__ int vq_code(uint8_t c, bool comp) {        // A C G T -> 0..3 (complemented), N -> 4, else 5
+    int v;
+    switch (c) { case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break; case 'N': return 4; default: return 5; }
+    return comp ? 3 - v : v;
+}
+__global__ void vq_score_kernel(const uint8_t *seq, const uint8_t *qual, const VqReadRef *reads, const uint32_t *idx1, const uint32_t *idx2,
+                                const uint32_t *pos1, const uint8_t *ori, size_t n, const double *log_match, const double *log_mis,
+                                const uint8_t *bad_match, const uint8_t *bad_mis, uint32_t min_read_len, VqScoreOut *out) {
+    const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const VqReadRef a = reads[idx1[k]], b = reads[idx2[k]];
+    const bool f1 = ori[k] & 1, f2 = (ori[k] >> 1) & 1;
+    const uint32_t pos = pos1[k];
+    VqScoreOut o{0.0, 0, 0, 0, 0};
+    if (pos >= a.len || a.len < min_read_len || b.len < min_read_len) { o.status = 1; out[k] = o; return; }
+    const uint32_t L = min(a.len - pos, b.len);
+    for (uint32_t i = 0; i < L; ++i) {
+        // position j of the oriented read: the read itself, or its reverse complement with the qualities reversed (Read.h:158-200)
+        const uint64_t ia = a.off + (f1 ? (uint64_t)(pos + i) : (uint64_t)(a.len - 1 - (pos + i)));
+        const uint64_t ib = b.off + (f2 ? (uint64_t)i : (uint64_t)(b.len - 1 - i));
+        const int c1 = vq_code(seq[ia], !f1), c2 = vq_code(seq[ib], !f2);
+        if (c1 == 5 || c2 == 5) { o.status = 2; break; }                      // the reference asserts A/C/G/T/N
+        if (c1 == 4 || c2 == 4) continue;                                     // N: the position is skipped
+        const int q = (int)qual[ia] * NQ + (int)qual[ib];
+        if (c1 == c2) {
+            if (bad_match[q]) { o.status = 1; break; }
+            o.total += log_match[q];
+        } else {
+            ++o.mismatches;
+            if (bad_mis[q]) { o.status = 1; break; }
+            o.total += log_mis[q];
+        }
+        ++o.len;
+    }
+    out[k] = o;
+}
+}  // namespace
+
+void vq_overlap_scores(const char *fastq, const hlmi_vq_overlap *ov, uint64_t n, double mismatch, uint32_t min_read_len,
+                       double *score, double *mismatch_rate, int64_t *pos3) {
+    // singles.fastq: 4-line records, id = strtoul of the first word behind '@', bases upper-cased (FastqStorage.cpp:92-150)
+    const std::string data = read_file(fastq);
+    std::vector<VqReadRef> reads;
+    std::unordered_map<uint64_t, uint32_t> index_of;
+    std::string seq, qual;
+    {
+        size_t pos = 0, line = 0;
+        uint64_t id = 0;
+        std::string cur_seq;
+        while (pos < data.size()) {
+            size_t e = data.find('\n', pos);
+            if (e == std::string::npos) e = data.size();
+            const std::string_view l(data.data() + pos, e - pos);
+            pos = e + 1;
+            switch (line++ % 4) {
+                case 0: {
+                    if (l.empty() || l[0] != '@') fail(HLMI_EINVAL, "%s: read id does not start with @ (line %zu)", fastq, line);
+                    size_t b = 1;
+                    while (b < l.size() && isspace((unsigned char)l[b])) ++b;
+                    size_t w = b;
+                    while (w < l.size() && !isspace((unsigned char)l[w])) ++w;
+                    id = strtoul(std::string(l.substr(b, w - b)).c_str(), nullptr, 0);
+                    break;
+                }
+                case 1:
+                    cur_seq.assign(l);
+                    for (char &c : cur_seq) c = (char)toupper((unsigned char)c);
+                    break;
+                case 2: break;
+                case 3: {
+                    if (cur_seq.empty()) fail(HLMI_EINVAL, "%s: single read %llu has an empty sequence", fastq, (unsigned long long)id);
+                    if (l.size() != cur_seq.size()) fail(HLMI_EINVAL, "%s: read %llu: %zu bases, %zu qualities", fastq, (unsigned long long)id, cur_seq.size(), l.size());
+                    index_of[id] = (uint32_t)reads.size();
+                    reads.push_back(VqReadRef{(uint64_t)seq.size(), (uint32_t)cur_seq.size(), 0});
+                    seq += cur_seq;
+                    for (char c : l) {
+                        const int q = (int)(unsigned char)c - 33;
+                        if (q < 0 || q >= NQ) fail(HLMI_EINVAL, "%s: read %llu: quality character outside '!'..'~'", fastq, (unsigned long long)id);
+                        qual.push_back((char)q);
+                    }
+                    break;
+                }
+            }
+        }
+    }
+    if (!n) return;
+    // p per quality pair, in the reference's order of operations (EdgeCalculator.cpp:41-49, :62-66)
+    std::vector<double> P(NQ), lm((size_t)NQ * NQ), lx((size_t)NQ * NQ);
+    std::vector<uint8_t> bm((size_t)NQ * NQ), bx((size_t)NQ * NQ);
+    for (int q = 0; q < NQ; ++q) P[q] = pow(10, -q / 10.0);
+    for (int q1 = 0; q1 < NQ; ++q1)
+        for (int q2 = 0; q2 < NQ; ++q2) {
+            const double p1 = P[q1], p2 = P[q2];
+            const double pm = (1 - p1) * (1 - p2) + (p1 * p2) / 3.0;
+            const double px = p1 * (1 - p2) / 3.0 + p2 * (1 - p1) / 3.0 + (2 / 9.0) * p1 * p2;
+            lm[(size_t)q1 * NQ + q2] = log(pm); bm[(size_t)q1 * NQ + q2] = pm < mismatch;
+            lx[(size_t)q1 * NQ + q2] = log(px); bx[(size_t)q1 * NQ + q2] = px < mismatch;
+        }
+    std::vector<uint32_t> i1(n), i2(n), p1(n);
+    std::vector<uint8_t> ori(n);
+    for (uint64_t k = 0; k < n; ++k) {
+        if (ov[k].type1 != 's' || ov[k].type2 != 's') fail(HLMI_EINVAL, "overlap %llu is not single-single", (unsigned long long)k);
+        auto a = index_of.find(ov[k].id1), b = index_of.find(ov[k].id2);
+        if (a == index_of.end() || b == index_of.end())
+            fail(HLMI_EINVAL, "overlap %llu names a read that is not in %s", (unsigned long long)k, fastq);
+        i1[k] = a->second; i2[k] = b->second; p1[k] = ov[k].pos1;
+        ori[k] = (uint8_t)((ov[k].ori1 == '+' ? 1 : 0) | (ov[k].ori2 == '+' ? 2 : 0));
+    }
+    DBuf<uint8_t> d_seq, d_qual, d_ori, d_bm, d_bx;
+    DBuf<VqReadRef> d_reads;
+    DBuf<uint32_t> d_i1, d_i2, d_p1;
+    DBuf<double> d_lm, d_lx;
+    d_seq.upload((const uint8_t *)seq.data(), seq.size()); d_qual.upload((const uint8_t *)qual.data(), qual.size());
+    d_reads.upload(reads); d_i1.upload(i1); d_i2.upload(i2); d_p1.upload(p1); d_ori.upload(ori);
+    d_lm.upload(lm); d_lx.upload(lx); d_bm.upload(bm); d_bx.upload(bx);
+    DBuf<VqScoreOut> d_out(n);
+    hipLaunchKernelGGL(vq_score_kernel, grid1(n), dim3(WG), 0, stream(), d_seq.p, d_qual.p, d_reads.p, d_i1.p, d_i2.p, d_p1.p, d_ori.p,
+                       (size_t)n, d_lm.p, d_lx.p, d_bm.p, d_bx.p, min_read_len, d_out.p);
+    HIP_CHECK(hipGetLastError());
+    const std::vector<VqScoreOut> h = d_out.download(n);
+    for (uint64_t k = 0; k < n; ++k) {
+        if (h[k].status == 2) fail(HLMI_EINVAL, "overlap %llu: a base that is not A, C, G, T or N", (unsigned long long)k);
+        pos3[k] = (int64_t)reads[i1[k]].len - (int64_t)p1[k] - (int64_t)reads[i2[k]].len;
+        if (h[k].status == 1 || h[k].len == 0) { score[k] = 0; mismatch_rate[k] = 1.0; continue; }
+        const double total_len = (double)h[k].len;
+        mismatch_rate[k] = (double)(float)h[k].mismatches / total_len;         // float(mismatch_count)/total_len
+        score[k] = exp((1.0 / total_len) * h[k].total);
+    }
 }
 
 }  // namespace hlmi

@@ -167,6 +167,16 @@ int hlmi_vq_parse_overlaps(const char *savage_path, uint32_t min_overlap_len, ui
  * lanes. */
 int hlmi_vq_transitive_edges(uint32_t n_vertices, uint64_t n_edges, const uint32_t *src, const uint32_t *dst,
                              const uint32_t *ovlen, int remove_trans, uint8_t *flags, uint64_t *n_transitive);
+/* EdgeCalculator::overlap_score (EdgeCalculator.cpp:26-139) for the single-single overlaps of an overlaps file
+ * (compute_overlap's "s"-"s" branch, :186-222 - the only one HyLight reaches: --num_pairs 0): for overlap k of `ov`
+ * (as returned by hlmi_vq_parse_overlaps) score[k] = exp(mean log-probability that the overlapping bases of the two reads
+ * of fastq_singles come from one sequence, given their phred qualities), 0 when a position's probability falls below
+ * `mismatch`, a read is shorter than `min_read_len` or pos1 lies behind read 1; mismatch_rate[k] as the reference sets it
+ * (1.0 where it returns early); pos3[k] = len1 - pos1 - len2 (Edge::set_extra_pos).  The per-position sums are taken in
+ * sequence order in double precision, log / pow / exp are the host's libm (tables by quality pair): the same arithmetic as
+ * the reference's.  Reads are looked up by the integer id of their "@<id>" line (strtoul base 0, FastqStorage.cpp:109-117). */
+int hlmi_vq_overlap_scores(const char *fastq_singles, const hlmi_vq_overlap *ov, uint64_t n, double mismatch,
+                           uint32_t min_read_len, double *score, double *mismatch_rate, int64_t *pos3);
 
 /* ---- staged multi-GPU job: sketch shard -> (RCCL all-gather by the caller) -> run -------- */
 /* One process per GPU.  Every rank opens the same files, sketches its slice of the query

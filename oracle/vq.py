@@ -9,6 +9,8 @@ reference.
   parse_overlaps       EdgeCalculator.cpp:561-666 (construct_edges, in front of process_overlaps), Overlap.h:37-72,196-203
   transitive_edges     GraphAlgos.cpp:746-795 (findTransEdges, nonemptyIntersect), :938-993 (removeTransitiveEdges up to
                        the deletion, incl. the branch-reduction schedule)
+  overlap_score        EdgeCalculator.cpp:26-139 (score, phred_to_prob, overlap_score) and the single-single branch of
+                       compute_overlap (:186-222) with Read.h:158-200 (reverse complement, reversed qualities) - round 3
 """
 import ctypes
 
@@ -139,3 +141,59 @@ def transitive_edges(n_vertices, src, dst, ovlen=None, remove_trans=1):
                 if (a == u and ovlen[j] <= L) or (b == v and ovlen[j] <= L):
                     flags[j] |= 2
     return flags, len(cur)
+
+
+# ---- quality-aware overlap score (EdgeCalculator.cpp:26-139) -----------------------------------------------------------
+import math
+
+_COMP = {"A": "T", "T": "A", "C": "G", "G": "C", "N": "N"}
+
+
+def phred_to_prob(phred):
+    """EdgeCalculator.cpp:62-66: pow(10, -phred/10.0)."""
+    return math.pow(10, -phred / 10.0)
+
+
+def overlap_score(seq1, seq2, score1, score2, pos, mismatch=0.0, min_read_len=0):
+    """EdgeCalculator.cpp:70-139 -> (score, mismatch_rate).  Doubles in the reference's order of operations; log / pow /
+    exp are the platform's libm on both sides."""
+    mismatch_rate = 1.0
+    if pos >= len(seq1):
+        return 0.0, mismatch_rate
+    if len(seq1) < min_read_len or len(seq2) < min_read_len:
+        return 0.0, mismatch_rate
+    L = min(len(seq1) - pos, len(seq2))
+    total_score, total_len, mismatch_count = 0.0, 0.0, 0
+    for i in range(L):
+        nt1, nt2 = seq1[i + pos], seq2[i]
+        assert nt1 in "ATCGN" and nt2 in "ATCGN"
+        p1, p2 = phred_to_prob(ord(score1[i + pos]) - 33), phred_to_prob(ord(score2[i]) - 33)
+        if nt1 == "N" or nt2 == "N":                        # score() returns 1: skipped
+            continue
+        if nt1 == nt2:
+            p = (1 - p1) * (1 - p2) + (p1 * p2) / 3.0
+        else:
+            p = p1 * (1 - p2) / 3.0 + p2 * (1 - p1) / 3.0 + (2 / 9.0) * p1 * p2
+            mismatch_count += 1
+        if p < mismatch:                                    # score() returns 2: unacceptable mismatch
+            return 0.0, mismatch_rate
+        total_score += math.log(p)
+        total_len += 1
+    if total_len == 0:
+        return 0.0, mismatch_rate
+    import numpy as np
+    mismatch_rate = float(np.float32(mismatch_count)) / total_len      # float(mismatch_count)/total_len
+    total_score = (1.0 / total_len) * total_score
+    return math.exp(total_score), mismatch_rate
+
+
+def single_single_edge(seq_a, phred_a, seq_b, phred_b, pos1, ori1, ori2, mismatch=0.0, min_read_len=0):
+    """compute_overlap, type1 == type2 == "s" (EdgeCalculator.cpp:186-222): reads upper-cased on loading
+    (FastqStorage.cpp:124), reverse complement / reversed qualities for a '-' orientation -> (score, mismatch_rate, pos3)."""
+    def oriented(seq, phred, fwd):
+        seq = seq.upper()
+        return (seq, phred) if fwd else ("".join(_COMP[c] for c in reversed(seq)), phred[::-1])
+    s1, q1 = oriented(seq_a, phred_a, ori1)
+    s2, q2 = oriented(seq_b, phred_b, ori2)
+    score, mr = overlap_score(s1, s2, q1, q2, pos1, mismatch, min_read_len)
+    return score, mr, len(s1) - pos1 - len(s2)

@@ -113,3 +113,79 @@ def test_library_transitive_edges_hub_vertex():
     want = OV.transitive_edges(n, src, dst)
     got = api.vq_transitive_edges(n, src, dst)
     assert got[1] == want[1] == n - 2 and got[0] == want[0]
+
+
+# ---- quality-aware overlap score (EdgeCalculator.cpp:26-139, round 3) -----------------------------------------------------
+def test_oracle_overlap_score_known_answers():
+    import math
+    # constant quality '=' (Q28: what HyLight.extend_con writes, HyLight.py:289-305), every base matching:
+    # p = (1 - e)^2 + e^2 / 3 per position, score = exp(mean log p) = p
+    e = math.pow(10, -28 / 10.0)
+    p = (1 - e) * (1 - e) + (e * e) / 3.0
+    s, mr = OV.overlap_score("ACGTACGTAC", "GTACGTAC", "=" * 10, "=" * 8, 2)
+    assert abs(s - p) < 1e-15 and mr == 0.0
+    # one substitution among 8 positions
+    px = e * (1 - e) / 3.0 + e * (1 - e) / 3.0 + (2 / 9.0) * e * e
+    s, mr = OV.overlap_score("ACGTACGTAC", "GTACCTAC", "=" * 10, "=" * 8, 2)
+    assert abs(s - math.exp((7 * math.log(p) + math.log(px)) / 8)) < 1e-15 and mr == 0.125
+    # that substitution is unacceptable once `mismatch` exceeds its probability; N positions do not count; early returns
+    assert OV.overlap_score("ACGTACGTAC", "GTACCTAC", "=" * 10, "=" * 8, 2, mismatch=0.01) == (0.0, 1.0)
+    s, mr = OV.overlap_score("ACGTACGTAC", "GTNCGTAC", "=" * 10, "=" * 8, 2)
+    assert abs(s - p) < 1e-15 and mr == 0.0
+    assert OV.overlap_score("ACGT", "ACGT", "====", "====", 4) == (0.0, 1.0)                 # pos behind read 1
+    assert OV.overlap_score("ACGT", "ACGT", "====", "====", 0, min_read_len=5) == (0.0, 1.0)
+    assert OV.overlap_score("NNNN", "ACGT", "====", "====", 0) == (0.0, 1.0)                 # no countable position
+    # orientation: read 2 reverse-complemented, its qualities reversed
+    s, mr, pos3 = OV.single_single_edge("ACGTACGTAC", "IIIIIIIII5", "GTACGTAC", "5IIIIIII", 2, True, False)
+    want, _ = OV.overlap_score("ACGTACGTAC", "GTACGTAC", "IIIIIIIII5", "IIIIIII5", 2)
+    assert s == want and pos3 == 0
+
+
+@pytest.mark.gpu
+def test_library_overlap_scores_match_oracle(tmp_path):
+    from hylight_amd import api
+    rng = random.Random(11)
+    reads = {}
+    fq = tmp_path / "singles.fastq"
+    with open(fq, "w") as f:
+        for k in range(1, 61):
+            n = rng.randint(160, 900)
+            seq = "".join(rng.choice("ACGT") for _ in range(n))
+            if k % 7 == 0:
+                seq = seq[:50] + "N" * 3 + seq[53:]
+            if k % 9 == 0:
+                seq = seq.lower()                                   # upper-cased on loading
+            q = "".join(chr(33 + rng.randint(2, 41)) for _ in range(n)) if k % 3 else "=" * n
+            reads[k] = (seq, q)
+            f.write(f"@{k} extra\n{seq}\n+\n{q}\n")
+    comp = {"A": "T", "T": "A", "C": "G", "G": "C", "N": "N"}
+    ovs = []
+    for _ in range(400):                                            # overlaps that really overlap, with a few substitutions
+        a, b = rng.sample(range(1, 61), 2)
+        ori1, ori2 = rng.random() < 0.7, rng.random() < 0.7
+        sa = reads[a][0].upper()
+        s1 = sa if ori1 else "".join(comp[c] for c in reversed(sa))
+        pos = rng.randint(0, len(s1) - 40)
+        # rewrite read b so that its oriented form continues read a's from pos (plus noise): keep its own qualities
+        L = len(reads[b][0])
+        tgt = (s1[pos:] + "".join(rng.choice("ACGT") for _ in range(L)))[:L]
+        tgt = "".join(c if rng.random() > 0.01 or c == "N" else rng.choice("ACGT") for c in tgt)
+        sb = tgt if ori2 else "".join(comp[c] for c in reversed(tgt))
+        ovs.append((a, b, pos, ori1, ori2, sb))
+    # every overlap gets its own copy of read b (ids 1000+)
+    with open(fq, "a") as f:
+        for k, (a, b, pos, ori1, ori2, sb) in enumerate(ovs):
+            reads[1000 + k] = (sb, reads[b][1])
+            f.write(f"@{1000 + k}\n{sb}\n+\n{reads[b][1]}\n")
+    recs = [dict(id1=a, id2=1000 + k, pos1=pos, ori1="+" if o1 else "-", ori2="+" if o2 else "-")
+            for k, (a, b, pos, o1, o2, sb) in enumerate(ovs)]
+    recs.append(dict(id1=1, id2=2, pos1=len(reads[1][0]) + 5, ori1="+", ori2="+"))          # pos behind read 1
+    for mismatch, min_len in ((0.0, 0), (1e-4, 0), (0.0, 400)):
+        got = api.vq_overlap_scores(fq, recs, mismatch=mismatch, min_read_len=min_len)
+        n_pos = 0
+        for r, (s, mr, p3) in zip(recs, got):
+            a, b = reads[r["id1"]], reads[r["id2"]]
+            ws, wmr, wp3 = OV.single_single_edge(a[0], a[1], b[0], b[1], r["pos1"], r["ori1"] == "+", r["ori2"] == "+", mismatch, min_len)
+            assert (s, mr, p3) == (ws, wmr, wp3), (r, s, ws)          # the same doubles, bit for bit
+            n_pos += s > 0
+        assert n_pos > (150 if mismatch == 0.0 and min_len == 0 else 10)
