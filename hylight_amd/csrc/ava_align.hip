@@ -502,9 +502,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             // (the first two substitutions' places: sixth certificate below)
             const int k_want = bonus_row ? (L == end_row ? a.kext_bonus : 0) : a.kext_plain;
             int x1 = -1, x2 = -1;
-            for (int x = 0; x < L && (same || (!amb_ext && (k_ext <= allow || k_ext <= k_want))); x += 8) {
-                const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, left != rev, rev, x);
-                const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, left, false, x);
+            auto more = [&]() { return same || (!amb_ext && (k_ext <= allow || k_ext <= k_want)); };
+            auto take8 = [&](int x, uint64_t q8, uint64_t t8) {
                 const int rest = L - x;
                 const uint64_t keep = rest >= 8 ? ~0ull : (1ull << (8 * rest)) - 1ull;
                 uint64_t d = (q8 ^ t8) & keep;
@@ -517,6 +516,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 }
                 k_ext += __popcll(d);
                 same = same && d == 0 && !amb_ext;
+            };
+            for (int x = 0; x < L && more(); x += 16) {            // two steps' loads in flight together
+                const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, left != rev, rev, x);
+                const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, left, false, x);
+                uint64_t q8b = 0, t8b = 0;
+                if (x + 8 < L) {
+                    q8b = load_window8p(a.qcodes, (long long)tk.qa, left != rev, rev, x + 8);
+                    t8b = load_window8p(a.tcodes, (long long)tk.ta, left, false, x + 8);
+                }
+                take8(x, q8, t8);
+                if (x + 8 < L && more()) take8(x + 8, q8b, t8b);
             }
             if (!same && !amb_ext && k_ext <= allow) { tk.kind |= TASK_ONE; ++st[ST_WIDE_ONE]; }
             if (same) {
@@ -591,34 +601,37 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             const int want = a.kgap1 && gap == 1 ? 2 : 1;
             int found_a = 0, found_b = 0, a1 = mn, a2 = mn, b1 = -1, b2 = -1;
             bool amb = false;
-            for (int x = 0; x < mn && found_a < want; x += 8) {
-                const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, rev, rev, x);
-                const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, false, false, x);
-                const int left = mn - x;
-                const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
-                amb |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
-                uint64_t d = (q8 ^ t8) & keep;
-                d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
-                while (d && found_a < want) {
-                    const int y = (__ffsll((long long)d) - 1) >> 3;
-                    d &= d - 1;
-                    if (found_a++ == 0) a1 = x + y; else a2 = x + y;
-                }
-            }
+            // both scans in one loop: the start diagonal forwards, the end diagonal backwards, their four loads of a trip in
+            // flight together (one after the other the kernel waited 80 % of its time on a chain of dependent trips)
             const int sq = m > n ? m - n : 0, st_ = n > m ? n - m : 0;   // shift of the end diagonal in q / t
-            for (int y = 0; y < mn && found_b < want; y += 8) {           // end diagonal, elements mn-8-y .. mn-1-y
-                const int e0 = mn - 8 - y;
-                const uint64_t q8 = load_window8p(a.qcodes, (long long)tk.qa, rev, rev, e0 + sq);
-                const uint64_t t8 = load_window8p(a.tcodes, (long long)tk.ta, false, false, e0 + st_);
-                const int left = mn - y;
-                const uint64_t keep = left >= 8 ? ~0ull : ~0ull << (8 * (8 - left));
-                amb |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
-                uint64_t d = (q8 ^ t8) & keep;
-                d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
-                while (d && found_b < want) {
-                    const int z = 7 - (__clzll((long long)d) >> 3);      // highest set byte
-                    d &= ~(0xffull << (8 * z));
-                    if (found_b++ == 0) b1 = e0 + z; else b2 = e0 + z;
+            for (int x = 0; x < mn && (found_a < want || found_b < want); x += 8) {
+                const bool da = found_a < want, db = found_b < want;
+                const int e0 = mn - 8 - x;                                // end diagonal: elements mn-8-x .. mn-1-x
+                uint64_t q8 = 0, t8 = 0, q8e = 0, t8e = 0;
+                if (da) { q8 = load_window8p(a.qcodes, (long long)tk.qa, rev, rev, x); t8 = load_window8p(a.tcodes, (long long)tk.ta, false, false, x); }
+                if (db) { q8e = load_window8p(a.qcodes, (long long)tk.qa, rev, rev, e0 + sq); t8e = load_window8p(a.tcodes, (long long)tk.ta, false, false, e0 + st_); }
+                const int left = mn - x;
+                if (da) {
+                    const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
+                    amb |= ((q8 | t8) & keep & 0x0404040404040404ull) != 0;
+                    uint64_t d = (q8 ^ t8) & keep;
+                    d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
+                    while (d && found_a < want) {
+                        const int y = (__ffsll((long long)d) - 1) >> 3;
+                        d &= d - 1;
+                        if (found_a++ == 0) a1 = x + y; else a2 = x + y;
+                    }
+                }
+                if (db) {
+                    const uint64_t keep = left >= 8 ? ~0ull : ~0ull << (8 * (8 - left));
+                    amb |= ((q8e | t8e) & keep & 0x0404040404040404ull) != 0;
+                    uint64_t d = (q8e ^ t8e) & keep;
+                    d = (d | d >> 1 | d >> 2) & 0x0101010101010101ull;
+                    while (d && found_b < want) {
+                        const int z = 7 - (__clzll((long long)d) >> 3);      // highest set byte
+                        d &= ~(0xffull << (8 * z));
+                        if (found_b++ == 0) b1 = e0 + z; else b2 = e0 + z;
+                    }
                 }
             }
             int p_star = -1, xpos = -1;
