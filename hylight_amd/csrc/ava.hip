@@ -278,6 +278,7 @@ void format_ava_row(const PafRec &r, const uint32_t *ops, const std::string &qna
         m = snprintf(buf, sizeof buf, "%u%c", ops[i] >> 4, opc[ops[i] & 15]);
         out.append(buf, m);
     }
+    if (!r.cig_n) out.push_back('*');          // the bare row of a stub candidate (hlmi_ava_opts::stub_oh)
 }
 
 void ava_files(const char *target_fa, const char *query_fa, const hlmi_ava_opts &o, const char *out_paf) {

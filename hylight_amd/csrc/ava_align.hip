@@ -157,6 +157,9 @@ struct AlignArgs {
     uint32_t cap_runs;
     uint32_t *counters;     // [0] runs cursor, [1] overflow
     uint32_t run_buf_cap;   // runs the first traceback walk may keep in LDS (test hook HLMI_RUN_BUF_CAP lowers it)
+    uint8_t *cls_bare;      // stub rule: DP class (1..4, as cls) of the tasks of stub CANDIDATE pieces - nobody reads their rows'
+                            // content, so these run the score-only kernels (no traceback planes, no walk, no runs); null: the
+                            // candidates' tasks are classified like the others
     uint8_t *defer_flag;    // classification: tasks left to the second pass (flag per task, then their list and its length)
     const uint32_t *defer_list, *defer_count;
 };
@@ -308,10 +311,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         }
         Task tk{};
         bool held = false;           // end extension of a stub candidate: decided after the piece's blocks are scored
+        bool bare = false;           // task of a stub candidate: only its score is wanted
         if (live) {
             const uint32_t pc = ref.pk & 0x3fffffffu, kind = ref.pk >> 30;
             const PieceGeom pg = a.geom.pg[pc];
             held = PASS == 1 && kind != 0 && pg.stub_cand != 0;
+            bare = a.cls_bare != nullptr && pg.stub_cand != 0;
             const FixPt f0 = a.geom.fps[ref.fp];
             FixPt f1{0, 0};
             if (kind == 0) f1 = a.geom.fps[ref.fp + 1];
@@ -672,6 +677,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             if (xs >= 0) { runs[nr++] = (uint32_t)(xe - xs) << 4 | OP_X; prev = xe; }
             if (m > prev) runs[nr++] = (uint32_t)(m - prev) << 4 | OP_EQ;
         }
+        if (bare) nr = 0;                                     // (the score is all a candidate's task reports)
         uint32_t wave_total;
         const uint32_t mine = wave_excl_sum_u32(nr, lane, wave_total);
         uint32_t base = 0;
@@ -710,7 +716,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             }
         }
         if (live) {
-            cls[ti] = c;
+            cls[ti] = bare ? 0 : c;
+            if (a.cls_bare) a.cls_bare[ti] = bare ? c : 0;
             if (c != 0) a.tasks[ti] = tk;                      // a DP kernel will want the record
             if (held) ++st[ST_STUB_EXT];
             else if (m > 0 && n > 0) {
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 else {
                     ++st[ST_DP];
                     if (c == 2 || c == 4) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
-                    else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m_dp; if (c == 1 && m_dp < NR_SMALL) ++st[ST_NARROW_SMALL]; }
+                    else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m_dp; if (c == 1 && m_dp < NR_SMALL && !bare) ++st[ST_NARROW_SMALL]; }
                 }
             }
         }
@@ -1036,7 +1043,8 @@ constexpr int PK_T0 = 12;                    // s_t2 index of target element dlo
 
 // sq2[i] = base i of the query windows of both tasks (A | B << 8); st2[PK_T0 - dlo + x] = target base x of each task,
 // i.e. both tasks read their row-i base of lane l at the same index PK_T0 + l - 1 + i
-template <bool AMBI, int NR_CHUNKS>
+// TB = false: scores only (tasks of stub candidates) - no traceback planes; H(m, n) of both tasks is kept instead
+template <bool AMBI, int NR_CHUNKS, bool TB = true>
 __device__ __forceinline__ void narrow_rows_pk(const AlignArgs &a, int rows, int mA, int mB, int dloA, int dloB, int l,
                                                const uint16_t *sq2, const uint16_t *st2, uint32_t (*plA)[NR_CHUNKS][64],
                                                uint32_t (*plB)[NR_CHUNKS][64], int lane, int &HendA, int &HendB) {
@@ -1069,16 +1077,19 @@ __device__ __forceinline__ void narrow_rows_pk(const AlignArgs &a, int rows, int
         const s2 e = s2_of(dpp_z<0x111>(int_of(p))) - v_goel;
         const s2 h = max2(ht, e);
         const s2 fo = h - v_goe, fe = f - v_ge, eo = e + v_go;
-        a0A = shift_in(a0A, mm.x == h.x);   a0B = shift_in(a0B, mm.y == h.y);
-        a1A = shift_in(a1A, e.x >= f.x);    a1B = shift_in(a1B, e.y >= f.y);
-        a2A = shift_in(a2A, eo.x > h.x);    a2B = shift_in(a2B, eo.y > h.y);
-        a3A = shift_in(a3A, fe.x > fo.x);   a3B = shift_in(a3B, fe.y > fo.y);
-        a4A = shift_in(a4A, x.x != 0);      a4B = shift_in(a4B, x.y != 0);
+        if (TB) {
+            a0A = shift_in(a0A, mm.x == h.x);   a0B = shift_in(a0B, mm.y == h.y);
+            a1A = shift_in(a1A, e.x >= f.x);    a1B = shift_in(a1B, e.y >= f.y);
+            a2A = shift_in(a2A, eo.x > h.x);    a2B = shift_in(a2B, eo.y > h.y);
+            a3A = shift_in(a3A, fe.x > fo.x);   a3B = shift_in(a3B, fe.y > fo.y);
+            a4A = shift_in(a4A, x.x != 0);      a4B = shift_in(a4B, x.y != 0);
+        }
         G = max2(fo, fe);
         H = h;
-        if (AMBI) { if (i == mA) HendA = h.x; if (i == mB) HendB = h.y; }
+        if (AMBI || !TB) { if (i == mA) HendA = h.x; if (i == mB) HendB = h.y; }
     };
     auto flush = [&](int c, int up) {
+        if (!TB) return;
         plA[PL_DIAG][c][lane] = a0A << up; plA[PL_EGEF][c][lane] = a1A << up; plA[PL_EEXT][c][lane] = a2A << up;
         plA[PL_FEXT][c][lane] = a3A << up; plA[PL_NE][c][lane] = a4A << up;
         plB[PL_DIAG][c][lane] = a0B << up; plB[PL_EGEF][c][lane] = a1B << up; plB[PL_EEXT][c][lane] = a2B << up;
@@ -1098,9 +1109,9 @@ __device__ __forceinline__ void narrow_rows_pk(const AlignArgs &a, int rows, int
 }
 
 constexpr int PK_WAVES = 1;          // waves per workgroup of the packed kernel: its LDS (12 KB per wave with 128 rows) sets the occupancy
-template <int NR_MAX>
+template <int NR_MAX, bool TB = true>
 __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArgs a) {
-    constexpr int NR_CHUNKS = NR_MAX / 32, NQ_STEPS = NR_MAX / 64, NT_STEPS = NR_MAX / 64 + 1;
+    constexpr int NR_CHUNKS = TB ? NR_MAX / 32 : 1, NQ_STEPS = NR_MAX / 64, NT_STEPS = NR_MAX / 64 + 1;
     constexpr int T2_LEN = NR_MAX + PK_T0 + NARROW_W + NARROW_DELTA + 12;
     // the run buffers of the walks share the LDS of the staged sequences (dead once the rows are done)
     constexpr int Q2_LEN = NR_MAX + 4, RUN_BUF = NR_MAX >= 128 ? RUN_BUF_NARROW : 40;
@@ -1168,13 +1179,22 @@ __global__ __launch_bounds__(64 * PK_WAVES) void align_narrow_pk_kernel(AlignArg
         const int rows = (int)wave_max_u32_dpp((uint32_t)(mA > mB ? mA : mB));       // (idle halves: m = 0)
         int HendA = 0, HendB = 0;
         const bool amb = __any(ambig);
-        if (amb) narrow_rows_pk<true, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, q2, t2, s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
-        else narrow_rows_pk<false, NR_CHUNKS>(a, rows, mA, mB, tA.dlo, tB.dlo, l, q2, t2, s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
+        if (amb) narrow_rows_pk<true, NR_CHUNKS, TB>(a, rows, mA, mB, tA.dlo, tB.dlo, l, q2, t2, s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
+        else narrow_rows_pk<false, NR_CHUNKS, TB>(a, rows, mA, mB, tA.dlo, tB.dlo, l, q2, t2, s_pl[wv][0], s_pl[wv][1], lane, HendA, HendB);
         // H(m, n) of each task sits in the lane of its end diagonal (quads with an ambiguous base only)
         const int endA = __shfl(HendA, g * 16 + ((tA.n - mA - tA.dlo) & (NARROW_W - 1)), 64) - DP_BIAS16;
         const int endB = __shfl(HendB, g * 16 + ((tB.n - mB - tB.dlo) & (NARROW_W - 1)), 64) - DP_BIAS16;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!TB) {                         // the score is H(m, n) (+ the trimmed matches): no walk, no runs
+            const int hf = l & 1;
+            if (l < 2 && (hf ? liveB : liveA)) {
+                const Task &t = hf ? tB : tA;
+                a.out[hf ? tiB : tiA] = TaskOut{(hf ? endB : endA) + a.match * t.trim, t.m, t.n, 0, 0, 0};
+            }
+            __builtin_amdgcn_wave_barrier();         // (the sequence area is the next pair's)
+            continue;
+        }
         // lanes 0 and 1 of every group walk the two tasks of the group
         const int hf = l & 1;
         const bool walker = l < 2 && (hf ? liveB : liveA);
@@ -1230,7 +1250,7 @@ constexpr int WT_LEN = WT_PAD + SEQ_T_MAX + 64;
 //   NE    q != t
 enum { WP_DIAG = 0, WP_EGEF, WP_EP, WP_FP, WP_EX1, WP_EX2, WP_FX1, WP_FX2, WP_NE, N_WPLANES };
 
-template <bool AMBI, bool EXT, bool TWO, int W_CHUNKS>
+template <bool AMBI, bool EXT, bool TWO, int W_CHUNKS, bool TB = true>
 __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int dlo, int lane, int end_row,
                                           const uint8_t *sq, const uint8_t *st, uint32_t (*pl)[W_CHUNKS][64], int &Hend,
                                           int &best_h, int &best_i) {
@@ -1266,18 +1286,22 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
         const int e = TWO && e2 > e1 ? e2 : e1;
         const int h = ht > e ? ht : e;
         const int fo = h - goe, fe = f1 - ge;
-        a0 = shift_in(a0, mm == h);
-        a1 = shift_in(a1, e >= f);
-        a2 = shift_in(a2, e1 + go > h);
-        a3 = shift_in(a3, fe > fo);
-        a4 = shift_in(a4, ne);
+        if (TB) {
+            a0 = shift_in(a0, mm == h);
+            a1 = shift_in(a1, e >= f);
+            a2 = shift_in(a2, e1 + go > h);
+            a3 = shift_in(a3, fe > fo);
+            a4 = shift_in(a4, ne);
+        }
         G = fo > fe ? fo : fe;
         if (TWO) {
             const int fo2 = h - goe2, fe2 = f2 - ge2;
-            b0 = shift_in(b0, e2 > e1);
-            b1 = shift_in(b1, f2 > f1);
-            b2 = shift_in(b2, e2 + go2 > h);
-            b3 = shift_in(b3, fe2 > fo2);
+            if (TB) {
+                b0 = shift_in(b0, e2 > e1);
+                b1 = shift_in(b1, f2 > f1);
+                b2 = shift_in(b2, e2 + go2 > h);
+                b3 = shift_in(b3, fe2 > fo2);
+            }
             G2 = fo2 > fe2 ? fo2 : fe2;
         }
         H = h;
@@ -1286,7 +1310,7 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
             const int hb = h + (i == end_row ? a.end_bonus : 0);
             if ((uint32_t)(i - imin) <= (uint32_t)span && span >= 0 && hb > best_h) { best_h = hb; best_i = i; }
         }
-        if ((i & 31) == 0) {
+        if (TB && (i & 31) == 0) {
             const int c = (i >> 5) - 1;
             pl[WP_DIAG][c][lane] = a0; pl[WP_EGEF][c][lane] = a1; pl[WP_EX1][c][lane] = a2; pl[WP_FX1][c][lane] = a3;
             pl[WP_NE][c][lane] = a4;
@@ -1294,7 +1318,7 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
         }
     }
     Hend = H;
-    if (m & 31) {
+    if (TB && (m & 31)) {
         const int c = m >> 5, up = 32 - (m & 31);
         pl[WP_DIAG][c][lane] = a0 << up; pl[WP_EGEF][c][lane] = a1 << up; pl[WP_EX1][c][lane] = a2 << up;
         pl[WP_FX1][c][lane] = a3 << up; pl[WP_NE][c][lane] = a4 << up;
@@ -1367,10 +1391,11 @@ __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, in
     return n_runs;
 }
 
-template <int ROWS_MAX>
+// TB = false: scores (and, for extensions, the cell they stop in) only: tasks of stub candidates
+template <int ROWS_MAX, bool TB = true>
 __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
-    constexpr int W_CHUNKS = ROWS_MAX / 32;
-    __shared__ uint32_t s_pl[WAVES][N_WPLANES][W_CHUNKS][64];
+    constexpr int W_CHUNKS = TB ? ROWS_MAX / 32 : 1;
+    __shared__ uint32_t s_pl[WAVES][TB ? N_WPLANES : 1][W_CHUNKS][64];
     __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][ROWS_MAX + 4];
     __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][WT_LEN];
     __shared__ uint32_t s_runs[WAVES][RUN_BUF_WIDE];
@@ -1415,8 +1440,8 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         const bool amb = __any(ambig);
         const bool two = a.go2 > 0 && !(tk.kind & TASK_ONE);
         auto rows_of = [&](auto AMB, auto EXTN, auto TW) {
-            wide_rows<decltype(AMB)::value, decltype(EXTN)::value, decltype(TW)::value, W_CHUNKS>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend,
-                                                                                                best_h, best_i);
+            wide_rows<decltype(AMB)::value, decltype(EXTN)::value, decltype(TW)::value, W_CHUNKS, TB>(a, m, n, dlo, lane, end_row, sq, st, pl, Hend,
+                                                                                                    best_h, best_i);
         };
         using T_ = std::true_type; using F_ = std::false_type;
         if (kind == 0) {
@@ -1448,6 +1473,10 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!TB) {
+            if (lane == 0) a.out[ti] = TaskOut{score, ei, ej, 0, 0, kind != 0 && ei == end_row ? 0x80000000u : 0u};
+            continue;
+        }
         uint32_t *rbuf = s_runs[wv];
         const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_WIDE ? a.run_buf_cap : (uint32_t)RUN_BUF_WIDE;
         uint32_t cp_n = 0, cp_off = 0;
@@ -1490,6 +1519,7 @@ struct AsmArgs {
     const PieceGeom *pg;        // stub rule: with `late` set, a stub candidate (pg[i].stub_cand) whose blocks alone do not reach
     uint8_t *late;              // stub_score is flagged here - its end extensions, held back so far, have to run after all
     int stub_score;
+    int bare;                   // 1: the rows of stub candidates are bare (no CIGAR, columns 10 / 11 zero): their tasks report scores only
 };
 
 // One wavefront per piece, one lane per task (64 tasks per step).  The row's CIGAR is the concatenation of the
@@ -1511,6 +1541,7 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
         const FixPt *fp = a.fps + p.fp_off;
         const TaskOut *to = a.tout + a.task_off[i];
         const uint32_t n_tasks = p.n_fp + 1;
+        const bool bare = a.bare && a.pg[i].stub_cand != 0;
         uint32_t *w = WRITE ? ops + ops_off[i] : nullptr;
         long long score = 0;
         unsigned long long nmatch = 0, blen = 0;
@@ -1525,12 +1556,12 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                 r = to[t];
                 keep = true;
                 if (t == 0 || t == n_tasks - 1)   // an extension counts when it gains something (bonus: decision only)
-                    keep = !(r.score + ((r.pad & 0x80000000u) ? a.end_bonus : 0) <= 0 || r.n_runs == 0);
+                    keep = !(r.score + ((r.pad & 0x80000000u) ? a.end_bonus : 0) <= 0 || (r.n_runs == 0 && !bare));
             }
             if (keep && t == 0) { ext_l_i = r.bi; ext_l_j = r.bj; }
             if (keep && t == n_tasks - 1 && t != 0) { ext_r_i = r.bi; ext_r_j = r.bj; }
             long long sc = keep ? r.score : 0;
-            const uint32_t nr = keep ? r.n_runs : 0;
+            const uint32_t nr = keep && !bare ? r.n_runs : 0;
             const uint32_t first = r.pad & 15u, last = (r.pad >> 4) & 15u;     // codes of the first / last run (TaskOut::pad)
             const unsigned long long ne_mask = __ballot(nr != 0);
             const unsigned long long below = ne_mask & ((1ull << lane) - 1ull);
@@ -1567,11 +1598,11 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
         const int ri = __shfl(ext_r_i, last_lane, 64), rj = __shfl(ext_r_j, last_lane, 64);
         if (!WRITE) {
             if (lane == 0) {
-                const bool ok = slots > 0 && score >= a.min_dp_score;
+                const bool ok = (slots > 0 || bare) && score >= a.min_dp_score;
                 valid[i] = ok ? 1 : 0;
                 n_ops[i] = ok ? slots : 0;
                 // (the extensions of a stub candidate have not run: `score` is the score of its blocks)
-                if (a.late) a.late[i] = a.pg[i].stub_cand && !(slots > 0 && score >= a.stub_score) ? 1 : 0;
+                if (a.late) a.late[i] = a.pg[i].stub_cand && !((slots > 0 || bare) && score >= a.stub_score) ? 1 : 0;
             }
             continue;
         }
@@ -1660,6 +1691,14 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     DBuf<uint32_t> late_idx(o.stub_oh >= 0 ? P : 0);
     size_t n_late = 0;
     const unsigned nba = (unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32);
+    // packed form of the near-diagonal DP (two tasks per lane, 16-bit scores): block scores must stay within +-4096 of the bias
+    const int worst = std::max(std::max(o.match, o.mismatch), std::max(o.ambi, o.gap_open + o.gap_ext));
+    const bool packed = worst > 0 && (long long)worst * (BLOCK_MAX + NARROW_W + 2) <= 4000 && o.match >= 0 && o.mismatch >= 0 &&
+                        o.ambi >= 0 && o.gap_open >= 0 && o.gap_ext >= 0 && !getenv("HLMI_NARROW_UNPACKED");
+    // stub rule, second half: nobody reads the content of a stub candidate's row, so its tasks report scores only (score-only
+    // instances of the packed and the 64-diagonal kernel; HLMI_STUB_FULL_ROWS keeps the candidates' CIGARs: test hook)
+    const bool bare = o.stub_oh >= 0 && packed && !getenv("HLMI_STUB_FULL_ROWS");
+    as.bare = bare ? 1 : 0;
     for (int attempt = 0;; ++attempt) {
         const size_t cap_runs = run_share + open_chunks;
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
@@ -1706,9 +1745,48 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         aa.run_buf_cap = 0xffffffffu;
         if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
         // pass 1: classify every task, finish the diagonal fast path right away
-        DBuf<uint8_t> cls(NT), f1(NT);
+        DBuf<uint8_t> cls(NT), f1(NT), cls_bare(bare ? NT : 0);
         DBuf<uint32_t> list1(NT), list2(NT), list3(NT), list4(NT);
         DBuf<uint32_t> list_n(4);
+        aa.cls_bare = bare ? cls_bare.p : nullptr;
+        // the tasks of stub candidates (cls_bare): score-only kernels over their own four lists
+        size_t n_bare_tasks = 0;
+        auto run_bare = [&]() {
+            if (!bare) return;
+            select_classes4_async(cls_bare.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
+            const std::vector<uint32_t> hb = list_n.download(4);
+            n_bare_tasks += (size_t)hb[0] + hb[1] + hb[2] + hb[3];
+            for (int which = 0; which < 2; ++which) {            // near-diagonal lists in ascending row order (octets run equally long)
+                DBuf<uint32_t> &lst = which ? list3 : list1;
+                const size_t nl = which ? hb[2] : hb[0];
+                if (nl < 8) continue;
+                DBuf<uint32_t> key(nl);
+                hipLaunchKernelGGL(task_rows_key_kernel, grid1(nl), dim3(WG), 0, stream(), tasks.p, lst.p, nl, key.p);
+                sort_pairs_u32_u32(key, lst, nl, 0, 7);
+            }
+            auto pk_grid = [](size_t n) { return dim3((unsigned)std::max<size_t>(1, std::min<size_t>(((n + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32))); };
+            auto w_grid = [](size_t n) { return dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + WAVES - 1) / WAVES, 256 * 16))); };
+            if (hb[0]) {
+                KTimer kt("align_score_narrow");
+                aa.list = list1.p; aa.n_list = hb[0];
+                hipLaunchKernelGGL((align_narrow_pk_kernel<NR_SHORT, false>), pk_grid(hb[0]), dim3(64 * PK_WAVES), 0, stream(), aa);
+            }
+            if (hb[2]) {
+                KTimer kt("align_score_narrow_long");
+                aa.list = list3.p; aa.n_list = hb[2];
+                hipLaunchKernelGGL((align_narrow_pk_kernel<BLOCK_MAX, false>), pk_grid(hb[2]), dim3(64 * PK_WAVES), 0, stream(), aa);
+            }
+            if (hb[1]) {
+                KTimer kt("align_score_wide");
+                aa.list = list2.p; aa.n_list = hb[1];
+                hipLaunchKernelGGL((align_kernel<EXT_MAX, false>), w_grid(hb[1]), dim3(WG), 0, stream(), aa);
+            }
+            if (hb[3]) {
+                KTimer kt("align_score_wide_short");
+                aa.list = list4.p; aa.n_list = hb[3];
+                hipLaunchKernelGGL((align_kernel<WIDE_SHORT, false>), w_grid(hb[3]), dim3(WG), 0, stream(), aa);
+            }
+        };
         {
             KTimer kt("align_classify");
             const unsigned nbc = (unsigned)std::min<size_t>(cdiv(NT, (size_t)WG), MAX_BLOCKS);
@@ -1733,10 +1811,6 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             sort_pairs_u32_u32(key, lst, nl, 0, 7);
         }
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
-        // packed form (two tasks per lane, 16-bit scores): block scores must stay within +-4096 of the bias
-        const int worst = std::max(std::max(o.match, o.mismatch), std::max(o.ambi, o.gap_open + o.gap_ext));
-        const bool packed = worst > 0 && (long long)worst * (BLOCK_MAX + NARROW_W + 2) <= 4000 && o.match >= 0 && o.mismatch >= 0 &&
-                            o.ambi >= 0 && o.gap_open >= 0 && o.gap_ext >= 0 && !getenv("HLMI_NARROW_UNPACKED");
         if (n1 && packed) {
             // the list is in ascending row order: its head (fewer than NR_SMALL rows, counted by the classifier)
             // runs in the instance with half the plane LDS and twice the resident waves
@@ -1789,6 +1863,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             }
         };
         run_wide(n2, n4);
+        run_bare();
         size_t n_wide_late = 0;
         if (o.stub_oh >= 0) {
             // Stub rule (hlmi_ava_opts::stub_oh; proof at oracle/ava_oracle.c:is_stub).  The end extensions of the stub
@@ -1808,16 +1883,23 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                 hipLaunchKernelGGL(late_tasks_kernel, grid1(n_late), dim3(WG), 0, stream(), late_idx.p, n_late, ch.pieces.p, toff.p,
                                    list1.p, list_n.p);
                 HIP_CHECK(hipMemsetAsync(cls.p, 0, NT, stream()));
+                if (bare) HIP_CHECK(hipMemsetAsync(cls_bare.p, 0, NT, stream()));
                 {
                     KTimer kt("align_classify");
                     aa.defer_list = list1.p; aa.defer_count = list_n.p;
                     const unsigned nb2 = (unsigned)std::min<size_t>(cdiv(2 * n_late, (size_t)WG), MAX_BLOCKS);
                     hipLaunchKernelGGL(classify_kernel<2>, dim3(nb2 ? nb2 : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
                 }
-                select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
-                const std::vector<uint32_t> hl = list_n.download(4);
-                run_wide(hl[1], hl[3]);
-                n_wide_late = (size_t)hl[1] + hl[3];
+                if (bare) {                        // (every late task belongs to a candidate)
+                    const size_t before = n_bare_tasks;
+                    run_bare();
+                    n_wide_late = n_bare_tasks - before;
+                } else {
+                    select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
+                    const std::vector<uint32_t> hl = list_n.download(4);
+                    run_wide(hl[1], hl[3]);
+                    n_wide_late = (size_t)hl[1] + hl[3];
+                }
                 as.plist = late_idx.p; as.n_pieces = n_late;
                 const unsigned nbl = (unsigned)std::min<size_t>(cdiv(n_late, (size_t)WAVES), 256 * 32);
                 {
@@ -1828,7 +1910,10 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                 as.plist = nullptr; as.n_pieces = P;
             }
         }
-        if (attempt == 0) { stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)(n2 + n4 + n_wide_late)); }
+        if (attempt == 0) {
+            stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)(n2 + n4 + (bare ? 0 : n_wide_late)));
+            stat_add("align_tasks_score_only", (double)n_bare_tasks);
+        }
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> hc = counters.download(2);
         if (!hc[1]) break;

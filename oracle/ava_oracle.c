@@ -443,10 +443,12 @@ static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t,
 }
 
 /* one chain (anchors ascending) -> alignment pieces -> PAF rows */
-static void emit_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const seqset_t *T, int ti, int strand, piece_t *p) {
+/* bare: the row of a stub candidate (see is_stub_candidate) - its content never reaches anybody, so it carries none: columns
+ * 10 and 11 are 0 and the CIGAR is "*" */
+static void emit_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const seqset_t *T, int ti, int strand, piece_t *p, int bare) {
     if (p->cg.n && p->score >= o->min_dp_score) {
         long nm = 0, bl = 0;
-        for (int x = 0; x < p->cg.n; ++x) {
+        for (int x = 0; x < p->cg.n && !bare; ++x) {
             long l = p->cg.op[x] >> 4;
             bl += l;
             if ((p->cg.op[x] & 15) == 7) nm += l;
@@ -455,10 +457,11 @@ static void emit_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi
         int qs = strand ? ql - p->qe : p->qs, qe = strand ? ql - p->qs : p->qe;
         fprintf(out, "%s\t%d\t%d\t%d\t%c\t%s\t%d\t%d\t%d\t%ld\t%ld\t0\tNM:i:%ld\ttp:A:S\tcg:Z:", Q->name[qi], ql, qs, qe,
                 strand ? '-' : '+', T->name[ti], T->len[ti], p->ts, p->te, nm, bl, bl - nm);
-        for (int x = 0; x < p->cg.n; ++x) {
+        for (int x = 0; x < p->cg.n && !bare; ++x) {
             static const char opc[16] = {'?', 'I', 'D', '?', '?', '?', '?', '=', 'X', '?', '?', '?', '?', '?', '?', '?'};
             fprintf(out, "%u%c", p->cg.op[x] >> 4, opc[p->cg.op[x] & 15]);
         }
+        if (bare) fputc('*', out);
         fputc('\n', out);
     }
     p->cg.n = 0;
@@ -499,24 +502,33 @@ static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const ui
  * line of the consumer's 1000-line windows, so it has to be written exactly when the full specification writes it:
  * score >= min_dp_score.  Extensions only add a positive score, except that one reaching the query end may be taken
  * with a score down to 1 - end_bonus; such an end is not an interior end, so blocks >= min_dp_score + end_bonus
- * decides "reported" before any extension has run.  Such a piece is written without its end extensions. */
-static int is_stub(const ava_opts_t *o, const piece_t *p, int ql, int tl) {
+ * decides "reported" before any extension has run.  Such a piece is written without its end extensions.
+ * A piece that meets the geometric half of the rule - a stub CANDIDATE - fails the consumer's test whether or not it is
+ * extended, so nobody ever reads its row's content: a candidate's row (extended or not) is written bare (columns 10, 11 = 0,
+ * CIGAR "*"; the consumer's first test drops a row of length 0 without a division).  The product therefore computes only the
+ * SCORES of a candidate's blocks and extensions. */
+static int is_stub_candidate(const ava_opts_t *o, const piece_t *p, int ql, int tl) {
     if (o->stub_oh < 0 || g_ext_max != EXT_MAX || g_ext_band != BAND_W) return 0;
-    const int h = o->stub_oh, bonus = o->end_bonus > 0 ? o->end_bonus : 0;
-    if (!p->cg.n || p->score < o->min_dp_score + bonus) return 0;
+    const int h = o->stub_oh;
     return (p->qs > EXT_MAX + h && p->ts > EXT_MAX + BAND_W + h) || (ql - p->qe > EXT_MAX + h && tl - p->te > EXT_MAX + BAND_W + h);
+}
+static int is_stub(const ava_opts_t *o, const piece_t *p, int ql, int tl) {
+    const int bonus = o->end_bonus > 0 ? o->end_bonus : 0;
+    if (!p->cg.n || p->score < o->min_dp_score + bonus) return 0;
+    return is_stub_candidate(o, p, ql, tl);
 }
 
 static void close_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa, const seqset_t *T, int ti,
                         int strand, piece_t *p, uint32_t *scratch) {
     const int ql = Q->len[qi], tl = T->len[ti];
+    const int cand = is_stub_candidate(o, p, ql, tl);      /* (on the unextended piece, as the stub test itself) */
     const int stub = is_stub(o, p, ql, tl);
     if (!stub) {
         extend_left(o, qa, T->code[ti], p, scratch);
         extend_right(o, qa, ql, T->code[ti], tl, p, scratch);
     }
     if (p->cg.n && p->score >= o->min_dp_score) { ++g_n_pieces; g_n_stubs += stub; }
-    emit_piece(out, o, Q, qi, T, ti, strand, p);
+    emit_piece(out, o, Q, qi, T, ti, strand, p, cand);
 }
 
 static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa /* aligned orientation */,

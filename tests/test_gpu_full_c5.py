@@ -54,7 +54,7 @@ def test_c5_slices_merge_to_the_full_pass(c5):
     assert same_file(merged, out)
 
 
-@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_NARROW_LONG_UNPACKED", "HLMI_CHAIN_UNPACKED", "HLMI_NO_STUB"])
+@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_NARROW_LONG_UNPACKED", "HLMI_STUB_FULL_ROWS", "HLMI_CHAIN_UNPACKED", "HLMI_NO_STUB"])
 def test_c5_fallback_forms_agree_on_a_slice(c5, monkeypatch, var):
     d, cfg, r, out, rows, st = c5
     monkeypatch.setenv(var, "1")

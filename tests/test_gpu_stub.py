@@ -66,3 +66,10 @@ def test_stage_output_does_not_depend_on_the_rule(divergent, monkeypatch):
     assert st_on["ava_rows"] == st_off["ava_rows"] and st_on["rows_after_v4"] == st_off["rows_after_v4"]
     assert st_on["align_ext_held"] > 0 and st_off.get("align_ext_held", 0) == 0
     assert st_on["align_tasks_wide"] < st_off["align_tasks_wide"]
+    # the candidates' tasks report scores only: fewer CIGAR ops come out of the overlapper, the same final rows
+    assert st_on["align_tasks_score_only"] > 0 and st_on["cigar_ops"] < 0.7 * st_off["cigar_ops"]
+    monkeypatch.delenv("HLMI_NO_STUB")
+    monkeypatch.setenv("HLMI_STUB_FULL_ROWS", "1")                  # stubs, but with their blocks' CIGARs (the round-3a form)
+    full = d / "full_rows.paf"
+    api.split_reads2(fa, fa, 4, d, full, long=True, **stage)
+    assert open(full).read() == open(on).read() and api.last_stats()["align_tasks_score_only"] == 0
