@@ -5,7 +5,7 @@ are queries of every chunk); of the --nsplit target chunks the test runs as many
 (the reference's unit of work, utils.py:54: one worker per chunk; 1/7.5 of one rank's share of an 8-rank job), four of
 C4's 1000 (1/31 of a rank's share).  The pair-once rule (strcmp(qname, tname) < 0) makes a chunk's work proportional to
 the rank of its targets' names: chunk 40 of C5 (reads r333k..r341k) sits in the middle.  A whole C5 pass is ~60 of these,
-i.e. ~5 minutes on one card.  The read sets are made by the block-parallel simulator
+i.e. ~2.5 minutes on one card.  The read sets are made by the block-parallel simulator
 (hylight_amd/simulate.py:simulate_reads_to_fasta) in seconds."""
 import os
 import time
