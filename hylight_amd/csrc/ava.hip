@@ -181,7 +181,12 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         // (never below 8192: a batch of many short reads rather takes the wider anchor form than ends early)
         size_t q_floor = 8192;
         if (const char *e = getenv("HLMI_QCAP_MIN")) q_floor = (size_t)std::max(1, atoi(e));      // tuning hook
-        q_cap = std::min<size_t>(q_cap, std::max<size_t>(q_floor, (size_t)1 << std::max(0, std::min(spare, 16))));
+        // (when even q_floor queries do not fit the one-word form, the batch takes the word + small-key form anyway - the
+        //  (target, strand) bits travel apart - and only its own widths bound the batch: on the full C4, 4 000 targets per
+        //  sub-run, batches of 8 192 queries held a third of the anchors a batch is sized for)
+        const int spare_split = 64 - (bits_for(max_tlen) + bits_for(std::max<uint64_t>(ql[k98], 1)) + 8);
+        const int use = ((size_t)1 << std::max(0, std::min(spare, 16))) >= q_floor ? spare : spare_split;
+        q_cap = std::min<size_t>(q_cap, std::max<size_t>(q_floor, (size_t)1 << std::max(0, std::min(use, 16))));
         // the widest anchor form (key + value) still keeps query, target, strand and target position in one 64-bit key
         const int key_spare = 64 - (bits_for(nT > 1 ? nT - 1 : 1) + 1 + bits_for(max_tlen));
         q_cap = std::min<size_t>(q_cap, (size_t)1 << std::max(0, std::min(key_spare, 16)));
@@ -223,6 +228,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
 
     // ---- concatenate + stream order ---------------------------------------------------------------------
     HostTimer ht_concat("concat_order");
+    HostTimer *ht_part = new HostTimer("concat_alloc");
     size_t R = 0, E = 0;
     for (auto &p : parts) { R += p.n_rows; E += p.n_ops; }
     stat_add("ava_rows", (double)R);
@@ -231,6 +237,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     DBuf<PafRec> recs(R);
     DBuf<uint64_t> hi64(R), lo64(R);
     out.ops.alloc(E ? E : 1);
+    delete ht_part; ht_part = new HostTimer("concat_copy");
     size_t r0 = 0, e0 = 0;
     for (auto &p : parts) {
         HIP_CHECK(hipMemcpyAsync(recs.p + r0, p.recs.p, p.n_rows * sizeof(PafRec), hipMemcpyDeviceToDevice, stream()));
@@ -242,7 +249,9 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         e0 += p.n_ops;
     }
     sync();
+    delete ht_part; ht_part = new HostTimer("concat_free_parts");
     parts.clear();
+    delete ht_part; ht_part = new HostTimer("concat_order_sort");
     DBuf<uint32_t> perm(R);
     hipLaunchKernelGGL(iota_kernel, grid1(R), dim3(WG), 0, stream(), perm.p, R);
     sort_pairs_u64_u32(lo64.p, perm.p, R);
@@ -252,7 +261,9 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     out.recs.alloc(R);
     hipLaunchKernelGGL(gather_rows_kernel, grid1(R), dim3(WG), 0, stream(), recs.p, perm.p, out.recs.p, R);
     HIP_CHECK(hipGetLastError());
+    delete ht_part; ht_part = new HostTimer("concat_download");
     std::vector<uint64_t> h_hi = hi_g.download(R);
+    delete ht_part;
     out.n_rows = R;
     out.n_ops = E;
     size_t i = 0;
