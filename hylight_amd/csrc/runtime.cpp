@@ -3,6 +3,8 @@
 
 #include "common.h"
 
+#include <iterator>
+
 namespace hlmi {
 
 namespace {
@@ -111,14 +113,46 @@ constexpr size_t POOL_CAP = 160ull << 30;                // keep at most this mu
 constexpr size_t GRAN = 2ull << 20;
 }  // namespace
 
+// Size classes: multiples of 2 MiB up to 64 MiB, above that multiples of an eighth of the size's power of two (at most 12.5 %
+// of slack): the multi-GB buffers of consecutive query batches differ by a few per cent and then fall into the same class, so a
+// released block serves the next batch instead of sitting in the cache beside a fresh hipMalloc (full C4: the cache grew until
+// the card was full, everything was trimmed and allocated again - the steps of a pass took 9, 12, 25 s).
+static size_t size_class(size_t bytes) {
+    size_t want = (bytes + GRAN - 1) / GRAN * GRAN;
+    if (want > (64ull << 20)) {
+        size_t p2 = 1;
+        while ((p2 << 1) <= want) p2 <<= 1;
+        const size_t step = p2 >> 3;
+        want = (want + step - 1) / step * step;
+    }
+    return want;
+}
+
 void *dev_alloc(size_t bytes) {
-    const size_t want = (bytes + GRAN - 1) / GRAN * GRAN;
+    const size_t want = size_class(bytes);
     auto it = g_free_blocks.lower_bound(want);
     if (it != g_free_blocks.end() && it->first <= want + want / 2) {
         void *p = it->second;
         g_pooled_bytes -= it->first;
         g_free_blocks.erase(it);
         return p;
+    }
+    // a miss: make room first when the card is nearly full - cached blocks go, largest first, until the request fits (a failed
+    // hipMalloc and a trim of everything cost a second per 30 GB that has to be allocated again)
+    if (!g_free_blocks.empty()) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            bool drained = false;
+            while (free_b < want + (1ull << 30) && !g_free_blocks.empty()) {
+                if (!drained) { if (g_stream) (void)hipStreamSynchronize(g_stream); drained = true; }   // queued kernels may still use a cached block
+                auto big = std::prev(g_free_blocks.end());
+                (void)hipFree(big->second);
+                g_block_size.erase(big->second);
+                g_pooled_bytes -= big->first;
+                free_b += big->first;
+                g_free_blocks.erase(big);
+            }
+        } else (void)hipGetLastError();
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
