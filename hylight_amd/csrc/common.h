@@ -62,6 +62,7 @@ std::map<std::string, double> &stats();
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_pool_trim();            // give every cached block back to the driver
+size_t dev_available_bytes();    // free on the card + cached in the pool (0: unknown)
 
 // ------------------------------------------------------------------------------------------
 // device buffer (RAII)

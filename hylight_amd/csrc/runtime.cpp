@@ -167,6 +167,12 @@ void *dev_alloc(size_t bytes) {
     return p;
 }
 
+size_t dev_available_bytes() {           // free on the card + cached here: what a run can still take
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return free_b + g_pooled_bytes;
+}
+
 void dev_free(void *p) {
     auto it = g_block_size.find(p);
     if (it == g_block_size.end()) { (void)hipFree(p); return; }
