@@ -82,14 +82,19 @@ struct AvaInput {
     // batch's bytes per anchor (divergent read sets carry five times the CIGAR ops per anchor of clean ones)
     uint64_t max_out_bytes = 0;
 };
-// HBM a run's output occupies until the caller has filtered it: CIGAR ops twice (per batch, then concatenated), the
+// HBM a run's output occupies until the caller has filtered it: CIGAR ops once (they stay in their batch buffers), the
 // 64-byte records three times (per batch, concatenated, stream-ordered) plus their order keys
-inline uint64_t ava_out_bytes(uint64_t rows, uint64_t ops) { return 8 * ops + 216 * rows; }
+inline uint64_t ava_out_bytes(uint64_t rows, uint64_t ops) { return 4 * ops + 216 * rows; }
 
 struct AvaRows {            // overlapper output in stream order (chunk, query, target, strand, chain, piece)
     size_t n_rows = 0, n_ops = 0;
     DBuf<PafRec> recs;
-    DBuf<uint32_t> ops;
+    // The CIGAR ops stay where the alignment passes of the query batches wrote them (one buffer per batch or span): a row's
+    // cig_off counts 4-byte words from `ops_base`, the lowest of those buffers.  (Round 2 copied them into one array: 92 GB
+    // per bench step on the full C4, and the rows' ops sat in HBM twice while that happened.)
+    std::vector<DBuf<uint32_t>> ops_parts;
+    std::vector<uint64_t> ops_part_len;      // ops in each part
+    const uint32_t *ops_base = nullptr;
     std::vector<uint64_t> chunk_row_start;   // n_chunks+1
     uint64_t refused_anchors = 0;            // != 0: the run was given up, it would have had this many anchors ...
     double refused_shrink = 1.0;             // ... and fits when the targets shrink by this factor

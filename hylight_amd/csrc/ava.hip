@@ -236,17 +236,22 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     if (!R) return;
     DBuf<PafRec> recs(R);
     DBuf<uint64_t> hi64(R), lo64(R);
-    out.ops.alloc(E ? E : 1);
+    uintptr_t base_addr = ~(uintptr_t)0;
+    for (auto &p : parts) if (p.n_ops) base_addr = std::min(base_addr, (uintptr_t)p.ops.p);
+    if (base_addr == ~(uintptr_t)0) base_addr = 0;
+    out.ops_base = (const uint32_t *)base_addr;
     delete ht_part; ht_part = new HostTimer("concat_copy");
     size_t r0 = 0, e0 = 0;
     for (auto &p : parts) {
         HIP_CHECK(hipMemcpyAsync(recs.p + r0, p.recs.p, p.n_rows * sizeof(PafRec), hipMemcpyDeviceToDevice, stream()));
         HIP_CHECK(hipMemcpyAsync(hi64.p + r0, p.ord_hi.p, p.n_rows * 8, hipMemcpyDeviceToDevice, stream()));
         HIP_CHECK(hipMemcpyAsync(lo64.p + r0, p.ord_lo.p, p.n_rows * 8, hipMemcpyDeviceToDevice, stream()));
-        if (p.n_ops) HIP_CHECK(hipMemcpyAsync(out.ops.p + e0, p.ops.p, p.n_ops * 4, hipMemcpyDeviceToDevice, stream()));
-        if (e0) hipLaunchKernelGGL(shift_cigar_kernel, grid1(p.n_rows), dim3(WG), 0, stream(), recs.p + r0, p.n_rows, (uint64_t)e0);
+        const uint64_t shift = p.n_ops ? (uint64_t)(((uintptr_t)p.ops.p - base_addr) / 4) : 0;     // the part's ops stay in place
+        if (shift) hipLaunchKernelGGL(shift_cigar_kernel, grid1(p.n_rows), dim3(WG), 0, stream(), recs.p + r0, p.n_rows, shift);
         r0 += p.n_rows;
         e0 += p.n_ops;
+        out.ops_part_len.push_back(p.n_ops);
+        out.ops_parts.push_back(std::move(p.ops));
     }
     sync();
     delete ht_part; ht_part = new HostTimer("concat_free_parts");
@@ -322,10 +327,27 @@ void ava_files(const char *target_fa, const char *query_fa, const hlmi_ava_opts 
     ava_device(in, o, rows);
     ktimer_flush();
     std::vector<PafRec> hr = rows.recs.download(rows.n_rows);
-    std::vector<uint32_t> hops = rows.ops.download(rows.n_ops);
+    // the parts of the CIGAR array, on the host one after the other: a row's offset from ops_base -> its place there
+    std::vector<uint32_t> hops;
+    std::vector<std::pair<uint64_t, uint64_t>> where;          // (first word of the part counted from ops_base, its place in hops)
+    for (size_t k = 0; k < rows.ops_parts.size(); ++k) {
+        if (!rows.ops_part_len[k]) continue;
+        where.emplace_back((uint64_t)(rows.ops_parts[k].p - rows.ops_base), hops.size());
+        const std::vector<uint32_t> part = rows.ops_parts[k].download(rows.ops_part_len[k]);
+        hops.insert(hops.end(), part.begin(), part.end());
+    }
+    std::sort(where.begin(), where.end());
     std::vector<std::string> lines(rows.n_rows);
-    for (size_t i = 0; i < rows.n_rows; ++i)
-        format_ava_row(hr[i], hops.data() + hr[i].cig_off, name_of_rank[hr[i].qid], name_of_rank[hr[i].tid], lines[i]);
+    static const uint32_t no_ops[1] = {0};
+    for (size_t i = 0; i < rows.n_rows; ++i) {
+        const uint32_t *ops = no_ops;
+        if (hr[i].cig_n) {
+            auto it = std::upper_bound(where.begin(), where.end(), std::pair<uint64_t, uint64_t>(hr[i].cig_off, ~(uint64_t)0));
+            --it;
+            ops = hops.data() + it->second + (hr[i].cig_off - it->first);
+        }
+        format_ava_row(hr[i], ops, name_of_rank[hr[i].qid], name_of_rank[hr[i].tid], lines[i]);
+    }
     write_lines(out_paf, lines);
 }
 

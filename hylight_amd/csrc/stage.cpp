@@ -281,7 +281,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
             const uint64_t r0 = rows.chunk_row_start[c0], r1 = rows.chunk_row_start[c1];
             std::vector<uint64_t> crs(rows.chunk_row_start.begin() + c0, rows.chunk_row_start.begin() + c1 + 1);
             for (auto &v : crs) v -= r0;
-            filter_stage_device(rows.recs.p + r0, (size_t)(r1 - r0), rows.ops.p, crs, cfg, fo);
+            filter_stage_device(rows.recs.p + r0, (size_t)(r1 - r0), rows.ops_base, crs, cfg, fo);
             n_v4 += fo.n_after_v4; n_ev += fo.n_events; n_pairs += fo.n_pairs;
             const double tf = now_s();
             std::vector<PafRec> kept = download_rows(rows.recs.p + r0, fo.rows);
