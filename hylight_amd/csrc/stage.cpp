@@ -32,6 +32,9 @@ struct Job::Impl {
     DevSketch own;                    // sketch owned by the job (single-GPU path)
     const Mz *d_qmz = nullptr;        // installed query sketch (own.mz or caller memory)
     std::vector<uint64_t> qmz_off;
+    // anchors / output bytes per target base seen by the last pass over this job: the next pass sizes its first sub-run
+    // from them instead of probing with 128 Mbases (and being refused on deep read sets)
+    double est_anchors_per_base = 0, est_out_per_base = 0;
 };
 
 static double now_s() {
@@ -201,6 +204,11 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     uint64_t budget_bases = 128ull << 20;
     if (const char *e = getenv("HLMI_SUBRUN_MBASES")) budget_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
     const bool fixed_budget = getenv("HLMI_SUBRUN_MBASES") != nullptr;
+    if (!fixed_budget && m.est_anchors_per_base > 0) {
+        const double by_anchors = subrun_anchors / m.est_anchors_per_base;
+        const double by_bytes = m.est_out_per_base > 0 ? subrun_out / m.est_out_per_base : by_anchors;
+        budget_bases = std::min<uint64_t>(SUBRUN_MAX_BASES, std::max<uint64_t>(4ull << 20, (uint64_t)(0.9 * std::min(by_anchors, by_bytes))));
+    }
     // the rows' text: every formatting thread appends to a buffer of its own, `lines` are views into those buffers
     std::vector<std::string_view> lines;
     std::vector<std::unique_ptr<std::string>> text;
@@ -316,6 +324,10 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         }
         t_fmt += t_fmt_sub;
         t_flt += now_s() - t1 - t_fmt_sub;
+    }
+    if (done_bases && done_anchors > 0) {
+        m.est_anchors_per_base = done_anchors / (double)done_bases;
+        m.est_out_per_base = done_out_bytes / (double)done_bases;
     }
     stat_set("subruns", (double)n_subruns);
     stat_set("rows_after_v4", (double)n_v4);
