@@ -623,12 +623,14 @@ __device__ __forceinline__ void dp16_prepare(Dp16State &z, const int *pen_tab, u
     const int tj = row_lane<J>(z.M_t), qj = row_lane<J>(z.M_q);
     z.M_t = select_by_mask(me, z.N_t, z.M_t); z.M_q = select_by_mask(me, z.N_q, z.M_q); z.M_s = select_by_mask(me, z.N_s, z.M_s);
     const uint32_t dr = (uint32_t)(z.M_t - tj), dq = (uint32_t)(z.M_q - qj);          // 4 x gap; a negative gap is huge
-    const uint32_t lo = dr < dq ? dr : dq, hi = dr < dq ? dq : dr;
+    const uint32_t hi = dr < dq ? dq : dr;
     uint32_t di = sad_u32(dr, dq, 0u);
     di = di < bw4 ? di : bw4;
     const int pen = *(const int *)((const char *)pen_tab + di);
-    const uint32_t mn = lo < (uint32_t)z.M_s ? lo : (uint32_t)z.M_s;
-    z.w = ((lo >= 4u) & (hi <= lim4)) ? (int)(mn << 6) + pen : PK_NEG;
+    // the smaller gap, capped by the span (>= k for an anchor, 0 in the lanes past the group's end): one v_min3, and
+    // "both gaps >= 1" is a test of that minimum
+    const uint32_t mn = min(min(dr, dq), (uint32_t)z.M_s);
+    z.w = ((mn >= 4u) & (hi <= lim4)) ? (int)(mn << 6) + pen : PK_NEG;
 }
 // steps J .. 15 of a block: finish the sender, push it, prepare the next one
 template <int J>
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(64 * D16_WAVES) void chain_dp16_kernel(ChainArgs a,
 // over its four groups (dp16_groups); a group with the proof only needs the chain bookkeeping, read from fp, a group
 // without it takes the 64-predecessor DP as before, a group that cannot reach the minimum score is dropped.
 template <int TAB, int MODE = 0>
-__global__ __launch_bounds__(64 * CHAIN_WAVES) void chain_kernel(ChainArgs a) {
+__global__ __launch_bounds__(64 * CHAIN_WAVES) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 8 : 4, 8))) void chain_kernel(ChainArgs a) {
     static_assert(MODE == 0 || TAB == 3, "the 16-predecessor pass uses the packed table");
     typedef typename std::conditional<TAB == 1, uint8_t, typename std::conditional<TAB == 3, int, uint16_t>::type>::type pen_t;
     __shared__ pen_t pen_tab[TAB ? PEN_TAB : 1];

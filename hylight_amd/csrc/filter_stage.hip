@@ -565,7 +565,7 @@ __global__ __launch_bounds__(WG) void pile_tiny_events_kernel(const PafRec *recs
 }
 
 template <int PILE_WG, typename CT>
-__global__ __launch_bounds__(PILE_WG) void snp_pileup_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *ent_rec,
+__global__ __launch_bounds__(PILE_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void snp_pileup_kernel(const PafRec *recs, const uint32_t *ops, const uint32_t *ent_rec,
                                                               const uint32_t *row_pair, const uint64_t *ent_key, const uint32_t *ent_val,
                                                               const uint32_t *seg_start, const uint32_t *list, size_t n_seg, size_t n_ent,
                                                               int long_mode, int mc, uint32_t *pair_mut, unsigned long long *n_events) {
