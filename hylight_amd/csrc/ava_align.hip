@@ -1547,6 +1547,8 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
         unsigned long long nmatch = 0, blen = 0;
         uint32_t slots = 0;                       // S - M carried over the 64-task steps
         uint32_t carry_code = 99;                 // last code of the last non-empty kept task so far
+        constexpr uint32_t NO_SLOT = 0xffffffffu;
+        uint32_t open_idx = NO_SLOT, open_val = 0; // WRITE: the slot still taking merges (wave-uniform)
         int ext_l_i = 0, ext_l_j = 0, ext_r_i = 0, ext_r_j = 0;
         for (uint32_t t0 = 0; t0 < n_tasks; t0 += 64) {
             const uint32_t t = t0 + (uint32_t)lane;
@@ -1572,18 +1574,48 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
             uint32_t tot_runs, tot_mrg;
             const uint32_t S = wave_excl_sum_u32(nr, lane, tot_runs);
             const uint32_t Mx = wave_excl_sum_u32(mrg ? 1u : 0u, lane, tot_mrg);
-            if (WRITE && nr) {
-                // (tried in round 3: all lanes copying the step's runs together by flat index, owner found by a search over the
-                //  prefix sums - 59 -> 134 ms: most tasks have one to three runs, the search costs more than the loop it removes)
+            if (WRITE) {
+                // No atomics, no zeroed slots: every slot has ONE writer.  A slot is opened by a task's last run (or its only
+                // run when that does not merge into the slot before) and takes the first runs of the tasks after it while they
+                // merge; it closes at the next opener.  With P = inclusive prefix sum of the merged first-run lengths, the
+                // opener at lane a collects P(b) - P(a), b = the next opener: one scan and one shuffle per 64 tasks.  The
+                // slot open at the end of a step is carried in (open_idx, open_val) and written when it closes.
+                // (Round 3 until here: the slots were zeroed and the first / last run of every task added atomically - C3's rows
+                //  are mostly exact-match tasks of one run each, ~50 adds in a row on ONE address.)
+                const uint32_t F = nr ? a.runs[r.runs_off] : 0u;
+                const uint32_t L = nr >= 2 ? a.runs[r.runs_off + nr - 1] : F;
+                const uint32_t P = wave_prefix_sum_incl_dpp(mrg ? F >> 4 : 0u);
+                const bool opens = nr != 0 && (!mrg || nr >= 2);
+                const unsigned long long om = __ballot(opens);
+                const uint32_t P_end = (uint32_t)__builtin_amdgcn_readlane((int)P, 63);
+                const uint32_t T0 = om ? (uint32_t)__shfl((int)P, __ffsll((long long)om) - 1, 64) : P_end;
+                open_val += T0 << 4;
+                if (om && open_idx != NO_SLOT && lane == 0) w[open_idx] = open_val;
+                const unsigned long long above = lane == 63 ? 0ull : om & ~((2ull << lane) - 1ull);
+                const uint32_t P_next = (uint32_t)__shfl((int)P, above ? __ffsll((long long)above) - 1 : 63, 64);
                 const uint32_t base = slots + S - (Mx + (mrg ? 1u : 0u));
-                for (uint32_t x = 0; x < nr; ++x) {
-                    const uint32_t run = a.runs[r.runs_off + x];
-                    const uint32_t len = run >> 4;
-                    blen += len;
-                    if ((run & 15u) == OP_EQ) nmatch += len;
-                    if (x == 0 && mrg) atomicAdd(&w[base], len << 4);
-                    else if (x == 0 || x == nr - 1) atomicAdd(&w[base + x], run);
-                    else w[base + x] = run;
+                const uint32_t own_slot = base + (nr ? nr - 1 : 0u);
+                const uint32_t own_val = L + ((P_next - P) << 4);
+                if (om) {
+                    const int lb = 63 - __clzll((long long)om);              // the step's last opener: its slot stays open
+                    open_idx = (uint32_t)__builtin_amdgcn_readlane((int)own_slot, lb);
+                    open_val = (uint32_t)__builtin_amdgcn_readlane((int)own_val, lb);
+                    if (opens && lane != lb) w[own_slot] = own_val;
+                }
+                if (nr) {
+                    blen += F >> 4;
+                    if ((F & 15u) == OP_EQ) nmatch += F >> 4;
+                }
+                if (nr >= 2) {
+                    blen += L >> 4;
+                    if ((L & 15u) == OP_EQ) nmatch += L >> 4;
+                    if (!mrg) w[base] = F;
+                    for (uint32_t x = 1; x + 1 < nr; ++x) {
+                        const uint32_t run = a.runs[r.runs_off + x];
+                        blen += run >> 4;
+                        if ((run & 15u) == OP_EQ) nmatch += run >> 4;
+                        w[base + x] = run;
+                    }
                 }
             }
             slots += tot_runs - tot_mrg;
@@ -1609,6 +1641,7 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { nmatch += __shfl_xor(nmatch, o, 64); blen += __shfl_xor(blen, o, 64); }
         if (lane == 0) {
+            if (open_idx != NO_SLOT) w[open_idx] = open_val;
             const int qs = (int)fp[0].q - li, ts = (int)fp[0].t - lj;
             const int qe = (int)fp[p.n_fp - 1].q + ri, te = (int)fp[p.n_fp - 1].t + rj;
             const uint32_t ql = a.qlen[p.q];
@@ -1953,7 +1986,6 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     out.ops.alloc(n_ops ? n_ops : 1);
     DBuf<PafRec> recs(P);
     DBuf<uint64_t> hi(P), lo(P);
-    out.ops.zero();
     {
         KTimer kt("assemble_write");
         hipLaunchKernelGGL(assemble_kernel<true>, dim3(nba), dim3(WG), 0, stream(), as, nullptr, valid.p, ooff.p, out.ops.p,
