@@ -1550,12 +1550,15 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
         constexpr uint32_t NO_SLOT = 0xffffffffu;
         uint32_t open_idx = NO_SLOT, open_val = 0; // WRITE: the slot still taking merges (wave-uniform)
         int ext_l_i = 0, ext_l_j = 0, ext_r_i = 0, ext_r_j = 0;
+        TaskOut r_next{0, 0, 0, 0, 0, 0};
+        if ((uint32_t)lane < n_tasks) r_next = to[lane];
         for (uint32_t t0 = 0; t0 < n_tasks; t0 += 64) {
             const uint32_t t = t0 + (uint32_t)lane;
-            TaskOut r{0, 0, 0, 0, 0, 0};
+            TaskOut r = r_next;
+            r_next = TaskOut{0, 0, 0, 0, 0, 0};
+            if (t + 64 < n_tasks) r_next = to[t + 64];        // in flight while this step's runs are copied
             bool keep = false;
             if (t < n_tasks) {
-                r = to[t];
                 keep = true;
                 if (t == 0 || t == n_tasks - 1)   // an extension counts when it gains something (bonus: decision only)
                     keep = !(r.score + ((r.pad & 0x80000000u) ? a.end_bonus : 0) <= 0 || (r.n_runs == 0 && !bare));
@@ -1610,6 +1613,8 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                     blen += L >> 4;
                     if ((L & 15u) == OP_EQ) nmatch += L >> 4;
                     if (!mrg) w[base] = F;
+                    // (tried: four loads at a time, then their stores - 45 -> 47 ms; the head of the next piece requested
+                    //  a piece ahead - 45 -> 48.5 ms)
                     for (uint32_t x = 1; x + 1 < nr; ++x) {
                         const uint32_t run = a.runs[r.runs_off + x];
                         blen += run >> 4;
