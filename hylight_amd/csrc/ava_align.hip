@@ -1393,12 +1393,14 @@ __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, in
 
 // TB = false: scores (and, for extensions, the cell they stop in) only: tasks of stub candidates
 template <int ROWS_MAX, bool TB = true>
-__global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(TB && ROWS_MAX <= 128 ? 4 : 1, 8))) void align_kernel(AlignArgs a) {
+    // (the 128-row instance: 4 workgroups per CU need <= 40 KB of LDS and <= 128 registers each - it sat at 41.2 KB and 129)
+    constexpr int RUN_BUF = TB && ROWS_MAX <= 128 ? 96 : RUN_BUF_WIDE;
     constexpr int W_CHUNKS = TB ? ROWS_MAX / 32 : 1;
     __shared__ uint32_t s_pl[WAVES][TB ? N_WPLANES : 1][W_CHUNKS][64];
     __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][ROWS_MAX + 4];
     __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][WT_LEN];
-    __shared__ uint32_t s_runs[WAVES][RUN_BUF_WIDE];
+    __shared__ uint32_t s_runs[WAVES][RUN_BUF];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -1478,7 +1480,7 @@ __global__ __launch_bounds__(WG) void align_kernel(AlignArgs a) {
             continue;
         }
         uint32_t *rbuf = s_runs[wv];
-        const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF_WIDE ? a.run_buf_cap : (uint32_t)RUN_BUF_WIDE;
+        const uint32_t rcap = a.run_buf_cap < (uint32_t)RUN_BUF ? a.run_buf_cap : (uint32_t)RUN_BUF;
         uint32_t cp_n = 0, cp_off = 0;
         if (lane == 0) {
             const uint32_t *planes = &pl[0][0][0];
