@@ -8,6 +8,7 @@
 #include <utility>
 
 #include "common.h"
+#include "wave_ops.h"
 
 namespace hlmi {
 
@@ -184,6 +185,48 @@ __global__ __launch_bounds__(WG) void head_count_split_kernel(const K *skey, con
     const unsigned long long m = __ballot(f);
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) { cnt[i >> 6] = (uint32_t)__popcll(m); mask[i >> 6] = m; }
 }
+// The 16-bit form, four elements per thread: three wide loads instead of sixteen narrow ones (the predecessor of a
+// thread's first element comes from the lane below, lane 0 fetches its own).  The four ballots are bit planes by lane;
+// word j of the wave's 256 flags interleaves their 16-bit slices j (lanes 0 .. 3 build one word each).
+__global__ __launch_bounds__(WG) void head_count_split4_kernel(const uint16_t *skey, const uint64_t *val, size_t n, int shift,
+                                                                uint32_t *cnt, unsigned long long *mask) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
+    const size_t i0 = 4 * t;
+    uint64_t v[4] = {0, 0, 0, 0};
+    uint32_t s[4] = {0, 0, 0, 0};
+    if (i0 + 3 < n) {
+        const ulonglong2 a = ((const ulonglong2 *)val)[2 * t], b = ((const ulonglong2 *)val)[2 * t + 1];
+        const uint2 ss = ((const uint2 *)skey)[t];
+        v[0] = a.x >> shift; v[1] = a.y >> shift; v[2] = b.x >> shift; v[3] = b.y >> shift;
+        s[0] = ss.x & 0xffffu; s[1] = ss.x >> 16; s[2] = ss.y & 0xffffu; s[3] = ss.y >> 16;
+    } else {
+        for (int k = 0; k < 4; ++k) if (i0 + k < n) { v[k] = val[i0 + k] >> shift; s[k] = skey[i0 + k]; }
+    }
+    uint32_t pv_lo = (uint32_t)wave_shr1((int)(uint32_t)v[3], 0), pv_hi = (uint32_t)wave_shr1((int)(uint32_t)(v[3] >> 32), 0);
+    uint32_t ps = (uint32_t)wave_shr1((int)s[3], 0);
+    if (lane == 0 && i0 > 0 && i0 < n) { const uint64_t x = val[i0 - 1] >> shift; pv_lo = (uint32_t)x; pv_hi = (uint32_t)(x >> 32); ps = skey[i0 - 1]; }
+    const uint64_t pv = (uint64_t)pv_hi << 32 | pv_lo;
+    const bool f0 = i0 < n && (i0 == 0 || s[0] != ps || v[0] != pv);
+    const bool f1 = i0 + 1 < n && (s[1] != s[0] || v[1] != v[0]);
+    const bool f2 = i0 + 2 < n && (s[2] != s[1] || v[2] != v[1]);
+    const bool f3 = i0 + 3 < n && (s[3] != s[2] || v[3] != v[2]);
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2), b3 = __ballot(f3);
+    if (lane < 4) {
+        auto spread = [](unsigned long long x) {           // bit i of the low 16 -> bit 4 i
+            x &= 0xffffull;
+            x = (x | x << 24) & 0x000000ff000000ffull;
+            x = (x | x << 12) & 0x000f000f000f000full;
+            x = (x | x << 6) & 0x0303030303030303ull;
+            x = (x | x << 3) & 0x1111111111111111ull;
+            return x;
+        };
+        const int sh = 16 * lane;
+        const unsigned long long m = spread(b0 >> sh) | spread(b1 >> sh) << 1 | spread(b2 >> sh) << 2 | spread(b3 >> sh) << 3;
+        const size_t w = (t - (size_t)lane) / 16 + (size_t)lane;
+        if (w < (n + 63) / 64) { cnt[w] = (uint32_t)__popcll(m); mask[w] = m; }
+    }
+}
 // second pass: the ballots of the first (8 B per 64 keys) instead of the keys again
 __global__ __launch_bounds__(WG) void head_scatter_kernel(const unsigned long long *mask, size_t n, const uint32_t *off,
                                                            uint32_t *out_idx, uint32_t *total) {
@@ -193,6 +236,19 @@ __global__ __launch_bounds__(WG) void head_scatter_kernel(const unsigned long lo
     const int lane = (int)(threadIdx.x & 63);
     if ((m >> lane) & 1ull) out_idx[off[i >> 6] + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
     if (i == n - 1) *total = off[i >> 6] + (uint32_t)__popcll(m);
+}
+// the same with one thread per 64 keys: for sparse heads (anchor groups of hundreds: one set bit in six words)
+__global__ __launch_bounds__(WG) void head_scatter_words_kernel(const unsigned long long *mask, size_t nw, const uint32_t *off,
+                                                                 uint32_t *out_idx, uint32_t *total) {
+    const size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    unsigned long long m = mask[w];
+    uint32_t o = off[w];
+    if (w == nw - 1) *total = o + (uint32_t)__popcll(m);
+    while (m) {
+        out_idx[o++] = (uint32_t)(w * 64 + (size_t)(__ffsll((long long)m) - 1));
+        m &= m - 1;
+    }
 }
 
 size_t select_run_heads_u64(const uint64_t *key, size_t n, int shift, uint32_t *out_idx) {
@@ -217,13 +273,23 @@ size_t select_run_heads_split(const void *skey, int key_bytes, const uint64_t *v
     DBuf<unsigned long long> mask(nw);
     const dim3 grid(cdiv(n, WG));
     if (key_bytes == 2)
-        hipLaunchKernelGGL(head_count_split_kernel<uint16_t>, grid, dim3(WG), 0, stream(), (const uint16_t *)skey, val, n, val_shift, cnt.p, mask.p);
+        hipLaunchKernelGGL(head_count_split4_kernel, dim3(cdiv(cdiv(n, (size_t)4), WG)), dim3(WG), 0, stream(), (const uint16_t *)skey, val, n,
+                           val_shift, cnt.p, mask.p);
     else
         hipLaunchKernelGGL(head_count_split_kernel<uint32_t>, grid, dim3(WG), 0, stream(), (const uint32_t *)skey, val, n, val_shift, cnt.p, mask.p);
     exclusive_scan_u32(cnt.p, off.p, nw);
-    hipLaunchKernelGGL(head_scatter_kernel, grid, dim3(WG), 0, stream(), mask.p, n, off.p, out_idx, total.p);
+    // sparse heads: one thread per mask word; dense ones (short reads: groups of a few anchors): one per key
+    uint32_t h_last[2];
+    HIP_CHECK(hipMemcpyAsync(&h_last[0], off.p + (nw - 1), 4, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(&h_last[1], cnt.p + (nw - 1), 4, hipMemcpyDeviceToHost, stream()));
+    sync();
+    const size_t n_heads = (size_t)h_last[0] + h_last[1];
+    if (n_heads * 16 < n)
+        hipLaunchKernelGGL(head_scatter_words_kernel, dim3(cdiv(nw, WG)), dim3(WG), 0, stream(), mask.p, nw, off.p, out_idx, total.p);
+    else
+        hipLaunchKernelGGL(head_scatter_kernel, grid, dim3(WG), 0, stream(), mask.p, n, off.p, out_idx, total.p);
     HIP_CHECK(hipGetLastError());
-    return (size_t)download_one(total.p);
+    return n_heads;
 }
 
 void select_flagged_indices_async(const uint8_t *flags, uint32_t *out_idx, size_t n, uint32_t *d_count) {
