@@ -716,11 +716,14 @@ __global__ __launch_bounds__(PILE_LIGHT_WG) void snp_pileup_light_kernel(const P
                                                                           unsigned long long *n_events) {
     __shared__ uint32_t sV[PILE_TILE / 4];                            // four 8-bit counters per word
     __shared__ uint32_t s_is[PILE_LIGHT_ROWS], s_ie[PILE_LIGHT_ROWS], s_len;
+    // the X events of the cached ops of the rows somebody reads: (position - t0) | row << 16, tested by ALL threads
+    __shared__ uint32_t s_ev[PILE_LIGHT_ROWS * 64 * PILE_LIGHT_IT], s_nev, s_hits[PILE_LIGHT_ROWS], s_pair[PILE_LIGHT_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t seg = list[blockIdx.x];
     const size_t b = seg_start[seg], e = seg + 1 < n_seg ? seg_start[seg + 1] : n_ent;
     const int n_rows = (int)(e - b);
     if (tid == 0) s_len = 0;
+    if (tid < PILE_LIGHT_ROWS) s_pair[tid] = NO_PAIR;
     __syncthreads();
     // ---- every wave: its (at most two) rows, walked once ---------------------------------------------------------------
     uint32_t pos[2][PILE_LIGHT_IT];
@@ -741,6 +744,7 @@ __global__ __launch_bounds__(PILE_LIGHT_WG) void snp_pileup_light_kernel(const P
         if (lane == 0) {
             const uint32_t s0 = qside ? r.qs : r.ts, e0 = qside ? r.qe : r.te;
             s_is[k] = s0 < e0 ? s0 : 0; s_ie[k] = s0 < e0 ? e0 : 0;
+            s_pair[k] = pg[sl];
             atomicMax(&s_len, qside ? r.qlen : r.tlen);
         }
         spill[sl] = r.cig_n > 64u * PILE_LIGHT_IT;
@@ -785,13 +789,26 @@ __global__ __launch_bounds__(PILE_LIGHT_WG) void snp_pileup_light_kernel(const P
     for (uint32_t t0 = 0; t0 < read_len + 2; t0 += PILE_TILE) {
         const uint32_t n_pos = min((uint32_t)PILE_TILE, read_len + 2 - t0);
         for (uint32_t w = tid; w < (n_pos + 3) / 4; w += PILE_LIGHT_WG) sV[w] = 0;
+        if (tid < PILE_LIGHT_ROWS) s_hits[tid] = 0;
+        if (tid == 0) s_nev = 0;
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             if (wave + 8 * sl >= n_rows) continue;
 #pragma unroll
-            for (int u = 0; u < PILE_LIGHT_IT; ++u)
-                if (((xm[sl] >> u) & 1u) && pos[sl][u] >= t0 && pos[sl][u] - t0 < n_pos) lds_inc<uint8_t>(sV, pos[sl][u] - t0);
+            for (int u = 0; u < PILE_LIGHT_IT; ++u) {
+                const bool in = ((xm[sl] >> u) & 1u) && pos[sl][u] >= t0 && pos[sl][u] - t0 < n_pos;
+                if (in) lds_inc<uint8_t>(sV, pos[sl][u] - t0);
+                if (pg[sl] != NO_PAIR) {                               // (wave-uniform: the row's pair)
+                    const unsigned long long m = __ballot(in);
+                    if (m) {
+                        uint32_t at = 0;
+                        if (lane == 0) at = atomicAdd(&s_nev, (uint32_t)__popcll(m));
+                        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                        if (in) s_ev[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (pos[sl][u] - t0) | (uint32_t)(wave + 8 * sl) << 16;
+                    }
+                }
+            }
             if (spill[sl]) tail(sl, [&](uint32_t q, bool isx) { if (isx && q >= t0 && q - t0 < n_pos) lds_inc<uint8_t>(sV, q - t0); });
         }
         __syncthreads();
@@ -802,17 +819,27 @@ __global__ __launch_bounds__(PILE_LIGHT_WG) void snp_pileup_light_kernel(const P
             for (int i = 0; i < n_rows; ++i) cov += (s_is[i] < q && q < s_ie[i]) ? 1 : 0;
             return cov - cnt >= mc;
         };
+        // The coverage test of the X positions, one event per thread: with a wave per row the waves of a segment of five
+        // rows left three quarters of the workgroup idle here, and this test is half of the workgroup's time (phase
+        // timers: 19 % + 34 % waiting at the barrier behind it for the slowest row).
+        {
+            const uint32_t n_ev = s_nev;
+            for (uint32_t i = tid; i < n_ev; i += PILE_LIGHT_WG) {
+                const uint32_t w = s_ev[i];
+                if (supported(t0 + (w & 0xffffu))) atomicAdd(&s_hits[w >> 16], 1u);
+            }
+        }
+        // (the uncached tail of a long row stays with the row's wave)
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            if (wave + 8 * sl >= n_rows || pg[sl] == NO_PAIR) continue;
+            if (wave + 8 * sl >= n_rows || pg[sl] == NO_PAIR || !spill[sl]) continue;
             uint32_t hits = 0;
-#pragma unroll
-            for (int u = 0; u < PILE_LIGHT_IT; ++u)
-                if (((xm[sl] >> u) & 1u) && pos[sl][u] >= t0 && pos[sl][u] - t0 < n_pos && supported(pos[sl][u])) ++hits;
-            if (spill[sl]) tail(sl, [&](uint32_t q, bool isx) { if (isx && q >= t0 && q - t0 < n_pos && supported(q)) ++hits; });
+            tail(sl, [&](uint32_t q, bool isx) { if (isx && q >= t0 && q - t0 < n_pos && supported(q)) ++hits; });
             hits = wave_prefix_sum_incl_dpp(hits);
-            if (lane == 63 && hits) atomicAdd(&pair_mut[pg[sl]], hits);
+            if (lane == 63 && hits) atomicAdd(&s_hits[wave + 8 * sl], hits);
         }
+        __syncthreads();
+        if (tid < PILE_LIGHT_ROWS && s_hits[tid]) atomicAdd(&pair_mut[s_pair[tid]], s_hits[tid]);
         __syncthreads();
     }
     if (lane == 0 && ev) atomicAdd(&n_events[(blockIdx.x * 16u + (uint32_t)wave) & (PILE_EV_SLOTS - 1)], ev);
