@@ -1530,6 +1530,7 @@ struct AsmArgs {
 // non-empty kept task, run x of a task lands in slot S - M + x: a merged first run shares the slot of the run
 // it extends.  Slots are zero-initialised and the first / last run of a task are added atomically (they are the
 // only ones other tasks can touch); pass <false> needs just the first and last code of each task.
+constexpr uint32_t ASM_MID = 4;
 template <bool WRITE>
 __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, const uint64_t *ops_off,
                                                        uint32_t *ops, PafRec *recs, uint64_t *ord_hi, uint64_t *ord_lo) {
@@ -1589,6 +1590,11 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                 //  are mostly exact-match tasks of one run each, ~50 adds in a row on ONE address.)
                 const uint32_t F = nr ? a.runs[r.runs_off] : 0u;
                 const uint32_t L = nr >= 2 ? a.runs[r.runs_off + nr - 1] : F;
+                // the first interior runs travel with F and L: a load behind this step's stores would wait for them
+                // (loads and stores share one counter), and that wait was 63 % of the kernel (phase timers)
+                uint32_t mid[ASM_MID];
+#pragma unroll
+                for (uint32_t u = 0; u < ASM_MID; ++u) mid[u] = u + 3 <= nr ? a.runs[r.runs_off + 1 + u] : 0u;
                 const uint32_t P = wave_prefix_sum_incl_dpp(mrg ? F >> 4 : 0u);
                 const bool opens = nr != 0 && (!mrg || nr >= 2);
                 const unsigned long long om = __ballot(opens);
@@ -1617,7 +1623,14 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                     if (!mrg) w[base] = F;
                     // (tried: four loads at a time, then their stores - 45 -> 47 ms; the head of the next piece requested
                     //  a piece ahead - 45 -> 48.5 ms)
-                    for (uint32_t x = 1; x + 1 < nr; ++x) {
+#pragma unroll
+                    for (uint32_t u = 0; u < ASM_MID; ++u)
+                        if (u + 3 <= nr) {
+                            blen += mid[u] >> 4;
+                            if ((mid[u] & 15u) == OP_EQ) nmatch += mid[u] >> 4;
+                            w[base + 1 + u] = mid[u];
+                        }
+                    for (uint32_t x = 1 + ASM_MID; x + 1 < nr; ++x) {
                         const uint32_t run = a.runs[r.runs_off + x];
                         blen += run >> 4;
                         if ((run & 15u) == OP_EQ) nmatch += run >> 4;
