@@ -1531,9 +1531,12 @@ struct AsmArgs {
 // it extends.  Slots are zero-initialised and the first / last run of a task are added atomically (they are the
 // only ones other tasks can touch); pass <false> needs just the first and last code of each task.
 constexpr uint32_t ASM_MID = 4;
+constexpr int ASM_STAGE = 1024;      // slots of one 64-task step staged in LDS (per wave)
 template <bool WRITE>
 __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, const uint64_t *ops_off,
                                                        uint32_t *ops, PafRec *recs, uint64_t *ord_hi, uint64_t *ord_lo) {
+    __shared__ uint32_t s_stage[WRITE ? WAVES : 1][WRITE ? ASM_STAGE : 1];
+    uint32_t *const stage = s_stage[WRITE ? (threadIdx.x >> 6) : 0];
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -1607,11 +1610,18 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                 const uint32_t base = slots + S - (Mx + (mrg ? 1u : 0u));
                 const uint32_t own_slot = base + (nr ? nr - 1 : 0u);
                 const uint32_t own_val = L + ((P_next - P) << 4);
+                // The step's slots [slots, slots + n_out) are put together in LDS and leave as whole lines: a lane's own
+                // stores are 4 bytes each at a stride of its neighbours' run counts (~10 partial lines per store
+                // instruction; the kernel spent 63 % of its time issuing them).  A step with more slots than the buffer
+                // holds stores directly.
+                const uint32_t n_out = tot_runs - tot_mrg;
+                const bool staged = n_out <= (uint32_t)ASM_STAGE;
+                auto put = [&](uint32_t slot, uint32_t v) { if (staged) stage[slot - slots] = v; else w[slot] = v; };
                 if (om) {
                     const int lb = 63 - __clzll((long long)om);              // the step's last opener: its slot stays open
                     open_idx = (uint32_t)__builtin_amdgcn_readlane((int)own_slot, lb);
                     open_val = (uint32_t)__builtin_amdgcn_readlane((int)own_val, lb);
-                    if (opens && lane != lb) w[own_slot] = own_val;
+                    if (opens && lane != lb) put(own_slot, own_val);
                 }
                 if (nr) {
                     blen += F >> 4;
@@ -1620,7 +1630,7 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                 if (nr >= 2) {
                     blen += L >> 4;
                     if ((L & 15u) == OP_EQ) nmatch += L >> 4;
-                    if (!mrg) w[base] = F;
+                    if (!mrg) put(base, F);
                     // (tried: four loads at a time, then their stores - 45 -> 47 ms; the head of the next piece requested
                     //  a piece ahead - 45 -> 48.5 ms)
 #pragma unroll
@@ -1628,14 +1638,22 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                         if (u + 3 <= nr) {
                             blen += mid[u] >> 4;
                             if ((mid[u] & 15u) == OP_EQ) nmatch += mid[u] >> 4;
-                            w[base + 1 + u] = mid[u];
+                            put(base + 1 + u, mid[u]);
                         }
                     for (uint32_t x = 1 + ASM_MID; x + 1 < nr; ++x) {
                         const uint32_t run = a.runs[r.runs_off + x];
                         blen += run >> 4;
                         if ((run & 15u) == OP_EQ) nmatch += run >> 4;
-                        w[base + x] = run;
+                        put(base + x, run);
                     }
+                }
+                if (staged) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                      // the LDS writes (lgkmcnt 0)
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t k = (uint32_t)lane; k < n_out; k += 64)
+                        if (slots + k != open_idx) w[slots + k] = stage[k];    // (the open slot is written when it closes)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                      // read before the next step overwrites it
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             slots += tot_runs - tot_mrg;
