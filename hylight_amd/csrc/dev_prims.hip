@@ -185,6 +185,22 @@ __global__ __launch_bounds__(WG) void head_count_split_kernel(const K *skey, con
     const unsigned long long m = __ballot(f);
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) { cnt[i >> 6] = (uint32_t)__popcll(m); mask[i >> 6] = m; }
 }
+// bit i of the low 16 bits of x -> bit 4 i
+__device__ __forceinline__ unsigned long long spread16x4(unsigned long long x) {
+    x &= 0xffffull;
+    x = (x | x << 24) & 0x000000ff000000ffull;
+    x = (x | x << 12) & 0x000f000f000f000full;
+    x = (x | x << 6) & 0x0303030303030303ull;
+    x = (x | x << 3) & 0x1111111111111111ull;
+    return x;
+}
+// four elements per thread, flags f0..f3 of a thread's elements as ballots b0..b3 (bit planes by lane): the word of the
+// wave's elements 64 j .. 64 j + 63 interleaves the planes' 16-bit slices j
+__device__ __forceinline__ unsigned long long planes_word(unsigned long long b0, unsigned long long b1, unsigned long long b2,
+                                                          unsigned long long b3, int j) {
+    const int sh = 16 * j;
+    return spread16x4(b0 >> sh) | spread16x4(b1 >> sh) << 1 | spread16x4(b2 >> sh) << 2 | spread16x4(b3 >> sh) << 3;
+}
 // The 16-bit form, four elements per thread: three wide loads instead of sixteen narrow ones (the predecessor of a
 // thread's first element comes from the lane below, lane 0 fetches its own).  The four ballots are bit planes by lane;
 // word j of the wave's 256 flags interleaves their 16-bit slices j (lanes 0 .. 3 build one word each).
@@ -213,16 +229,7 @@ __global__ __launch_bounds__(WG) void head_count_split4_kernel(const uint16_t *s
     const bool f3 = i0 + 3 < n && (s[3] != s[2] || v[3] != v[2]);
     const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2), b3 = __ballot(f3);
     if (lane < 4) {
-        auto spread = [](unsigned long long x) {           // bit i of the low 16 -> bit 4 i
-            x &= 0xffffull;
-            x = (x | x << 24) & 0x000000ff000000ffull;
-            x = (x | x << 12) & 0x000f000f000f000full;
-            x = (x | x << 6) & 0x0303030303030303ull;
-            x = (x | x << 3) & 0x1111111111111111ull;
-            return x;
-        };
-        const int sh = 16 * lane;
-        const unsigned long long m = spread(b0 >> sh) | spread(b1 >> sh) << 1 | spread(b2 >> sh) << 2 | spread(b3 >> sh) << 3;
+        const unsigned long long m = planes_word(b0, b1, b2, b3, lane);
         const size_t w = (t - (size_t)lane) / 16 + (size_t)lane;
         if (w < (n + 63) / 64) { cnt[w] = (uint32_t)__popcll(m); mask[w] = m; }
     }
@@ -304,36 +311,50 @@ void select_flagged_indices_async(const uint8_t *flags, uint32_t *out_idx, size_
     HIP_CHECK(hipGetLastError());
 }
 
-// class c - 1 owns cnt / mask / off entries [(c - 1) nw, c nw): one scan serves the four selections
-__global__ __launch_bounds__(WG) void class_count_kernel(const uint8_t *cls, size_t n, size_t nw, uint32_t *cnt, unsigned long long *mask) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const uint8_t c = i < n ? cls[i] : 0;
-    const size_t w = i >> 6;
+// class c - 1 owns cnt / mask / off entries [(c - 1) nw, c nw): one scan serves the four selections;
+// four elements per thread (one 32-bit load instead of four byte loads; lane 4 k + j builds word j of class k + 1)
+__global__ __launch_bounds__(WG) void class_count4_kernel(const uint8_t *cls, size_t n, size_t nw, uint32_t *cnt, unsigned long long *mask) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
+    const size_t i0 = 4 * t;
+    uint32_t c4 = 0;
+    if (i0 + 3 < n) c4 = ((const uint32_t *)cls)[t];
+    else for (int k = 0; k < 4; ++k) if (i0 + k < n) c4 |= (uint32_t)cls[i0 + k] << (8 * k);
+    unsigned long long b[4][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned long long m = __ballot(c == k + 1);
-        if ((threadIdx.x & 63) == 0 && w < nw) { cnt[(size_t)k * nw + w] = (uint32_t)__popcll(m); mask[(size_t)k * nw + w] = m; }
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[k][e] = __ballot(((c4 >> (8 * e)) & 0xffu) == (uint32_t)(k + 1));
+    if (lane < 16) {
+        const int k = lane >> 2, j = lane & 3;
+        unsigned long long m = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) if (kk == k) m = planes_word(b[kk][0], b[kk][1], b[kk][2], b[kk][3], j);
+        const size_t w = (t - (size_t)lane) / 16 + (size_t)j;
+        if (w < nw) { cnt[(size_t)k * nw + w] = (uint32_t)__popcll(m); mask[(size_t)k * nw + w] = m; }
     }
 }
 struct Out4 { uint32_t *p[4]; };
-__global__ __launch_bounds__(WG) void class_scatter_kernel(const uint8_t *cls, size_t n, size_t nw, const uint32_t *cnt,
-                                                            const unsigned long long *mask, const uint32_t *off, Out4 out,
-                                                            uint32_t *d_counts) {
+// scatter by mask word: one thread per (class, 64 elements) - the class lists are sparse (a few set bits per word), the
+// byte array is not read again
+__global__ __launch_bounds__(WG) void class_scatter_words_kernel(size_t nw, const uint32_t *cnt, const unsigned long long *mask,
+                                                                  const uint32_t *off, Out4 out, uint32_t *d_counts) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < 4) {                                          // the four totals
         const size_t k = i;
         const uint32_t end = k < 3 ? off[(k + 1) * nw] : off[4 * nw - 1] + cnt[4 * nw - 1];
         d_counts[k] = end - off[k * nw];
     }
-    if (i >= n) return;
-    const uint8_t c = cls[i];
-    if (c < 1 || c > 4) return;
-    const size_t k = (size_t)c - 1, w = i >> 6;
-    const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long m = mask[k * nw + w];
-    out.p[k][off[k * nw + w] - off[k * nw] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    if (i >= 4 * nw) return;
+    const size_t k = i / nw, w = i - k * nw;
+    unsigned long long m = mask[i];
+    uint32_t o = off[i] - off[k * nw];
+    uint32_t *dst = out.p[k];
+    while (m) {
+        dst[o++] = (uint32_t)(w * 64 + (size_t)(__ffsll((long long)m) - 1));
+        m &= m - 1;
+    }
 }
-
 void select_classes4_async(const uint8_t *cls, size_t n, uint32_t *out1, uint32_t *out2, uint32_t *out3, uint32_t *out4,
                            uint32_t *d_counts) {
     if (!n) { HIP_CHECK(hipMemsetAsync(d_counts, 0, 16, stream())); return; }
@@ -341,10 +362,9 @@ void select_classes4_async(const uint8_t *cls, size_t n, uint32_t *out1, uint32_
     const size_t nw = (n + 63) / 64;
     DBuf<uint32_t> cnt(4 * nw), off(4 * nw);
     DBuf<unsigned long long> mask(4 * nw);
-    const dim3 grid(cdiv(n, WG));
-    hipLaunchKernelGGL(class_count_kernel, grid, dim3(WG), 0, stream(), cls, n, nw, cnt.p, mask.p);
+    hipLaunchKernelGGL(class_count4_kernel, dim3(cdiv(cdiv(n, (size_t)4), WG)), dim3(WG), 0, stream(), cls, n, nw, cnt.p, mask.p);
     exclusive_scan_u32(cnt.p, off.p, 4 * nw);
-    hipLaunchKernelGGL(class_scatter_kernel, grid, dim3(WG), 0, stream(), cls, n, nw, cnt.p, mask.p, off.p,
+    hipLaunchKernelGGL(class_scatter_words_kernel, dim3(cdiv(4 * nw, WG)), dim3(WG), 0, stream(), nw, cnt.p, mask.p, off.p,
                        Out4{{out1, out2, out3, out4}}, d_counts);
     HIP_CHECK(hipGetLastError());
 }
