@@ -317,3 +317,32 @@ def test_ava_alignment_in_spans_of_pieces(tmp_path, monkeypatch):
     api.ava(fa, fa, tmp_path / "spans.paf")
     assert api.last_stats().get("align_spans", 0) >= 2
     assert open(tmp_path / "spans.paf").read() == open(tmp_path / "one.paf").read()
+
+
+def test_ava_cigar_runs_merging_across_many_tasks(tmp_path):
+    """Rows whose alignment tasks are almost all one exact-match run: the row's CIGAR collapses into a few ops, each
+    the sum of hundreds of tasks' runs, across several 64-task steps of the assembly (copies of one 24 kb read: exact, with
+    one substitution, one inserted base, one deleted base, a reverse-complement copy, and prefix / suffix pieces)."""
+    rng = np.random.default_rng(77)
+    base = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=24000)].copy()
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    def mk(name, seq):
+        return S.Read(name, np.ascontiguousarray(seq), None, 0, 0, 0, False)
+    sub = base.copy(); sub[11000] = ord("A") if sub[11000] != ord("A") else ord("C")
+    ins = np.concatenate([base[:7000], np.frombuffer(b"G", dtype=np.uint8), base[7000:]])
+    dele = np.concatenate([base[:16000], base[16001:]])
+    two = base.copy(); two[300] = ord("T") if two[300] != ord("T") else ord("G"); two[23000] = ord("C") if two[23000] != ord("C") else ord("A")
+    reads = [mk("dup0", base), mk("dup1", base.copy()), mk("sub", sub), mk("ins", ins), mk("del", dele), mk("two", two),
+             mk("rc", comp[base[::-1]]), mk("head", base[:15000].copy()), mk("tail", base[9000:].copy())]
+    fa = tmp_path / "dups.fa"
+    S.write_fasta(reads, fa)
+    api.ava(fa, fa, tmp_path / "g.paf")
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    got, want = open(tmp_path / "g.paf").read(), open(tmp_path / "o.paf").read()
+    rows = want.splitlines()
+    assert len(rows) >= 20
+    # the exact copies: one op for the whole read
+    assert any("cg:Z:24000=" in r for r in rows)
+    assert got == want
