@@ -1522,6 +1522,7 @@ struct AsmArgs {
     uint8_t *late;              // stub_score is flagged here - its end extensions, held back so far, have to run after all
     int stub_score;
     int bare;                   // 1: the rows of stub candidates are bare (no CIGAR, columns 10 / 11 zero): their tasks report scores only
+    uint32_t stage_cap;         // slots of one 64-task step that go through the LDS buffer (ASM_STAGE; test hook HLMI_ASM_STAGE_CAP lowers it)
 };
 
 // One wavefront per piece, one lane per task (64 tasks per step).  The row's CIGAR is the concatenation of the
@@ -1615,7 +1616,7 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
                 // instruction; the kernel spent 63 % of its time issuing them).  A step with more slots than the buffer
                 // holds stores directly.
                 const uint32_t n_out = tot_runs - tot_mrg;
-                const bool staged = n_out <= (uint32_t)ASM_STAGE;
+                const bool staged = n_out <= a.stage_cap;
                 auto put = [&](uint32_t slot, uint32_t v) { if (staged) stage[slot - slots] = v; else w[slot] = v; };
                 if (om) {
                     const int lb = 63 - __clzll((long long)om);              // the step's last opener: its slot stays open
@@ -1757,6 +1758,8 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     as.min_dp_score = o.min_dp_score; as.end_bonus = o.end_bonus;
     as.qlen = d_qlen; as.tlen = d_tlen; as.rank_q = in.d_rank_q; as.rank_t = in.d_rank_t; as.chunk_of_t = in.d_chunk_of_t;
     as.pg = pgeom.p; as.stub_score = o.min_dp_score + std::max(0, o.end_bonus);
+    as.stage_cap = (uint32_t)ASM_STAGE;
+    if (const char *e = getenv("HLMI_ASM_STAGE_CAP")) as.stage_cap = (uint32_t)std::min(ASM_STAGE, std::max(0, atoi(e)));
     DBuf<uint32_t> nops(P);
     DBuf<uint8_t> valid(P), late(o.stub_oh >= 0 ? P : 0);
     DBuf<uint32_t> late_idx(o.stub_oh >= 0 ? P : 0);

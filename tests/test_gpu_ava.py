@@ -191,6 +191,21 @@ def test_ava_traceback_run_buffer_overflow(tmp_path, monkeypatch):
     assert open(tmp_path / "b.paf").read() == want
 
 
+@pytest.mark.parametrize("cap", ["0", "40"])
+def test_ava_row_assembly_without_the_lds_stage(tmp_path, monkeypatch, cap):
+    """The assembly puts the CIGAR slots of a 64-task step together in LDS when they fit the buffer and stores them one
+    by one when they do not: with the buffer cut to nothing / to 40 slots every step / most steps take the direct path."""
+    reads = _sim(36, 40, err_sub=0.02, err_ins=0.005, err_del=0.005)
+    fa = _write(tmp_path, "r.fa", reads)
+    monkeypatch.setenv("HLMI_ASM_STAGE_CAP", cap)
+    api.ava(fa, fa, tmp_path / "g.paf")
+    monkeypatch.delenv("HLMI_ASM_STAGE_CAP")
+    OA.ava(fa, fa, tmp_path / "o.paf")
+    got, want = open(tmp_path / "g.paf").read(), open(tmp_path / "o.paf").read()
+    assert len(want.splitlines()) > 50
+    assert got == want
+
+
 def test_ava_target_subset_and_ambiguous_bases(tmp_path):
     reads = _sim(41, 36)
     reads[2].seq[1000:1004] = ord("N")
