@@ -220,13 +220,26 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     for (size_t ci = 0; ci < my_chunks.size() && m.Q.size();) {
         std::vector<uint32_t> sub_tids, chunk_of_t;
         uint32_t n_my = 0;
-        uint64_t sub_bases = 0;
+        // The budget counts WORK bases: with every pair taken once (strcmp(qname, tname) < 0, the all-vs-all calls) a
+        // target only meets the queries that rank below it, so a chunk's anchors grow with the name ranks of its reads -
+        // chunks of equal size differ by a factor of two and more, and estimates in plain bases made every other sub-run
+        // of the full C4 come back refused.  Weight 2 rank / names keeps the mean at one.
+        uint64_t sub_bases = 0, sub_real_bases = 0;
+        const double n_names = (double)std::max<size_t>(1, m.name_of_rank.size());
         while (ci < my_chunks.size()) {
             const auto &ch = m.chunks[my_chunks[ci]];
-            const uint64_t cb = m.T.off[ch.second] - m.T.off[ch.first];
-            if (n_my && (sub_bases + cb > budget_bases || sub_tids.size() + (ch.second - ch.first) > SUBRUN_MAX_TARGETS)) break;
+            const uint64_t cb_real = m.T.off[ch.second] - m.T.off[ch.first];
+            uint64_t cb = cb_real;
+            if (m.opts.pair_once) {
+                double w = 0;
+                for (uint32_t t = ch.first; t < ch.second; ++t) w += (double)m.T.len(t) * 2.0 * ((double)m.rank_t[t] + 0.5) / n_names;
+                cb = (uint64_t)w + 1;
+            }
+            if (n_my && (sub_bases + cb > budget_bases || sub_real_bases + cb_real > SUBRUN_MAX_BASES ||
+                         sub_tids.size() + (ch.second - ch.first) > SUBRUN_MAX_TARGETS)) break;
             for (uint32_t t = ch.first; t < ch.second; ++t) { sub_tids.push_back(t); chunk_of_t.push_back(n_my); }
             sub_bases += cb;
+            sub_real_bases += cb_real;
             ++n_my; ++ci;
         }
         if (sub_tids.empty()) continue;
