@@ -184,19 +184,19 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     std::vector<uint32_t> my_chunks;
     for (size_t c = 0; c < m.chunks.size(); ++c)
         if ((int)(c % (size_t)world) == rank) my_chunks.push_back((uint32_t)c);
-    constexpr double SUBRUN_ANCHORS = 1.2e10;
-    // rows + CIGARs of a sub-run sit in HBM twice while they are put into stream order, beside ~45 GB of batch buffers, and
-    // a sub-run is only refused at 1.5 x its budget: with the reads, the query sketch and the seed plan of a million long
-    // reads resident (84 GB on the full C4) the usual 64 GB do not fit and the pool thrashes - the budget follows what is
-    // free when the pass starts
+    constexpr double SUBRUN_ANCHORS = 2.0e10;    // (every sub-run counts the seeds of ALL queries again: fewer, larger ones)
+    // The rows of a sub-run sit in HBM twice while they are put into stream order (their CIGARs stay where the batches
+    // wrote them), beside ~45 GB of batch buffers, and a sub-run is only refused at 1.5 x its budget: with the reads, the
+    // query sketch and the seed plan of a million long reads resident (84 GB on the full C4) the usual 64 GB do not fit
+    // and the pool thrashes - the budget follows what is free when the pass starts
     double SUBRUN_OUT_BYTES = 64e9;
     if (const size_t avail = dev_available_bytes()) {
         const double plan = 12.0 * (m.qmz_off.empty() ? 0.0 : (double)m.qmz_off.back());        // count + run of every query minimizer
-        SUBRUN_OUT_BYTES = std::min(64e9, std::max(8e9, ((double)avail - plan - 50e9) / (2.2 * 1.5)));
+        SUBRUN_OUT_BYTES = std::min(64e9, std::max(8e9, ((double)avail - plan - 50e9) / (1.3 * 1.5)));
     }
     stat_set("subrun_out_budget_gb", SUBRUN_OUT_BYTES / 1e9);
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
-    double subrun_anchors_max = 2.4e10, subrun_out_max = 1.5 * SUBRUN_OUT_BYTES;
+    double subrun_anchors_max = 4.0e10, subrun_out_max = 1.5 * SUBRUN_OUT_BYTES;
     // test hooks: the refusal / retry path below with small inputs (millions of anchors / MB of output)
     if (const char *e = getenv("HLMI_SUBRUN_MAX_MANCHORS")) subrun_anchors_max = 1e6 * std::max(1e-3, atof(e));
     if (const char *e = getenv("HLMI_SUBRUN_MAX_OUT_MB")) subrun_out_max = 1e6 * std::max(1e-3, atof(e));
