@@ -254,10 +254,28 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
         }
     }
     if (!FILL) return;
-    uint32_t my_cnt = 0;
-    // the runs are served one after the other; the first 64 entries of the next run are already in flight while
-    // this one is worked on (two dependent reads per run would otherwise sit on the critical path 64 times)
-    unsigned long long todo = __ballot(hi != lo);
+    // one anchor of run b (this lane's entry e of it) - shared by the two loops below
+    auto emit = [&](bool ok, unsigned long long at, uint64_t y, unsigned long long zx, unsigned long long zy, uint32_t ql_b) {
+        if (!ok) return;
+        const uint32_t qspan = (uint32_t)(zx & 0xff), qpos = (uint32_t)zy >> 1, qz = (uint32_t)zy & 1;
+        const uint32_t q = (uint32_t)(zy >> 32), t = (uint32_t)(y >> 32);
+        const uint32_t tpos = (uint32_t)y >> 1, strand = qz ^ ((uint32_t)y & 1);
+        const uint32_t qp = strand ? ql_b - (qpos + 1 - qspan) - 1 : qpos;
+        const uint64_t kk = (uint64_t)(q - a.q_lo) << (a.tb + 1 + a.pb) | (uint64_t)t << (1 + a.pb) |
+                            (uint64_t)strand << a.pb | tpos;
+        if (a.sk) {         // the sorted bits apart: (target, strand) in a small key, the rest in one word
+            okey[at] = ((uint64_t)(q - a.q_lo) << a.pb | tpos) << a.vb | (uint64_t)qp << 8 | qspan;
+            if (a.sk == 2) ((uint16_t *)a.oskey)[at] = (uint16_t)(t << 1 | strand);
+            else ((uint32_t *)a.oskey)[at] = t << 1 | strand;
+        } else if (a.vb) okey[at] = kk << a.vb | (uint64_t)qp << 8 | qspan;
+        else { okey[at] = kk; oval[at] = (uint64_t)qp << 32 | (uint64_t)qspan << 24; }
+    };
+    // Runs of more than SHORT_RUN entries: one after the other, all 64 lanes striding the run; the first 64 entries of the
+    // next run are already in flight while this one is worked on (two dependent reads per run would otherwise sit on the
+    // critical path every time).
+    constexpr int SHORT_RUN = 32;
+    const unsigned long long any_run = __ballot(hi != lo);
+    unsigned long long todo = __ballot(hi - lo > (size_t)SHORT_RUN);
     uint64_t y_p = 0;
     uint32_t rt_p = 0;
     auto prefetch = [&](int bn) {
@@ -271,9 +289,8 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
         const unsigned long long lo_b = __shfl((unsigned long long)lo, b, 64), hi_b = __shfl((unsigned long long)hi, b, 64);
         const uint32_t rq_b = __shfl(rq, b, 64);
         const unsigned long long zx = __shfl((unsigned long long)z.x, b, 64), zy = __shfl((unsigned long long)z.y, b, 64);
-        unsigned long long w = FILL ? __shfl((unsigned long long)w0, b, 64) : 0;
-        const uint32_t ql_b = FILL ? __shfl(ql, b, 64) : 0;
-        uint32_t c = 0;
+        unsigned long long w = __shfl((unsigned long long)w0, b, 64);
+        const uint32_t ql_b = __shfl(ql, b, 64);
         uint64_t y = y_p;
         uint32_t rt = rt_p;
         if (todo) prefetch(__ffsll((long long)todo) - 1);
@@ -283,28 +300,41 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
             // the run holds partners only (counting pass), except the read itself when pairs are taken both ways
             const bool ok = e < hi_b && (a.pair_once || rt != rq_b + 1u);
             const unsigned long long mask = __ballot(ok);
-            if (FILL && ok) {
-                const uint32_t qspan = (uint32_t)(zx & 0xff), qpos = (uint32_t)zy >> 1, qz = (uint32_t)zy & 1;
-                const uint32_t q = (uint32_t)(zy >> 32), t = (uint32_t)(y >> 32);
-                const uint32_t tpos = (uint32_t)y >> 1, strand = qz ^ ((uint32_t)y & 1);
-                const uint32_t qp = strand ? ql_b - (qpos + 1 - qspan) - 1 : qpos;
-                const unsigned long long at = w + __popcll(mask & ((1ull << lane) - 1));
-                const uint64_t kk = (uint64_t)(q - a.q_lo) << (a.tb + 1 + a.pb) | (uint64_t)t << (1 + a.pb) |
-                                    (uint64_t)strand << a.pb | tpos;
-                if (a.sk) {         // the sorted bits apart: (target, strand) in a small key, the rest in one word
-                    okey[at] = ((uint64_t)(q - a.q_lo) << a.pb | tpos) << a.vb | (uint64_t)qp << 8 | qspan;
-                    if (a.sk == 2) ((uint16_t *)a.oskey)[at] = (uint16_t)(t << 1 | strand);
-                    else ((uint32_t *)a.oskey)[at] = t << 1 | strand;
-                } else if (a.vb) okey[at] = kk << a.vb | (uint64_t)qp << 8 | qspan;
-                else { okey[at] = kk; oval[at] = (uint64_t)qp << 32 | (uint64_t)qspan << 24; }
-            }
-            const uint32_t n = (uint32_t)__popcll(mask);
-            w += n;
-            c += n;
+            emit(ok, w + __popcll(mask & ((1ull << lane) - 1)), y, zx, zy, ql_b);
+            w += (uint32_t)__popcll(mask);
         }
-        if (lane == b) my_cnt = c;
     }
-    (void)my_cnt;
+    // Short runs, FOUR at a time: a quarter of the wave each (sub-runs of a few thousand targets against a million
+    // queries - the full C4 - have ~5 partners per query minimizer: 64 lanes on one run left nine tenths of them idle).
+    unsigned long long todo_s = any_run & ~__ballot(hi - lo > (size_t)SHORT_RUN);
+    const int g = lane >> 4, sl = lane & 15;
+    while (todo_s) {
+        int bsel[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bsel[k] = todo_s ? __ffsll((long long)todo_s) - 1 : -1; todo_s &= todo_s ? todo_s - 1 : 0; }
+        const int b = g == 0 ? bsel[0] : (g == 1 ? bsel[1] : (g == 2 ? bsel[2] : bsel[3]));
+        const int bs = b >= 0 ? b : 0;
+        const unsigned long long lo_b = __shfl((unsigned long long)lo, bs, 64);
+        const unsigned long long hi_all = __shfl((unsigned long long)hi, bs, 64);      // (every lane takes part in the shuffle)
+        const unsigned long long hi_b = b >= 0 ? hi_all : lo_b;
+        const uint32_t rq_b = __shfl(rq, bs, 64);
+        const unsigned long long zx = __shfl((unsigned long long)z.x, bs, 64), zy = __shfl((unsigned long long)z.y, bs, 64);
+        unsigned long long w = __shfl((unsigned long long)w0, bs, 64);
+        const uint32_t ql_b = __shfl(ql, bs, 64);
+#pragma unroll
+        for (int it = 0; it < SHORT_RUN / 16; ++it) {
+            const unsigned long long e = lo_b + (unsigned long long)(16 * it + sl);
+            uint64_t y = 0;
+            uint32_t rt = 0;
+            if (e < hi_b) { y = a.iy[e]; if (!a.pair_once) rt = a.irk[e]; }
+            const bool ok = e < hi_b && (a.pair_once || rt != rq_b + 1u);
+            const unsigned long long mask = __ballot(ok);
+            const uint32_t mg = (uint32_t)(mask >> (16 * g)) & 0xffffu;
+            emit(ok, w + __popc(mg & ((1u << sl) - 1u)), y, zx, zy, ql_b);
+            w += (uint32_t)__popc(mg);
+            if (!__any(lo_b + 16ull * (it + 1) < hi_b)) break;
+        }
+    }
 }
 
 __global__ void gather_u32_at_kernel(const uint32_t *src, const uint32_t *idx, uint32_t *dst, size_t n) {
