@@ -84,91 +84,128 @@ def pmc_valu(timer, workload):
 
 
 # ---- CPU baseline ------------------------------------------------------------------------------------------
-def cpu_baseline(fa, cfg, budget_s=25.0):
-    """The reference's CPU path timed beside the GPU number, on a bounded sample of the same workload.
-    (1) minimap2 on $PATH: the exact command line of script/filter_overlap_slr2.py:51 on sampled --nsplit chunks, one
-        process per chunk under a pool as wide as `xargs -P` (utils.py:65) -> kind "reference";
-    (2) otherwise the oracle (this repo's CPU restatement, kind "port"): oracle overlapper + oracle filters, one process
-        per host core.
-    Sample: the first N_T target reads of as many --nsplit chunks (spread over the file) as fit the budget, each against
-    ALL query reads - every sampled target sees the pile-up depth it has in the real run, which the support filter
-    (mc) depends on, and every process sketches the whole read file as each per-chunk minimap2 process of the
-    reference does.  `candidate_rows_per_s` (rows out of the overlapper) is the figure to hold against the GPU line's
-    config.candidate_rows_per_s; `value` counts the rows the filter chain keeps of those candidates - the query-side
-    pile-up of a chunk is thinner with a few targets than with all of them, so it is an indication, not the same
-    quantity as the GPU `value`."""
-    import multiprocessing as mp
+def _oracle_ava(target_fa, query_fa, out, long_mode, threads):
+    """One oracle overlapper run in a process of its own (OMP_NUM_THREADS = threads; the oracle's query loop is an
+    OpenMP loop).  Returns seconds."""
+    code = ("import sys; sys.path.insert(0, %r)\nfrom oracle import ava as OA\n"
+            "OA.ava(%r, %r, %r, OA.opts_long() if %r else OA.opts_short())\n") % (ROOT, target_fa, query_fa, out, bool(long_mode))
+    t = time.time()
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+    return time.time() - t
+
+
+def cpu_baseline(target_fa, query_fa, nsplit, stage, long_mode=True, budget_s=150.0, gpu_check=True):
+    """The reference's CPU path timed beside the GPU number on WHOLE --nsplit chunks - the reference's own unit of work
+    (script/utils.py:54-65: one worker process per chunk, its targets against ALL queries).
+    (1) minimap2 on $PATH: the exact command line of script/filter_overlap_slr2.py:51 / :55 with -t <cores> -> kind
+        "reference";
+    (2) otherwise the oracle (this repo's CPU restatement, kind "port"): oracle overlapper with its OpenMP query loop on
+        all host cores, then the oracle filter chain (the reference's filter is single-threaded Python per chunk; the
+        oracle's pile-up is its numpy restatement) -> rows the chunk contributes to the stage output.
+    Procedure: the middle chunk of the target file (under the pair-once rule a chunk's work grows with the name rank
+    of its reads: the middle one is the mean).  Its first 8 and first 32 targets against all queries give the fit
+    t = t_fixed + n_targets * t_target (t_fixed = reading + sketching the query file, which every per-chunk process of the
+    reference repeats); when the fit says the whole chunk fits the budget it is RUN and the measured time is the number,
+    otherwise the fit is the number and `sample` says so.  More chunks follow while the budget lasts.
+    gpu_check: the GPU overlapper's rows for the same whole chunk must equal the oracle's byte for byte, and the GPU
+    worker output for that chunk the oracle filter chain's (parity at the benched workload; outside the timed region)."""
     from oracle import filters as F
-    stage = cfg["stage"]
-    n_reads = cfg["sim"]["n_reads"]
-    ranges = F.chunk_ranges(2 * n_reads, cfg["nsplit"])
-    cores = min(len(os.sched_getaffinity(0)), 32)
+    cores = len(os.sched_getaffinity(0))
     tmp = tempfile.mkdtemp(prefix="hl_cpu_")
     mm2 = shutil.which("minimap2")
-    n_t = 2
-    # A process per (sampled chunk, slice of the query file): the rows of a chunk against a slice of the queries do not
-    # depend on the other slices, so the chunk's candidate rows are the slices' rows in file order - and one sketch pass
-    # over the 100 000 queries (which every per-chunk process of the reference repeats) is spread over PARTS cores.
-    parts = max(1, min(8, cores, n_reads // 2000))
-    per_round = max(1, cores // parts)                 # chunks worked on at a time
-    qparts = []
-    with open(fa) as src:
-        for p in range(parts):
-            qp = os.path.join(tmp, f"q{p}.fa")
-            with open(qp, "w") as dst:
-                for _ in range(2 * (n_reads * (p + 1) // parts - n_reads * p // parts)):
-                    dst.write(src.readline())
-            qparts.append(qp)
-    order = [(i * len(ranges)) // per_round + k for k in range(max(1, len(ranges) // per_round)) for i in range(per_round)]
-    order = [c for c in dict.fromkeys(order) if c < len(ranges)]          # round k takes chunk k of every stripe of the file
-    want = {}
-    for i in order[:64 * per_round]:
-        lo, hi = ranges[i]
-        for l in range(lo, min(hi, lo + 2 * n_t)):
-            want[l] = i
-    tl = {}
-    with open(fa) as f:
-        for l, text in enumerate(f):
-            if l in want:
-                tl.setdefault(want[l], []).append(text.rstrip("\n"))
-    t0 = time.time()
-    done, rows, cand = 0, 0, 0
-    with mp.get_context("fork").Pool(per_round * parts) as pool:
-        nxt = 0
-        while nxt < len(order) and order[nxt] in tl and (done == 0 or (time.time() - t0) * (1 + per_round / max(done, 1)) < budget_s):
-            batch = [c for c in order[nxt:nxt + per_round] if c in tl]
-            jobs = [(qparts[p], tl[c], os.path.join(tmp, f"c{c}_{p}"), mm2) for c in batch for p in range(parts)]
-            raw = pool.map(_cpu_chunk_part, jobs)
-            for k, c in enumerate(batch):
-                chunk_rows = [r for part in raw[k * parts:(k + 1) * parts] for r in part]
-                cand += len(chunk_rows)
-                rows += len(F.worker(chunk_rows, True, stage["len_over"], stage["mc"], stage["iden"]))
-            done += len(batch)
-            nxt += per_round
-    dt = time.time() - t0
+    t_start = time.time()
+    with open(target_fa) as f:
+        n_lines = sum(1 for _ in f)
+    ranges = F.chunk_ranges(n_lines, nsplit)
+    per_rec = 4 if open(target_fa).read(1) == "@" else 2
+
+    def chunk_file(c, n_targets=None):
+        lo, hi = ranges[c]
+        if n_targets is not None:
+            hi = min(hi, lo + per_rec * n_targets)
+        path = os.path.join(tmp, f"sub{c:05d}" + (f".first{n_targets}" if n_targets else ""))
+        with open(target_fa) as src, open(path, "w") as dst:
+            for l, text in enumerate(src):
+                if l >= hi:
+                    break
+                if l >= lo:
+                    dst.write(text)
+        return path, (hi - lo) // per_rec
+
+    def run(tf, out):
+        if mm2:
+            cmd = ([mm2, "-N", "40", "-t", str(cores), "-L", "--eqx", "-cx", "ava-pb", "-Hk19", "-m100", "-g10000", "--max-chain-skip", "25"]
+                   if long_mode else
+                   [mm2, "-t", str(cores), "-c", "--sr", "-DP", "--no-long-join", "-k", "21", "-w", "11", "-s", "60", "-m", "30", "-n", "2",
+                    "-A", "4", "-B", "2", "--end-bonus=100"]) + [tf, query_fa]
+            t = time.time()
+            with open(out, "w") as o:
+                subprocess.run(cmd, stdout=o, stderr=subprocess.DEVNULL, check=True)
+            return time.time() - t
+        return _oracle_ava(tf, query_fa, out, long_mode, cores)
+
+    def n_rows(path):
+        with open(path) as f:
+            return sum(1 for _ in f)
+
+    mid = len(ranges) // 2
+    n_full = (ranges[mid][1] - ranges[mid][0]) // per_rec
+    fit = None
+    if n_full > 64:
+        f8, n8 = chunk_file(mid, 8)
+        f32, n32 = chunk_file(mid, 32)
+        t8, t32 = run(f8, f8 + ".paf"), run(f32, f32 + ".paf")
+        t_target = max((t32 - t8) / (n32 - n8), 1e-9)
+        t_fixed = max(t8 - n8 * t_target, 0.0)
+        fit = dict(t_fixed_s=round(t_fixed, 2), t_target_s=round(t_target, 4), n_small=n8, n_large=n32,
+                   rows_per_target=n_rows(f32 + ".paf") / n32,
+                   whole_chunk_s_predicted=round(t_fixed + n_full * t_target, 1))
+    res = dict(cores=cores, kind="reference" if mm2 else "port", unit="overlaps/s", chunk_targets=n_full, fit=fit)
+    what = ("minimap2 (the command of filter_overlap_slr2.py:%d, -t %d)" % (51 if long_mode else 55, cores) if mm2 else
+            f"oracle overlapper (OpenMP over the queries, {cores} threads)") + " + oracle filter chain (one thread, as the reference's per-chunk Python)"
+    if fit and fit["whole_chunk_s_predicted"] > budget_s - (time.time() - t_start):
+        # one whole chunk does not fit the budget: the fit is the number
+        T = t_fixed + n_full * t_target
+        res.update(value=None, candidate_rows_per_s=fit["rows_per_target"] * n_full / T,
+                   sample=f"whole-chunk rate from the fit t = {fit['t_fixed_s']} s + n_targets x {fit['t_target_s']} s (first {n8} and first "
+                          f"{n32} targets of chunk {mid} of {len(ranges)} x all queries; a whole chunk of {n_full} targets would take "
+                          f"{T:.0f} s, over the budget of {budget_s:.0f} s), {what}; `value` (final overlaps/s) needs a whole chunk's "
+                          "pile-up and is not estimated")
+        shutil.rmtree(tmp, ignore_errors=True)
+        return res
+    order = [mid] + [c for k in range(1, len(ranges)) for c in (mid - k, mid + k) if 0 <= c < len(ranges)]
+    done, cand, final, t_ava, t_flt = [], 0, 0, 0.0, 0.0
+    checks = {}
+    for c in order:
+        if done and (time.time() - t_start) * (1 + 1.0 / len(done)) > budget_s:
+            break
+        cf, _ = chunk_file(c)
+        ta = run(cf, cf + ".paf")
+        rows = open(cf + ".paf").read().split("\n")[:-1]
+        tf = time.time()
+        kept = F.sort_scored(F.worker(rows, long_mode, stage["len_over"], stage["mc"], stage["iden"]))
+        tf = time.time() - tf
+        t_ava += ta; t_flt += tf; cand += len(rows); final += len(kept)
+        if gpu_check and not done and not mm2:
+            from hylight_amd import api
+            api.ava(cf, query_fa, cf + ".gpu.paf", api.ava_opts_long() if long_mode else api.ava_opts_short())
+            same = open(cf + ".gpu.paf").read().split("\n")[:-1] == rows
+            api.split_reads2(query_fa, target_fa, nsplit, tmp, cf + ".gpu.w.paf", long=long_mode, rank=c, world=len(ranges), **stage)
+            same_w = open(cf + ".gpu.w.paf").read().split("\n")[:-1] == kept
+            checks = dict(chunk=c, candidate_rows=len(rows), gpu_rows_identical=same, final_rows=len(kept), gpu_worker_identical=same_w)
+            if not (same and same_w):
+                sys.stderr.write(f"PARITY FAILURE at the benched workload: chunk {c}: {checks}\n")
+        done.append(c)
+    # the reference runs `threads` chunk workers side by side (xargs -P, utils.py:65): the filter's single thread per chunk
+    # costs t_flt / cores of the machine
+    T = t_ava + t_flt / cores
+    res.update(value=final / T, candidate_rows_per_s=cand / t_ava, chunks=done, seconds=dict(overlapper=round(t_ava, 2), filter_one_thread=round(t_flt, 2)),
+               parity=checks or None,
+               sample=f"{len(done)} WHOLE --nsplit chunk(s) (chunk {done[0]} of {len(ranges)} first: {n_full} targets x all queries), {what}; "
+                      f"value = final overlaps of these chunks / (overlapper wall on {cores} cores + filter seconds / {cores}: the reference "
+                      "runs one single-threaded filter per chunk, `threads` chunks side by side)")
     shutil.rmtree(tmp, ignore_errors=True)
-    what = ("minimap2 (the command of filter_overlap_slr2.py:51, -t 1 per process) + oracle filters for the count"
-            if mm2 else "oracle overlapper + oracle filters")
-    return dict(value=rows / dt, unit="overlaps/s", candidate_rows_per_s=cand / dt, cores=min(cores, per_round * parts),
-                kind="reference" if mm2 else "port",
-                sample=f"first {n_t} target reads of {done} of the {len(ranges)} --nsplit chunks x all {n_reads} queries "
-                       f"(full pile-up depth per sampled target; a chunk's queries in {parts} slices, one process each), {what}, "
-                       f"{dt:.1f} s wall; compare candidate_rows_per_s with config.candidate_rows_per_s - `value` is the filter's "
-                       f"keep on this sample, not the same quantity as the GPU value")
-
-
-def _cpu_chunk_part(args):
-    qfa, tlines, base, mm2 = args
-    with open(base + ".fa", "w") as f:
-        f.write("\n".join(tlines) + "\n")
-    if mm2:        # script/filter_overlap_slr2.py:51
-        with open(base + ".paf", "w") as out:
-            subprocess.run([mm2, "-N", "40", "-t", "1", "-L", "--eqx", "-cx", "ava-pb", "-Hk19", "-m100", "-g10000",
-                            "--max-chain-skip", "25", base + ".fa", qfa], stdout=out, stderr=subprocess.DEVNULL, check=True)
-    else:
-        from oracle import ava as OA
-        OA.ava(base + ".fa", qfa, base + ".paf")
-    return open(base + ".paf").read().split("\n")[:-1]
+    return res
 
 
 # ---- SURVEY.md 8d: algorithmic bytes of the whole stage from the counts of one step -------------------------------
@@ -404,8 +441,12 @@ def main():
             line["graph_error"] = str(e)[:200]
     if os.environ.get("HL_BENCH_STATS"):
         sys.stderr.write("STATS " + json.dumps({k: round(v, 4) for k, v in sorted(stats.items())}) + "\n")
-    if not args.no_cpu_baseline and world == 1 and not short_calls:
-        line["cpu_baseline"] = cpu_baseline(fa, cfg)
+    if not args.no_cpu_baseline and world == 1:
+        budget = float(os.environ.get("HL_CPU_BUDGET_S", "150"))
+        if short_calls:      # the first of the two calls: short reads (queries) against the contig pieces (chunked targets)
+            line["cpu_baseline"] = cpu_baseline(con_fa, short_fa, cfg["nsplit"], cfg["stage_short"], long_mode=False, budget_s=budget)
+        else:
+            line["cpu_baseline"] = cpu_baseline(fa, fa, cfg["nsplit"], cfg["stage"], long_mode=True, budget_s=budget)
     print(json.dumps(line), flush=True)
     for rn, _ in runners:
         rn.close()

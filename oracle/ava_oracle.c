@@ -12,6 +12,7 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
+#define _GNU_SOURCE
 #include <ctype.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -51,13 +52,15 @@ typedef struct {
  *   ORACLE_EXT_BAND    diagonals of an end extension (64)
  */
 static int g_block_max = BLOCK_MAX, g_shift_max = BAND_W - 2 * BAND_PAD - 1, g_ext_max = EXT_MAX, g_ext_band = BAND_W;
-static long g_n_pieces, g_n_stubs;      /* pieces reported / of them as stubs (oracle_last_counts) */
+static int g_chain_mm2;
+static long g_n_pieces, g_n_stubs;      /* pieces reported / of them as stubs (oracle_last_counts; atomic adds) */
 static void read_switches(void) {
     const char *e;
     g_block_max = (e = getenv("ORACLE_BLOCK_MAX")) ? atoi(e) : BLOCK_MAX;
     g_shift_max = (e = getenv("ORACLE_SHIFT_MAX")) ? atoi(e) : BAND_W - 2 * BAND_PAD - 1;
     g_ext_max = (e = getenv("ORACLE_EXT_MAX")) ? atoi(e) : EXT_MAX;
     g_ext_band = (e = getenv("ORACLE_EXT_BAND")) ? atoi(e) : BAND_W;
+    g_chain_mm2 = getenv("ORACLE_CHAIN_MM2") ? 1 : 0;
 }
 
 /* ---- sequences ---------------------------------------------------------------------------- */
@@ -527,7 +530,10 @@ static void close_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
         extend_left(o, qa, T->code[ti], p, scratch);
         extend_right(o, qa, ql, T->code[ti], tl, p, scratch);
     }
-    if (p->cg.n && p->score >= o->min_dp_score) { ++g_n_pieces; g_n_stubs += stub; }
+    if (p->cg.n && p->score >= o->min_dp_score) {
+        __atomic_fetch_add(&g_n_pieces, 1, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_n_stubs, stub, __ATOMIC_RELAXED);
+    }
     emit_piece(out, o, Q, qi, T, ti, strand, p, cand);
 }
 
@@ -586,8 +592,7 @@ static void chain_group(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
     /* ORACLE_CHAIN_MM2=1 (tests/test_deviation_effects.py only): the predecessor loop of minimap2's chaining as published
      * (Li 2018 and the --max-chain-skip / max-iteration heuristics HyLight's command line sets: skip 25, 5000
      * iterations) instead of the specification's fixed window of CHAIN_PRED - to MEASURE what the fixed window changes. */
-    static int mm2_mode = -1;
-    if (mm2_mode < 0) mm2_mode = getenv("ORACLE_CHAIN_MM2") ? 1 : 0;
+    const int mm2_mode = g_chain_mm2;
     int32_t *tmark = mm2_mode ? (int32_t *)calloc((size_t)n, 4) : 0;
     if (tmark) for (int i = 0; i < n; ++i) tmark[i] = -1;
     for (int i = 0; i < n; ++i) {
@@ -673,10 +678,18 @@ int oracle_ava(const char *target_fa, const char *query_fa, const ava_opts_t *o,
     index_build(T, o, &ix);
     int64_t qcap = 0;
     for (int i = 0; i < Q->n; ++i) if (Q->len[i] > qcap) qcap = Q->len[i];
+    /* Queries are independent of each other: one query per loop trip, its rows into a buffer of its own, the buffers
+     * written in query order - the output does not depend on the number of threads (OMP_NUM_THREADS; bench.py's CPU leg
+     * uses all host cores, the tests whatever the box has). */
+    char **qbuf = (char **)calloc((size_t)(Q->n ? Q->n : 1), sizeof(char *));
+    size_t *qbuf_n = (size_t *)calloc((size_t)(Q->n ? Q->n : 1), sizeof(size_t));
+#pragma omp parallel
+    {
     mz_t *qm = (mz_t *)malloc((size_t)(qcap + 1) * sizeof(mz_t));
     uint8_t *qrc = (uint8_t *)malloc((size_t)qcap + 1);
     anchor_t *an = 0;
     int64_t an_cap = 0;
+#pragma omp for schedule(dynamic, 16)
     for (int qi = 0; qi < Q->n; ++qi) {
         int ql = Q->len[qi];
         int64_t nm = oracle_sketch_codes(Q->code[qi], ql, (uint32_t)qi, o->k, o->w, o->hpc, qm, qcap);
@@ -697,14 +710,23 @@ int oracle_ava(const char *target_fa, const char *query_fa, const ava_opts_t *o,
         if (!na) continue;
         qsort(an, na, sizeof(anchor_t), cmp_anchor);
         for (int i = 0; i < ql; ++i) { uint8_t c = Q->code[qi][ql - 1 - i]; qrc[i] = c < 4 ? 3 - c : 4; }
+        FILE *qout = open_memstream(&qbuf[qi], &qbuf_n[qi]);
         for (int64_t b = 0; b < na;) {
             int64_t e = b;
             while (e < na && an[e].t == an[b].t && an[e].strand == an[b].strand) ++e;
-            chain_group(out, o, Q, qi, an[b].strand ? qrc : Q->code[qi], T, an + b, (int)(e - b));
+            chain_group(qout, o, Q, qi, an[b].strand ? qrc : Q->code[qi], T, an + b, (int)(e - b));
             b = e;
         }
+        fclose(qout);
     }
-    free(an); free(qm); free(qrc); free(ix.e);
+    free(an); free(qm); free(qrc);
+    }
+    for (int qi = 0; qi < Q->n; ++qi) {
+        if (qbuf_n[qi]) fwrite(qbuf[qi], 1, qbuf_n[qi], out);
+        free(qbuf[qi]);
+    }
+    free(qbuf); free(qbuf_n);
+    free(ix.e);
     fclose(out);
     seqset_free(T); seqset_free(Q);
     return 0;

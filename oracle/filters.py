@@ -229,11 +229,24 @@ def supported_pair_counts(snp, partners, intervals, mc):
     """mutation[pair] = number of supported SNP keys at which the pair disagrees.
     A key with v >= mc supporters is kept when at least mc further reads span it strictly
     (#intervals with start < pos < end, minus v)."""
+    from bisect import bisect_left, bisect_right
     mutation = defaultdict(int)
+    # every recorded interval has start < end (aligned spans), so the intervals with end <= pos are among those with
+    # start < pos and  #(start < pos < end) = #(start < pos) - #(end <= pos): two searches in sorted lists instead of a
+    # scan of the read's intervals per key (a target of a full-size chunk has ~10^3 intervals and ~10^4 keys)
+    starts, ends, odd = {}, {}, set()
+    for read, iv in intervals.items():
+        if any(s >= e for s, e in iv):
+            odd.add(read)                 # (hand-made rows only: counted by the definition below)
+        starts[read] = sorted(s for s, _ in iv)
+        ends[read] = sorted(e for _, e in iv)
     for (read, pos), v in snp.items():
         if v < mc:
             continue
-        spanning = sum(1 for s, e in intervals.get(read, ()) if s < pos < e)
+        if read in odd:
+            spanning = sum(1 for s, e in intervals.get(read, ()) if s < pos < e)
+        else:
+            spanning = bisect_left(starts.get(read, ()), pos) - bisect_right(ends.get(read, ()), pos)
         if spanning - v < mc:
             continue
         for other in partners[(read, pos)]:
@@ -275,12 +288,127 @@ def pass2(sorted_lines, mutation, long_mode, min_ovlp_len, iden, threshold=0.002
     return out
 
 
-def worker(raw_lines, long_mode, min_ovlp_len, mc, iden):
-    """One chunk: filter_overlap_slr2.main after the overlapper (slr2:51-152)."""
+def pair_counts_np(sorted_lines, long_mode, mc):
+    """snp_pileup + supported_pair_counts in one go with numpy - the SAME quantities (those two functions are the
+    definition and stay pinned to the reference's goldens; tests/test_oracle_filters.py holds this one to them on the golden
+    inputs and on simulated chunks).  A full-size chunk is ~4e5 rows and ~6e7 X events: minutes per chunk in the per-event
+    Python loops, seconds here.  Returns None when a CIGAR is not plain `<digits><=XIDMNSHP>...` text or an interval has no
+    extent (the caller then takes the definitional path)."""
+    import numpy as np
+    ids, names = {}, []
+
+    def rid(name):
+        i = ids.get(name)
+        if i is None:
+            i = ids[name] = len(names)
+            names.append(name)
+        return i
+
+    used = set()
+    rq, rt, rql, rqs, rqe, rts, rte, rminus, cigs = [], [], [], [], [], [], [], [], []
+    for line in sorted_lines:                                   # row selection: as snp_pileup
+        c = line.split("\t")
+        if len(c) < 6:
+            continue
+        q, t = c[0], c[5]
+        if q == t or (c[-1].strip() if long_mode else c[-1]) == "*":
+            continue
+        if long_mode:
+            pk = pair_key(q, t)
+            if pk in used:
+                continue
+            used.add(pk)
+        last = c[-1].strip()
+        rq.append(rid(q)); rt.append(rid(t)); rql.append(int(c[1])); rqs.append(int(c[2])); rqe.append(int(c[3]))
+        rts.append(int(c[7])); rte.append(int(c[8])); rminus.append(c[4] != "+")
+        cigs.append(last[5:].encode() if last.startswith("cg:Z:") else b"")
+    if not rq:
+        return {}
+    rq, rt, rql, rqs, rqe, rts, rte = (np.asarray(x, dtype=np.int64) for x in (rq, rt, rql, rqs, rqe, rts, rte))
+    rminus = np.asarray(rminus, dtype=bool)
+    if (rts >= rte).any() or (long_mode and (rqs >= rqe).any()):
+        return None
+    big = np.frombuffer(b"".join(cigs), dtype=np.uint8)
+    row_off = np.zeros(len(cigs) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in cigs], out=row_off[1:])
+    if len(big) and big.min() < 48:
+        return None
+    L = np.flatnonzero(big > 57)                                 # one op letter per CIGAR op (digits are 48..57)
+    if not len(L):
+        return {}
+    op = big[L]
+    lut = np.zeros(256, dtype=bool)
+    lut[np.frombuffer(b"=XIDMNSHP", dtype=np.uint8)] = True
+    if not lut[op].all():
+        return None
+    ndig = np.empty(len(L), dtype=np.int64)
+    ndig[0] = L[0]
+    ndig[1:] = L[1:] - L[:-1] - 1
+    if ndig.min() < 1 or ndig.max() > 9:
+        return None
+    nonempty = row_off[1:] > row_off[:-1]
+    if (big[row_off[1:][nonempty] - 1] <= 57).any():             # a CIGAR ends with its last op letter
+        return None
+    n = big[L - 1].astype(np.int32) - 48
+    for p in range(2, int(ndig.max()) + 1):
+        m = np.flatnonzero(ndig >= p)
+        n[m] += (big[L[m] - p].astype(np.int32) - 48) * np.int32(10 ** (p - 1))
+    first = np.searchsorted(L, row_off[:-1], side="left")        # index of each row's first op (len(L): none)
+    # positions inside a row: cumulated op lengths minus their value at the row's first op; 32-bit sums that wrap
+    # around give the right DIFFERENCES (a row spans far less than 2^31 bases)
+    isx = op == ord("X")
+    adv = (op == ord("=")) | isx
+    dq = np.where(adv | (op == ord("I")), n, np.int32(0))
+    dt = np.where(adv | (op == ord("D")), n, np.int32(0))
+    del adv
+    cq, ct = np.cumsum(dq, dtype=np.int32), np.cumsum(dt, dtype=np.int32)
+    del dq, dt
+    xi = np.flatnonzero(isx)
+    xr = np.searchsorted(first, xi, side="right") - 1            # row of every X op (rows without ops share `first` with the next)
+    has_ops = first < np.concatenate((first[1:], [len(L)]))
+    if not has_ops.all():                                        # map through the rows that have ops
+        rows_with = np.flatnonzero(has_ops)
+        xr = rows_with[np.searchsorted(first[rows_with], xi, side="right") - 1]
+    f = first[xr]
+    cq0 = np.where(f > 0, cq[np.maximum(f, 1) - 1], np.int32(0))
+    ct0 = np.where(f > 0, ct[np.maximum(f, 1) - 1], np.int32(0))
+    q0 = np.where(rminus, rql - rqe, rqs)
+    qpos = q0[xr] + (cq[xi] - cq0).astype(np.int64)
+    tpos = rts[xr] + (ct[xi] - ct0).astype(np.int64)
+    del cq, ct
+    ev_read, ev_pos, ev_other = rt[xr], tpos, rq[xr]
+    iv_read, iv_s, iv_e = rt, rts, rte
+    if long_mode:
+        qkey = np.where(rminus[xr], rql[xr] - qpos + 1, qpos)
+        ev_read = np.concatenate((ev_read, rq[xr])); ev_pos = np.concatenate((ev_pos, qkey)); ev_other = np.concatenate((ev_other, rt[xr]))
+        iv_read = np.concatenate((iv_read, rq)); iv_s = np.concatenate((iv_s, rqs)); iv_e = np.concatenate((iv_e, rqe))
+    if not len(ev_read):
+        return {}
+    if ev_pos.min() < 0 or ev_pos.max() >= 1 << 31 or iv_s.min() < 0 or iv_e.max() >= 1 << 31:
+        return None
+    key = ev_read << 32 | ev_pos
+    uk, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    sk = np.sort(iv_read << 32 | iv_s)
+    ek = np.sort(iv_read << 32 | iv_e)
+    ur = uk >> 32 << 32
+    spanning = (np.searchsorted(sk, uk, side="left") - np.searchsorted(sk, ur, side="left")) \
+        - (np.searchsorted(ek, uk, side="right") - np.searchsorted(ek, ur, side="left"))
+    good = (cnt >= mc) & (spanning - cnt >= mc)
+    ge = good[inv]
+    a, b = ev_read[ge], ev_other[ge]
+    pu, pc = np.unique(np.minimum(a, b) << 32 | np.maximum(a, b), return_counts=True)
+    return {pair_key(names[int(k) >> 32], names[int(k) & 0xffffffff]): int(v) for k, v in zip(pu, pc)}
+
+
+def worker(raw_lines, long_mode, min_ovlp_len, mc, iden, fast=True):
+    """One chunk: filter_overlap_slr2.main after the overlapper (slr2:51-152).  fast=False: the pile-up by the
+    definitional per-event functions (snp_pileup, supported_pair_counts) instead of their numpy restatement."""
     kept = window_filter(raw_lines, variant=4, min_len=30, min_o=3)
     srt = sort_intermediate(kept)
-    snp, partners, intervals = snp_pileup(srt, long_mode)
-    mutation = supported_pair_counts(snp, partners, intervals, mc)
+    mutation = pair_counts_np(srt, long_mode, mc) if fast else None
+    if mutation is None:
+        snp, partners, intervals = snp_pileup(srt, long_mode)
+        mutation = supported_pair_counts(snp, partners, intervals, mc)
     return pass2(srt, mutation, long_mode, min_ovlp_len, iden)
 
 

@@ -1,0 +1,130 @@
+"""GPU vs oracle, byte for byte, AT THE BENCHED WORKLOADS (BASELINE.json configs[2], [4], [3]):
+
+  * C3 (100 000 reads, --nsplit 200): one WHOLE --nsplit chunk - 504 target reads against all 100 000 queries, the
+    reference's unit of work (script/utils.py:54-65) - raw overlapper rows (hlmi_ava = the minimap2 call of
+    filter_overlap_slr2.py:51) and the worker's output for the chunk (hlmi_split_reads2_shard restricted to it vs the
+    oracle overlapper + oracle/filters.py): every target sees its real pile-up depth (~1000 x pooled);
+  * C5 at its real depth and divergence (50 strains, ANI 95-99 %, 2 % read errors; a tenth of the reads on a tenth
+    of the genome length = the same depth): targets sampled across the file against ALL queries;
+  * C4s (the short-read calls of the hybrid pipeline, script/HyLight.py:200): contig pieces sampled across the file
+    against all short reads of C4 at a tenth.
+
+tests/test_gpu_c2_chunks_oracle.py does the same for C2.  The oracle runs its OpenMP query loop on all host cores."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from hylight_amd import api
+from hylight_amd import workloads as W
+from oracle import filters as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_proc(target, query, out, long_mode=True, stub=-1):
+    """The oracle overlapper in a process of its own (the GPU works meanwhile)."""
+    code = ("import sys; sys.path.insert(0, %r)\nfrom oracle import ava as OA\n"
+            "o = OA.opts_long() if %r else OA.opts_short()\no.stub_oh = %d\nOA.ava(%r, %r, %r, o)\n") % (ROOT, long_mode, stub, target, query, out)
+    return subprocess.Popen([sys.executable, "-c", code])
+
+
+def _lines(path):
+    with open(path) as f:
+        return f.read().split("\n")[:-1]
+
+
+def _first_difference(got, want):
+    for i, (g, w) in enumerate(zip(got, want)):
+        if g != w:
+            return f"row {i}:\n  gpu    {g[:300]}\n  oracle {w[:300]}"
+    return f"row counts {len(got)} (gpu) vs {len(want)} (oracle)"
+
+
+def test_one_whole_chunk_of_c3_matches_the_oracle(tmp_path):
+    cfg = W.config("C3")
+    fa = str(tmp_path / "s1.fa")
+    W.make_long(cfg, fa)
+    with open(fa) as f:
+        lines = f.read().split("\n")[:-1]
+    ranges = F.chunk_ranges(len(lines), cfg["nsplit"])
+    assert len(ranges) == 199
+    c = 60                                     # 504 reads; by the pair-once rule it meets ~30 % of its overlapping queries
+    lo, hi = ranges[c]
+    assert hi - lo == 1008
+    cf = str(tmp_path / f"sub{c:05d}")
+    with open(cf, "w") as f:
+        f.write("\n".join(lines[lo:hi]) + "\n")
+    del lines
+    p = _oracle_proc(cf, fa, cf + ".oracle.paf")
+    api.ava(cf, fa, cf + ".gpu.paf")
+    stage = cfg["stage"]
+    api.split_reads2(fa, fa, cfg["nsplit"], tmp_path, tmp_path / "w.paf", long=True, rank=c, world=len(ranges), **stage)
+    assert p.wait(timeout=1500) == 0
+    want, got = _lines(cf + ".oracle.paf"), _lines(cf + ".gpu.paf")
+    assert len(want) > 100_000
+    assert got == want, "whole C3 chunk, raw overlapper rows: " + _first_difference(got, want)
+    w = F.sort_scored(F.worker(want, True, stage["len_over"], stage["mc"], stage["iden"]))
+    g = _lines(tmp_path / "w.paf")
+    print(f"C3 chunk {c}: {len(want)} candidate rows, {len(w)} final rows")
+    assert g == w, "whole C3 chunk, worker output: " + _first_difference(g, w)
+
+
+def _sampled_targets(fa, out, n, per_rec=2):
+    with open(fa) as f:
+        lines = f.read().split("\n")[:-1]
+    n_rec = len(lines) // per_rec
+    pick = sorted({(k * n_rec) // n + (n_rec // (2 * n)) for k in range(n)})
+    with open(out, "w") as f:
+        for r in pick:
+            f.write("\n".join(lines[per_rec * r:per_rec * (r + 1)]) + "\n")
+    return len(pick)
+
+
+def test_c5_depth_sample_matches_the_oracle(tmp_path):
+    cfg = W.config("C5", 0.1)                  # 50 000 reads on 50 strains x 200 kb: C5's depth, divergence and error model
+    fa = str(tmp_path / "s1.fa")
+    W.make_long(cfg, fa)
+    tf = str(tmp_path / "targets.fa")
+    assert _sampled_targets(fa, tf, 48) == 48
+    procs = [_oracle_proc(tf, fa, tf + f".oracle{stub}.paf", stub=stub) for stub in (-1, 3)]
+    o = api.ava_opts_long()
+    api.ava(tf, fa, tf + ".gpu-1.paf", o)
+    o.stub_oh = 3                              # the form the stage entry points run (stub rule)
+    api.ava(tf, fa, tf + ".gpu3.paf", o)
+    for p in procs:
+        assert p.wait(timeout=1500) == 0
+    for stub in (-1, 3):
+        want, got = _lines(tf + f".oracle{stub}.paf"), _lines(tf + f".gpu{stub}.paf")
+        assert len(want) > 5_000
+        assert got == want, f"C5 sample (stub_oh {stub}): " + _first_difference(got, want)
+    stage = cfg["stage"]
+    rows = _lines(tf + ".oracle3.paf")
+    print(f"C5 sample: {len(rows)} candidate rows of 48 targets, "
+          f"{len(F.worker(rows, True, stage['len_over'], stage['mc'], stage['iden']))} final rows")
+
+
+def test_c4_short_calls_sample_matches_the_oracle(tmp_path):
+    from hylight_amd import simulate as S
+    cfg = W.config("C4", 0.02)                 # 200 000 short reads, 100 strains x 50 kb: C4's short-read depth
+    _, _, strains = W.make_long(dict(cfg, sim=dict(cfg["sim"], n_reads=10)), str(tmp_path / "unused.fa"))
+    short_fa, con_fa = str(tmp_path / "short.fa"), str(tmp_path / "contigs.fa")
+    W.make_short(cfg, strains, short_fa)
+    contigs = [S.Read(f"longr_con_{k}_{a}", g[a:a + 40_000].copy(), None, k, a, a + 40_000, False)
+               for k, g in enumerate(strains) for a in range(0, len(g) - 10_000, 40_000)]
+    S.write_fasta(contigs, con_fa)
+    tf = str(tmp_path / "targets.fa")
+    n = _sampled_targets(con_fa, tf, 12)
+    procs = [_oracle_proc(tf, short_fa, tf + f".oracle{stub}.paf", long_mode=False, stub=stub) for stub in (-1, 3)]
+    o = api.ava_opts_short()
+    api.ava(tf, short_fa, tf + ".gpu-1.paf", o)
+    o.stub_oh = 3
+    api.ava(tf, short_fa, tf + ".gpu3.paf", o)
+    for p in procs:
+        assert p.wait(timeout=1500) == 0
+    for stub in (-1, 3):
+        want, got = _lines(tf + f".oracle{stub}.paf"), _lines(tf + f".gpu{stub}.paf")
+        assert len(want) > 2_000 * n
+        assert got == want, f"C4s sample (stub_oh {stub}): " + _first_difference(got, want)
