@@ -42,9 +42,17 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 
 # the hybrid pipeline (script/HyLight.py:200,207) over C4's short reads, 8 slices each
 SLICES = {"C3": 8, "C5": 64, "C4": 64, "C4s": 8}
 
-KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_narrow", "align_wide": "hlmi::align_kernel",
-                   "align_classify": "hlmi::classify_kernel", "seed_fill": "hlmi::seed_kernel<true>",
-                   "seed_count": "hlmi::seed_kernel<false>", "anchor_sort": "hlmi::anchor_"}
+KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_narrow_pk_kernel<128, true>",
+                   "align_narrow_small": "hlmi::align_narrow_pk_kernel<64, true>", "align_narrow_long": "hlmi::align_narrow_pk_kernel<256, true>",
+                   "align_score_narrow": "hlmi::align_narrow_pk_kernel<128, false>", "align_score_narrow_long": "hlmi::align_narrow_pk_kernel<256, false>",
+                   "align_wide": "hlmi::align_kernel<256, true>", "align_wide_short": "hlmi::align_kernel<128, true>",
+                   "align_score_wide": "hlmi::align_kernel<256, false>", "align_score_wide_short": "hlmi::align_kernel<128, false>",
+                   "align_long": "hlmi::align_long_kernel<true, true>", "align_score_long": "hlmi::align_long_kernel<true, false>",
+                   "align_classify": "hlmi::classify_kernel<1>", "assemble_write": "hlmi::assemble_kernel<true>",
+                   "assemble_count": "hlmi::assemble_kernel<false>", "seed_fill": "hlmi::seed_kernel<true>",
+                   "seed_count": "hlmi::seed_kernel<false>", "anchor_sort": "rocprim::radix_sort_onesweep",
+                   "filter_v4": "hlmi::window_filter_kernel", "filter_pileup_heavy": "hlmi::snp_pileup_kernel",
+                   "filter_pileup_light": "hlmi::snp_pileup_light_kernel"}
 
 
 def _latest_profile(suffix, workload):
@@ -68,18 +76,21 @@ def pmc_traffic(timer, workload):
 
 def pmc_valu(timer, workload):
     """What the kernel behind `timer` is really bound by (chain and banded DP are VALU work): the share
-    of the SIMDs' vector-issue cycles it uses, from the committed SQ counter pass (tools/summarize_sq.py;
-    SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    of the SIMDs' vector-issue cycles it uses, from the committed SQ counter pass (tools/summarize_sq.py: SQ_INSTS_VALU x 2
+    cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), and the same over the 0.893 the calibration kernel of
+    tools/valu_calib.hip reaches - profiles/r04_valu_calibration.json)."""
     f = _latest_profile("sq_counters", workload)
     if not f:
         return None
     d = json.load(open(f))
     name = KERNEL_OF_TIMER.get(timer, "")
     k = next((v for n, v in d.items() if name and n.startswith(name)), None)
-    if not k or not k.get("GRBM_GUI_ACTIVE"):
+    insts = (k or {}).get("SQ_INSTS_VALU") or (k or {}).get("SQ_ACTIVE_INST_VALU")
+    if not k or not k.get("GRBM_GUI_ACTIVE") or not insts:
         return None
-    busy = k["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0)
-    return dict(valu_issue_frac=round(busy, 4), valu_insts_per_launch=k.get("SQ_INSTS_VALU", 0.0) / max(k.get("launches", 1), 1),
+    busy = insts * 2.0 / (1024.0 * k["GRBM_GUI_ACTIVE"] / 8.0)
+    return dict(valu_issue_frac=round(busy, 4), valu_issue_vs_saturation=round(busy / 0.893, 4),
+                valu_insts_per_launch=insts / max(k.get("launches", 1), 1), frac_wait_any=k.get("frac_wait_any"),
                 source=os.path.basename(f))
 
 
@@ -370,17 +381,28 @@ def main():
     A, P = stats.get("anchors", 0.0), stats.get("pieces", 0.0)
     AB = stats.get("anchor_bytes", 16 * A)             # 8 B per anchor when a batch packs them into one word, else 16
     M = stats.get("minimizers_q", 0.0)
+    E, NT = stats.get("cigar_ops", 0.0), stats.get("align_tasks", 0.0)
+    rows_in, rows_v4 = stats.get("ava_rows", 0.0), stats.get("rows_after_v4", 0.0)
     algo = {
         # every anchor read once, the alignment pieces (32 B) and their fixed points (8 B) written once; the DP's
         # own arrays are scratch, not counted
         "chain": AB + 32 * P + 8 * stats.get("fixed_points", 0.0),
-        "align_narrow": stats.get("align_bases_narrow", 0.0) + 4 * stats.get("cigar_ops", 0.0) + 32 * stats.get("align_tasks_narrow", 0.0),
-        "align_wide": stats.get("align_bases_wide", 0.0) + 32 * stats.get("align_tasks_wide", 0.0),
-        "align_classify": stats.get("align_bases_classify", 0.0) + (32 + 24 + 1) * stats.get("align_tasks", 0.0),
+        "align_classify": stats.get("align_bases_classify", 0.0) + (32 + 24 + 1) * NT,
         "anchor_sort": 2 * AB,                         # one read + one write per anchor
         "seed_fill": 16 * M + 8 * A + AB,              # query minimizers, index occurrences (y), anchors out
         "seed_count": 16 * M + 4 * A,                  # query minimizers, rank/frequency word of every occurrence
+        # task results (24 B) and their runs in, merged CIGAR ops + 64-byte rows out
+        "assemble_write": 24 * NT + 4 * E + 4 * E + 64 * rows_in,
+        "assemble_count": 24 * NT,
+        "filter_v4": 64 * rows_in + rows_in,           # rows in, one flag out
+        # two walks over the CIGARs of the selected rows (their share of all ops), rows + references
+        "filter_pileup_heavy": 8 * E * (rows_v4 / rows_in if rows_in else 0.0) + 72 * rows_v4,
+        "filter_pileup_light": 8 * E * (rows_v4 / rows_in if rows_in else 0.0) + 72 * rows_v4,
     }
+    for key, v in stats.items():                       # every DP launch: its tasks' bases once + task record (32 B) + result (24 B)
+        if key.startswith("align_bases."):
+            t = key.split(".", 1)[1]
+            algo[t] = v + 56 * stats.get("align_n." + t, 0.0)
     launches = max(kn.get(dom, 1.0), 1.0)
     avg_ms = kms[dom] / launches
     bytes_per_launch = algo.get(dom, 0.0) / launches

@@ -22,7 +22,7 @@ class AvaOpts(C.Structure):
                 ("min_mid_occ", C.c_int), ("mid_occ_frac", C.c_double),
                 ("match", C.c_int), ("mismatch", C.c_int), ("gap_open", C.c_int), ("gap_ext", C.c_int),
                 ("ambi", C.c_int), ("min_dp_score", C.c_int), ("end_bonus", C.c_int), ("pair_once", C.c_int),
-                ("gap_open2", C.c_int), ("gap_ext2", C.c_int), ("stub_oh", C.c_int)]
+                ("gap_open2", C.c_int), ("gap_ext2", C.c_int), ("stub_oh", C.c_int), ("zdrop", C.c_int)]
 
 
 class VqOverlap(C.Structure):

@@ -13,15 +13,22 @@ namespace hlmi {
 // ---- spec constants (same values as oracle/ava_oracle.c) -------------------------------------
 constexpr int CHAIN_PRED = 64;
 constexpr int BLOCK_MIN = 32;
-constexpr int BLOCK_MAX = 256;
+constexpr int BLOCK_MAX = 256;      // rows / columns up to which a block takes the 16 / 64-diagonal kernels; longer: LONG blocks
 constexpr int BAND_W = 64;
 constexpr int BAND_PAD = 12;
 constexpr int NARROW_W = 16;        // blocks with |delta| <= NARROW_DELTA use a 16-diagonal band
 constexpr int NARROW_PAD = 5;
 constexpr int NARROW_DELTA = 5;
-constexpr int EXT_MAX = 256;
+constexpr int EXT_MAX = 256;        // an end extension runs over up to max(EXT_MAX, max_gap) rows (ext_rows)
+constexpr int ZDROP_STEP = 32;      // the z-drop test of an extension runs after rows 32, 64, ...
+constexpr int SHIFT_MAX = BAND_W - 2 * BAND_PAD - 1;     // 39: largest diagonal shift of one block
 constexpr int MAX_MID_OCC = 1000000;
 constexpr int NEG_INF = -(1 << 29);
+
+// rows an end extension may run over: minimap2 extends a chain end by up to max_gap bases (or to a z-drop)
+inline int ext_rows(const hlmi_ava_opts &o) { return o.max_gap > EXT_MAX ? o.max_gap : EXT_MAX; }
+// longest block / extension a chain can ask for (a link spans <= max_gap; fixed points are >= BLOCK_MIN apart)
+inline int long_rows_cap(const hlmi_ava_opts &o) { return ext_rows(o) + BLOCK_MIN + SHIFT_MAX + BAND_W + 1; }
 
 hlmi_ava_opts ava_opts_long();    // filter_overlap_slr2.py:51
 hlmi_ava_opts ava_opts_short();   // filter_overlap_slr2.py:55

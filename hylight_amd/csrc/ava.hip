@@ -54,6 +54,7 @@ hlmi_ava_opts ava_opts_long() {
     o.min_dp_score = 80; o.end_bonus = 0; o.pair_once = 1;
     o.gap_open2 = 24; o.gap_ext2 = 1;          // -O4,24 -E2,1: the preset's two-piece gap cost
     o.stub_oh = -1;                            // every piece extended (the stage sets the bound of its v4 filter)
+    o.zdrop = 400;                             // -z 400 (preset default): end extensions run up to max_gap rows or to a z-drop
     return o;
 }
 
@@ -69,6 +70,7 @@ hlmi_ava_opts ava_opts_short() {
     o.min_dp_score = 60; o.end_bonus = 100; o.pair_once = 0;
     o.gap_open2 = 32; o.gap_ext2 = 1;          // --sr: -O12,32 -E2,1
     o.stub_oh = -1;
+    o.zdrop = 0;                               // extensions stay within 256 rows (max_gap 200): no z-drop
     return o;
 }
 

@@ -1,8 +1,10 @@
 // ava_align.hip - S5 of the overlapper spec: base-level alignment of the chain pieces.
 //
 // Every piece is a list of fixed points; consecutive fixed points bound an independent global
-// alignment block (<= 256 x 256, |diagonal shift| <= 39) and the two piece ends get a local
-// extension (<= 256 rows).  Passes:
+// alignment block (|diagonal shift| <= 39, any length) and the two piece ends get a local
+// extension (up to max(256, max_gap) rows, z-drop).  Blocks of more than 256 rows or columns and
+// extensions of more than 256 rows are LONG tasks (align_long_kernel: the band walks the task in
+// tiles of 256 rows, its traceback planes live in a scratch area per wave).  Passes:
 //   make_tasks   one self-contained 32-byte record per block / extension
 //   classify     lane per task: square blocks with <= kmax substitutions are finished on the spot (proof at the
 //                kernel), the rest is split into near-diagonal (16-diagonal band) and wide (64 diagonals) lists
@@ -79,7 +81,8 @@ struct TaskGeom {
 // Window element x of a task: query = qcodes[qa + x] (complemented and read downwards, qcodes[qa - x], when exactly one
 // of "left extension" and "reverse strand" holds; complemented whenever the strand is reverse); target =
 // tcodes[ta + x], downwards for a left extension.
-__device__ __forceinline__ Task build_task(const PieceGeom &p, uint32_t piece, uint32_t kind, FixPt f0, FixPt f1) {
+// ext_max = ext_rows(opts): rows an end extension may run over
+__device__ __forceinline__ Task build_task(const PieceGeom &p, uint32_t piece, uint32_t kind, FixPt f0, FixPt f1, int ext_max) {
     const int ql = (int)p.ql, tl = (int)p.tl;
     const uint64_t qo = p.qo, to = p.to;
     const uint16_t rev = p.strand ? TASK_REV : 0;
@@ -87,28 +90,32 @@ __device__ __forceinline__ Task build_task(const PieceGeom &p, uint32_t piece, u
     auto qaddr = [&](int pos) { return p.strand ? qo + (uint64_t)(ql - 1 - pos) : qo + (uint64_t)pos; };
     if (kind == 1) {                    // left extension: elements run downwards from the fixed point
         const int qs = (int)f0.q, ts = (int)f0.t;
-        return Task{piece, (uint16_t)(1u | rev), (uint16_t)(qs <= EXT_MAX ? (qs + 1) << 1 : 0), qaddr(qs - 1),
-                    to + (uint64_t)(ts - 1), (int16_t)(qs < EXT_MAX ? qs : EXT_MAX), (int16_t)(ts < SEQ_T_MAX ? ts : SEQ_T_MAX),
-                    (int16_t)(-(BAND_W / 2 - 1)), 0};
+        // (columns: the band ends BAND_W / 2 diagonals right of the main one - more than m + BAND_W target bases are never
+        //  looked at, and the 64-diagonal kernels stage no more than SEQ_T_MAX of them)
+        const int m = qs < ext_max ? qs : ext_max, n2 = ts < m + BAND_W ? ts : m + BAND_W;
+        return Task{piece, (uint16_t)(1u | rev), (uint16_t)(qs <= ext_max ? (qs + 1) << 1 : 0), qaddr(qs - 1),
+                    to + (uint64_t)(ts - 1), (int16_t)m, (int16_t)n2, (int16_t)(-(BAND_W / 2 - 1)), 0};
     }
     if (kind == 2) {                    // right extension
         const int qe = (int)f0.q, te = (int)f0.t;
-        const int m = ql - qe < EXT_MAX ? ql - qe : EXT_MAX, n2 = tl - te < SEQ_T_MAX ? tl - te : SEQ_T_MAX;
-        return Task{piece, (uint16_t)(2u | rev), (uint16_t)(ql - qe <= EXT_MAX ? (ql - qe + 1) << 1 : 0), qaddr(qe),
+        const int m = ql - qe < ext_max ? ql - qe : ext_max, n2 = tl - te < m + BAND_W ? tl - te : m + BAND_W;
+        return Task{piece, (uint16_t)(2u | rev), (uint16_t)(ql - qe <= ext_max ? (ql - qe + 1) << 1 : 0), qaddr(qe),
                     to + (uint64_t)te, (int16_t)m, (int16_t)n2, (int16_t)(-(BAND_W / 2 - 1)), 0};
     }
     // block between two fixed points
     const int q0 = (int)f0.q, t0 = (int)f0.t, m = (int)f1.q - q0, n2 = (int)f1.t - t0;
-    const int delta = n2 - m;
-    // band rule: near-diagonal blocks use the 16-diagonal band
-    const bool narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
+    const int delta = n2 - m, ad = delta < 0 ? -delta : delta;
+    // band rule: near-diagonal blocks use the 16-diagonal band; a LONG block (more than BLOCK_MAX rows or
+    // columns) takes 64 diagonals centred on the diagonals of its two corners
+    const bool lng = m > BLOCK_MAX || n2 > BLOCK_MAX;
+    const bool narrow = !lng && ad <= NARROW_DELTA;
     return Task{piece, rev, (uint16_t)(narrow ? 1 : 0), qaddr(q0), to + (uint64_t)t0, (int16_t)m, (int16_t)n2,
-                (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD)), 0};
+                (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : lng ? (BAND_W - 1 - ad) / 2 : BAND_PAD)), 0};
 }
 // references of the tasks of every piece and the piece's geometry (one wave per piece)
 __global__ __launch_bounds__(WG) void task_ref_kernel(const Piece *pieces, const uint32_t *task_off, size_t n, const uint32_t *qlen,
                                                        const uint32_t *tlen, const uint64_t *qoff, const uint64_t *toff,
-                                                       const FixPt *fps, int stub_oh, TaskRef *task_ref, PieceGeom *pg) {
+                                                       const FixPt *fps, int stub_oh, int ext_max, TaskRef *task_ref, PieceGeom *pg) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(WG) void task_ref_kernel(const Piece *pieces, const
             uint32_t cand = 0;
             if (stub_oh >= 0) {          // (oracle/ava_oracle.c:is_stub - the geometric half of the rule)
                 const FixPt a = fps[p.fp_off], b = fps[p.fp_off + p.n_fp - 1];
-                const uint32_t dq = (uint32_t)(EXT_MAX + stub_oh), dt = (uint32_t)(EXT_MAX + BAND_W + stub_oh);
+                const uint32_t dq = (uint32_t)(ext_max + stub_oh), dt = (uint32_t)(ext_max + BAND_W + stub_oh);
                 cand = ((a.q > dq && a.t > dt) || (ql - b.q > dq && tl - b.t > dt)) ? 1u : 0u;
             }
             pg[i] = PieceGeom{qoff[p.q], toff[p.t], ql, tl, p.strand, cand};
@@ -144,6 +151,10 @@ struct AlignArgs {
     int match, mismatch, go, ge, ambi;
     int go2, ge2;           // second piece of the gap cost (go2 <= 0: one piece); only the 64-diagonal kernel can meet gaps long enough for it
     int end_bonus;          // ranks extension cells that reach the query end (0 in long mode)
+    int ext_max;            // rows an end extension may run over (ext_rows)
+    int ext_all_long;       // 1: every extension runs in align_long_kernel (the z-drop could change an extension of <= EXT_MAX rows)
+    int ungapped;           // 1: bandwidth 0 (minimap2 -r 0: the DP band is the diagonal alone) - blocks are square, tasks the
+                            // certificates do not settle are compared along the diagonal (align_ungapped_kernel)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     int kgap1;              // 1: blocks with |n - m| = 1 and one substitution finish in the classifier (fifth certificate)
     int one_ok;             // 1: extensions may be certified for the one-piece rows (HLMI_NO_ONE_PIECE_CERT: test hook)
@@ -235,8 +246,10 @@ __device__ __forceinline__ uint32_t load_window4p(const uint8_t *codes, long lon
 
 // stats[]: 0 bases (Lq + Lt) of all tasks, 1 of the square blocks compared here, 2 of the narrow DP tasks, 3 of the
 // wide DP tasks, 4 tasks finished on the diagonal fast path, 5 DP tasks, 6 DP rows
-enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, ST_EXT_CERT, ST_EXT_DP_ROW, ST_EXT_DP_K, N_ALIGN_STATS };
+enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, ST_EXT_CERT, ST_EXT_DP_ROW, ST_EXT_DP_K, ST_LONG, ST_BASES_LONG, N_ALIGN_STATS };
 constexpr int NR_SMALL = 64;                    // narrow tasks with fewer rows than this run in the instance with half the plane LDS
+constexpr uint8_t CLS_LONG = 5;                 // class of the LONG tasks (align_long_kernel)
+constexpr uint8_t CLS_UNGAPPED = 6;             // bandwidth 0: every task a certificate does not settle (align_ungapped_kernel)
 
 // 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
 __device__ __forceinline__ uint64_t load_codes8(const uint8_t *base, long long idx, long long total) {
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
     const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t n_thr = (size_t)gridDim.x * blockDim.x;
     uint32_t chunk_off = 0, chunk_left = 0;
-    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
+    uint32_t st[N_ALIGN_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // < 2^32 per thread by far
     const size_t n_units = PASS == 1 ? a.n_tasks : (size_t)*a.defer_count;
     const size_t rounds = (n_units + n_thr - 1) / n_thr;              // uniform trip count: the allocation is per wave
     // the reference of a task (PASS 2: its index in the list) is fetched a round ahead
@@ -320,18 +333,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             const FixPt f0 = a.geom.fps[ref.fp];
             FixPt f1{0, 0};
             if (kind == 0) f1 = a.geom.fps[ref.fp + 1];
-            tk = build_task(pg, pc, kind, f0, f1);
+            tk = build_task(pg, pc, kind, f0, f1, a.ext_max);
         }
         const int m = tk.m, n = tk.n;
         uint8_t c = 2;
         bool try_fast = false;
         if (live) {
             if (m <= 0 || n <= 0 || held) c = 0;
-            else if ((tk.kind & 3) == 0) { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
+            else if ((tk.kind & 3) == 0) {
+                if (m > BLOCK_MAX || n > BLOCK_MAX) c = CLS_LONG;     // LONG block: no certificate is tried (no shared minimizer over
+                                                                      // more than 256 bases: the sequences differ there)
+                else { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
+            } else if (m > EXT_MAX || a.ext_all_long) c = CLS_LONG;   // (after the certificates of the second pass)
             if (c == 2 && (m < n - tk.dlo ? m : n - tk.dlo) <= WIDE_SHORT) c = 4;      // rows the 64-diagonal kernel really runs
         }
         if (PASS == 1 && live) {                                      // second / third certificate: the other pass
-            const bool defer = c != 0 && a.kmax >= 0 && ((tk.kind & 3) != 0 || m != n);
+            const bool defer = c != 0 && a.kmax >= 0 && ((tk.kind & 3) != 0 || (m != n && c != CLS_LONG));
             a.defer_flag[ti] = defer ? 1 : 0;
             if (defer) { live = false; try_fast = false; }
         }
@@ -705,7 +722,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         // the suffix, so the DP of the block without it followed by T matches is the DP of the block, bit for bit
         // (needs match > 0 and gap costs >= 0, as the certificates; one row is always left).
         int m_dp = m;
-        if (live && !fast && (c == 1 || c == 3) && a.kmax >= 0 && last_x >= 0 && a.trim_ok) {
+        if (live && !fast && (c == 1 || c == 3) && a.kmax >= 0 && last_x >= 0 && a.trim_ok && !a.ungapped) {
             const int mn = m < n ? m : n;
             int T = mn - 1 - last_x;
             T = T < mn - 1 ? T : mn - 1;
@@ -716,6 +733,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             }
         }
         if (live) {
+            if (a.ungapped && c != 0) c = CLS_UNGAPPED;       // (the certificates above hold for the diagonal band as well)
             cls[ti] = bare ? 0 : c;
             if (a.cls_bare) a.cls_bare[ti] = bare ? c : 0;
             if (c != 0) a.tasks[ti] = tk;                      // a DP kernel will want the record
@@ -727,7 +745,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 if (c == 0) ++st[ST_FAST];
                 else {
                     ++st[ST_DP];
-                    if (c == 2 || c == 4) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
+                    if (c == CLS_LONG) { ++st[ST_LONG]; st[ST_BASES_LONG] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
+                    else if (c == 2 || c == 4) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
                     else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m_dp; if (c == 1 && m_dp < NR_SMALL && !bare) ++st[ST_NARROW_SMALL]; }
                 }
             }
@@ -1330,7 +1349,7 @@ __device__ __forceinline__ void wide_rows(const AlignArgs &a, int m, int n, int 
 // reverse, the first `cap` kept in `buf`, with `out` written to out[total-1 .. 0] (left extensions in emission order).
 template <bool TWO>
 __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, int dlo, bool keep_order, uint32_t *out, uint32_t total,
-                              uint32_t *buf, uint32_t cap, uint32_t *ends = nullptr) {
+                              uint32_t *buf, uint32_t cap, uint32_t *ends = nullptr, int max_it = 4 * (EXT_MAX + SEQ_T_MAX)) {
     auto word = [&](int plane, int c, int lane) { return pl[(plane * chunks + c) * 64 + lane]; };
     int i = m0, j = n0, state = 0;                    // state: 0 H, 1 E1, 2 F1, 3 E2, 4 F2
     uint32_t cur_op = 0, cur_len = 0, n_runs = 0, e_first = 0, e_last = 0;
@@ -1341,7 +1360,7 @@ __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, in
         else if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
         ++n_runs;
     };
-    for (int it = 0; (i > 0 || j > 0) && it < 4 * (EXT_MAX + SEQ_T_MAX); ++it) {
+    for (int it = 0; (i > 0 || j > 0) && it < max_it; ++it) {
         uint32_t op, len;
         if (i == 0) {                                          // row 0: H(0,j) is a gap from the corner
             op = OP_D; len = (uint32_t)j; j = 0;
@@ -1503,6 +1522,303 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(TB && ROWS_M
         for (uint32_t k = (uint32_t)lane; k < cp_n; k += 64)     // left extensions keep the emission order
             a.runs[cp_off + k] = rbuf[kind == 1 ? k : cp_n - 1 - k];
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- pass 2c: LONG tasks - blocks of more than BLOCK_MAX rows or columns, extensions of more than EXT_MAX rows ----------------
+// What `minimap2 -c -g10000` buys (script/filter_overlap_slr2.py:51): the gap between two chained anchors is filled whatever
+// its length, and a chain end is extended until a z-drop.  Same recurrences, band (64 diagonals = the wave), tie rules and
+// best-cell rule as align_kernel; what differs is where things live:
+//   * the band walks the task in TILES of LONG_TILE rows: the two sequence windows of a tile are staged in LDS (a few
+//     hundred bytes per wave), H and the gap states of the band's last row stay in registers across tiles;
+//   * the nine traceback planes go to a scratch area of the wave in global memory, one 256-byte line per plane and 32 rows
+//     (9 x 8 bytes per row: a 10 000-row task writes 0.7 MB, re-read by its own walk while still in the caches), the walk's
+//     runs to a second scratch area, from where the whole wave copies them into the run pool;
+//   * an extension stops at a z-drop: after every ZDROP_STEP-th row the row's best in-rectangle cell is held against the best
+//     cell so far (oracle/ava_oracle.c:band_dp);
+//   * tasks are handed out through an atomic counter (their lengths span 256 .. 10 000 rows).
+// TB = false: scores (and the cell an extension stops in) only - tasks of stub candidates.
+constexpr int LONG_TILE = 256;
+constexpr int LT_LEN = LONG_TILE + BAND_W + 8;        // staged target elements: index (row in tile - 1) + lane, + 1 look-ahead
+struct LongArgs {
+    uint32_t *planes;       // per wave: N_WPLANES x chunks_cap x 64 words
+    uint32_t *run_scratch;  // per wave: runs_cap words
+    uint32_t chunks_cap;    // 32-row words per plane and lane one wave's area holds
+    uint32_t runs_cap;
+    int zdrop;              // 0: none
+    uint32_t *next;         // work counter (zeroed before the launch)
+    uint32_t *too_long;     // set when a task does not fit the scratch areas (the host sizes them from the options: never)
+};
+
+template <bool TWO, bool TB>
+__global__ __launch_bounds__(WG) void align_long_kernel(AlignArgs a, LongArgs la) {
+    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][LONG_TILE + 8];
+    __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][LT_LEN];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    uint32_t *const pl = TB ? la.planes + wave * ((size_t)N_WPLANES * la.chunks_cap * 64) : nullptr;
+    uint32_t *const rs = TB ? la.run_scratch + wave * (size_t)la.runs_cap : nullptr;
+    uint8_t *sq = s_q[wv], *st = s_t[wv];
+    uint32_t chunk_off = 0, chunk_left = 0;
+    const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * lane, goel = go + ge * lane;
+    const int go2 = a.go2, ge2 = a.ge2, goe2 = go2 + ge2, gel2 = ge2 * lane, goel2 = go2 + ge2 * lane;
+    for (;;) {
+        uint32_t li = 0;
+        if (lane == 0) li = atomicAdd(la.next, 1u);
+        li = (uint32_t)__builtin_amdgcn_readfirstlane((int)li);
+        if (li >= a.n_list) break;                                // (every wave gets here: the counter only grows)
+        const size_t ti = a.list[li];
+        const Task tk = a.tasks[ti];
+        const int n = tk.n, dlo = tk.dlo;
+        const int m = tk.m < n - dlo ? tk.m : n - dlo;            // rows below have no cell inside the band
+        const int kind = tk.kind & 3;
+        const int chunks = (m + 31) >> 5;
+        if (m <= 0 || n <= 0 || (TB && ((uint32_t)chunks > la.chunks_cap || (uint32_t)(m + n + 2) > la.runs_cap))) {
+            if (lane == 0) {
+                a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
+                if (m > 0 && n > 0) *la.too_long = 1;
+            }
+            continue;
+        }
+        const bool ext = kind != 0, rev = (tk.kind & TASK_REV) != 0, left = kind == 1;
+        const int end_row = ext ? (int)(tk.narrow >> 1) - 1 : -1;
+        const int j0 = dlo + lane;
+        int gap0 = go + ge * j0;
+        if (TWO && go2 + ge2 * j0 < gap0) gap0 = go2 + ge2 * j0;
+        int H = j0 == 0 ? DP_BIAS : (j0 > 0 ? DP_BIAS - gap0 : 0);          // row 0 (biased scores: narrow_rows)
+        int G = H - goe, G2 = TWO ? H - goe2 : 0;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        int best_h = 0, best_i = 0;                                          // biased like H: 0 = no cell yet
+        if (ext && j0 >= 0 && j0 <= n) best_h = H;
+        int rows_done = m;                                                   // a z-drop ends the task earlier
+        bool stop = false;
+        for (int r0 = 0; r0 < m && !stop; r0 += LONG_TILE) {
+            const int R = m - r0 < LONG_TILE ? m - r0 : LONG_TILE;
+            {   // stage the tile: query elements r0 .. r0 + R - 1, target elements eb .. eb + R + 63 (eb = r0 + dlo: the base
+                // of row r0 + 1 in lane 0); elements outside the windows read as the ambiguous code (their cells lie outside
+                // the rectangle)
+                __builtin_amdgcn_wave_barrier();
+                const int xq = r0 + 4 * lane;
+                uint32_t vq = 0x04040404u;
+                if (4 * lane < R) vq = load_window4p(a.qcodes, (long long)tk.qa, left != rev, rev, xq);
+                const int eb = r0 + dlo;
+                uint32_t vt[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int k = 4 * (lane + 64 * r), x = eb + k;
+                    vt[r] = 0x04040404u;
+                    if (k < R + 64 && x + 3 >= 0 && x < n) vt[r] = load_window4p(a.tcodes, (long long)tk.ta, left, false, x);
+                }
+                *(uint32_t *)(sq + 4 * lane) = vq;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int k = 4 * (lane + 64 * r);
+                    if (k < LT_LEN - 3) *(uint32_t *)(st + k) = vt[r];
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint8_t *tp = st + lane;                                   // target base of row r0 + ii: tp[ii - 1]
+            int qa = sq[0], t2 = tp[0];
+            for (int ii = 1; ii <= R; ++ii) {
+                const int i = r0 + ii;
+                const int qa_next = sq[ii], t2_next = tp[ii];
+                const bool ne = qa != t2;
+                int s = ne ? -a.mismatch : a.match;
+                s = (qa | t2) > 3 ? -a.ambi : s;
+                const int mm = H + s;
+                const int f1 = wave_shl1_z(G);
+                const int f2 = TWO ? wave_shl1_z(G2) : 0;
+                const int f = TWO && f2 > f1 ? f2 : f1;
+                const int ht = mm > f ? mm : f;
+                const int e1 = wave_shr1(wave_prefix_max_incl_dpp(ht + gel), 0) - goel;
+                const int e2 = TWO ? wave_shr1(wave_prefix_max_incl_dpp(ht + gel2), 0) - goel2 : 0;
+                const int e = TWO && e2 > e1 ? e2 : e1;
+                const int h = ht > e ? ht : e;
+                const int fo = h - goe, fe = f1 - ge;
+                if (TB) {
+                    a0 = shift_in(a0, mm == h);
+                    a1 = shift_in(a1, e >= f);
+                    a2 = shift_in(a2, e1 + go > h);
+                    a3 = shift_in(a3, fe > fo);
+                    a4 = shift_in(a4, ne);
+                }
+                G = fo > fe ? fo : fe;
+                if (TWO) {
+                    const int fo2 = h - goe2, fe2 = f2 - ge2;
+                    if (TB) {
+                        b0 = shift_in(b0, e2 > e1);
+                        b1 = shift_in(b1, f2 > f1);
+                        b2 = shift_in(b2, e2 + go2 > h);
+                        b3 = shift_in(b3, fe2 > fo2);
+                    }
+                    G2 = fo2 > fe2 ? fo2 : fe2;
+                }
+                H = h;
+                qa = qa_next; t2 = t2_next;
+                const bool inside = (uint32_t)(i + j0) <= (uint32_t)n;       // 0 <= j <= n
+                if (ext) {
+                    const int hb = h + (i == end_row ? a.end_bonus : 0);
+                    if (inside && hb > best_h) { best_h = hb; best_i = i; }
+                }
+                if ((i & 31) == 0) {
+                    if (TB) {
+                        const size_t c = (size_t)(i >> 5) - 1;
+                        pl[((size_t)WP_DIAG * chunks + c) * 64 + lane] = a0; pl[((size_t)WP_EGEF * chunks + c) * 64 + lane] = a1;
+                        pl[((size_t)WP_EX1 * chunks + c) * 64 + lane] = a2; pl[((size_t)WP_FX1 * chunks + c) * 64 + lane] = a3;
+                        pl[((size_t)WP_NE * chunks + c) * 64 + lane] = a4;
+                        if (TWO) {
+                            pl[((size_t)WP_EP * chunks + c) * 64 + lane] = b0; pl[((size_t)WP_FP * chunks + c) * 64 + lane] = b1;
+                            pl[((size_t)WP_EX2 * chunks + c) * 64 + lane] = b2; pl[((size_t)WP_FX2 * chunks + c) * 64 + lane] = b3;
+                        }
+                    }
+                    if (ext && la.zdrop > 0) {                               // z-drop (ZDROP_STEP = 32 = the planes' word)
+                        const int row_max = (int)wave_max_u32_dpp(inside ? (uint32_t)h : 0u);
+                        const int so_far = (int)wave_max_u32_dpp((uint32_t)best_h);
+                        if (row_max == 0 || so_far - row_max > la.zdrop) { rows_done = i; stop = true; break; }
+                    }
+                }
+            }
+        }
+        if (TB && (rows_done & 31)) {                                        // partial word: its first row up to bit 31
+            const size_t c = (size_t)(rows_done >> 5);
+            const int up = 32 - (rows_done & 31);
+            pl[((size_t)WP_DIAG * chunks + c) * 64 + lane] = a0 << up; pl[((size_t)WP_EGEF * chunks + c) * 64 + lane] = a1 << up;
+            pl[((size_t)WP_EX1 * chunks + c) * 64 + lane] = a2 << up; pl[((size_t)WP_FX1 * chunks + c) * 64 + lane] = a3 << up;
+            pl[((size_t)WP_NE * chunks + c) * 64 + lane] = a4 << up;
+            if (TWO) {
+                pl[((size_t)WP_EP * chunks + c) * 64 + lane] = b0 << up; pl[((size_t)WP_FP * chunks + c) * 64 + lane] = b1 << up;
+                pl[((size_t)WP_EX2 * chunks + c) * 64 + lane] = b2 << up; pl[((size_t)WP_FX2 * chunks + c) * 64 + lane] = b3 << up;
+            }
+        }
+        int ei, ej, score;
+        if (!ext) {
+            ei = m; ej = n;
+            score = __shfl(H, n - m - dlo, 64) - DP_BIAS;
+        } else {
+            // best cell: score (with the bonus), then fewest bases i + j, then fewest rows (align_kernel)
+            unsigned long long best = 0;
+            if (best_h > DP_BIAS / 2)
+                best = (unsigned long long)(uint32_t)(best_h - DP_BIAS + (1 << 20)) << 32 |
+                       (unsigned long long)(0xffffu - (uint32_t)(2 * best_i + dlo + lane)) << 16 |
+                       (unsigned long long)(0xffffu - (uint32_t)best_i);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long u = __shfl_xor(best, o, 64);
+                best = u > best ? u : best;
+            }
+            ei = (int)(0xffffu - (uint32_t)(best & 0xffff));
+            ej = (int)(0xffffu - (uint32_t)((best >> 16) & 0xffff)) - ei;
+            score = (int)(uint32_t)(best >> 32) - (1 << 20) - (ei == end_row ? a.end_bonus : 0);   // the bonus only ranks
+        }
+        const uint32_t flag = ext && ei == end_row ? 0x80000000u : 0u;
+        if constexpr (!TB) {
+            if (lane == 0) a.out[ti] = TaskOut{score, ei, ej, 0, 0, flag};
+            continue;
+        } else {
+            __threadfence_block();                                           // the planes of all lanes, before lane 0 reads them
+            __builtin_amdgcn_wave_barrier();
+            uint32_t n_runs = 0, off = 0, ends = 0;
+            bool ok = true;
+            if (lane == 0) {
+                n_runs = wide_walk<TWO>(pl, chunks, ei, ej, dlo, left, nullptr, 0, rs, la.runs_cap, &ends, 2 * (m + n) + 8);
+                if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
+                a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0, ends | flag};
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            n_runs = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_runs);
+            off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+            ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+            if (ok) for (uint32_t k = (uint32_t)lane; k < n_runs; k += 64)      // left extensions keep the emission order
+                a.runs[off + k] = rs[left ? k : n_runs - 1 - k];
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---- pass 2d: ungapped tasks ---------------------------------------------------------------------------------------------
+// bandwidth 0 = `minimap2 -r 0` of the contig-vs-contig call (script/HyLight.py:309): the DP band is the diagonal alone
+// (oracle/ava_oracle.c: W = 1).  A block (square: the chain's links have no diagonal shift) is its diagonal, an extension the
+// best prefix of its diagonal (score + end bonus on the row that reaches the query end, first row on ties, z-drop test every
+// ZDROP_STEP rows).  One lane per task, two passes over the bases (count the runs, then write them); the calls that take this
+// form have 10^3 .. 10^5 rows.
+template <bool TB>
+__global__ __launch_bounds__(WG) void align_ungapped_kernel(AlignArgs a, int zdrop) {
+    const int lane = threadIdx.x & 63;
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, n_thr = (size_t)gridDim.x * blockDim.x;
+    const size_t rounds = (a.n_list + n_thr - 1) / n_thr;             // uniform trip count: the allocation is per wave
+    uint32_t chunk_off = 0, chunk_left = 0;
+    for (size_t r = 0; r < rounds; ++r) {
+        const size_t u = r * n_thr + tid;
+        const bool live = u < a.n_list;
+        size_t ti = 0;
+        Task tk{};
+        if (live) { ti = a.list[u]; tk = a.tasks[ti]; }
+        const int kind = tk.kind & 3;
+        const bool ext = kind != 0, rev = (tk.kind & TASK_REV) != 0, left = kind == 1;
+        const int L = live ? (tk.m < tk.n ? tk.m : tk.n) : 0;
+        const int end_row = ext ? (int)(tk.narrow >> 1) - 1 : -1;
+        auto pair_at = [&](int x, uint64_t &q8, uint64_t &t8) {
+            q8 = load_window8p(a.qcodes, (long long)tk.qa, left != rev, rev, x);
+            t8 = load_window8p(a.tcodes, (long long)tk.ta, left, false, x);
+        };
+        int score = 0, best = 0, best_i = 0, best_s = 0, cur = -1;
+        uint32_t nr = 0, nr_best = 0, first_op = 0, last_op_best = 0;
+        bool stop = false;
+        for (int x = 0; x < L && !stop; x += 8) {
+            uint64_t q8, t8;
+            pair_at(x, q8, t8);
+            const int lim = L - x < 8 ? L - x : 8;
+            for (int y = 0; y < lim; ++y) {
+                const int qc = (int)(q8 >> (8 * y)) & 0xff, tc = (int)(t8 >> (8 * y)) & 0xff, i = x + y + 1;
+                score += (qc | tc) > 3 ? -a.ambi : (qc == tc ? a.match : -a.mismatch);
+                const int op = qc == tc ? (int)OP_EQ : (int)OP_X;
+                if (op != cur) { if (!nr) first_op = (uint32_t)op; ++nr; cur = op; }
+                if (ext) {
+                    const int rank = score + (i == end_row ? a.end_bonus : 0);
+                    if (rank > best) { best = rank; best_i = i; best_s = score; nr_best = nr; last_op_best = (uint32_t)op; }
+                    if (zdrop > 0 && (i & (ZDROP_STEP - 1)) == 0 && best - score > zdrop) { stop = true; break; }
+                }
+            }
+        }
+        const int take = ext ? best_i : L;
+        const int out_score = ext ? best_s : score;
+        uint32_t n_runs = ext ? nr_best : nr, last_op = ext ? last_op_best : (uint32_t)cur;
+        if (!TB || take == 0) n_runs = 0;
+        uint32_t wave_total;
+        const uint32_t mine = wave_excl_sum_u32(n_runs, lane, wave_total);
+        uint32_t base = 0;
+        bool ok = true;
+        if (wave_total) {
+            if (lane == 0) base = pool_take(a, wave_total, chunk_off, chunk_left, ok);
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            ok = __shfl((int)ok, 0, 64) != 0;
+        }
+        if (live && ok && n_runs) {                                   // second pass: the runs of [0, take), in sequence order
+            uint32_t k = 0, len = 0;
+            int op_cur = -1;
+            uint32_t *dst = a.runs + base + mine;
+            auto put = [&]() { dst[left ? n_runs - 1 - k : k] = len << 4 | (uint32_t)op_cur; ++k; };
+            for (int x = 0; x < take; x += 8) {
+                uint64_t q8, t8;
+                pair_at(x, q8, t8);
+                const int lim = take - x < 8 ? take - x : 8;
+                for (int y = 0; y < lim; ++y) {
+                    const int op = ((q8 >> (8 * y)) & 0xff) == ((t8 >> (8 * y)) & 0xff) ? (int)OP_EQ : (int)OP_X;
+                    if (op != op_cur) { if (len) put(); op_cur = op; len = 0; }
+                    ++len;
+                }
+            }
+            if (len) put();
+        }
+        if (live) {
+            // element 0 of a left extension is the base next to the fixed point: sequence order is the reverse
+            const uint32_t ends = n_runs ? (left ? end_codes(last_op, first_op) : end_codes(first_op, last_op)) : 0u;
+            a.out[ti] = TaskOut{out_score, ext ? take : (int)tk.m, ext ? take : (int)tk.n, base + mine, ok ? n_runs : 0,
+                                ends | (ext && take == end_row ? 0x80000000u : 0u)};
+        }
     }
 }
 
@@ -1713,6 +2029,24 @@ __global__ void late_tasks_kernel(const uint32_t *plist, size_t n, const Piece *
     tasks[2 * j + 1] = task_off[i] + pieces[i].n_fp;
 }
 
+// sum of (rows + columns) over the tasks of one DP launch: the algorithmic bytes of that launch (bench.py's roofline table)
+__global__ __launch_bounds__(WG) void list_bases_kernel(const Task *tasks, const uint32_t *list, size_t n, unsigned long long *out) {
+    unsigned long long v = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Task &t = tasks[list[i]];
+        v += (unsigned long long)((int)t.m + (int)t.n);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+// flag[i] = (cls[i] == v): the list of one class outside the four of select_classes4_async
+__global__ void class_flag_kernel(const uint8_t *cls, size_t n, uint8_t v, uint8_t *flag) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = cls[i] == v ? 1 : 0;
+}
+
 __global__ void compact_rows_kernel(const uint32_t *idx, size_t n, const PafRec *recs, const uint64_t *hi,
                                     const uint64_t *lo, PafRec *orecs, uint64_t *ohi, uint64_t *olo) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -1739,7 +2073,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     DBuf<TaskRef> task_ref(NT);
     DBuf<PieceGeom> pgeom(P);
     hipLaunchKernelGGL(task_ref_kernel, dim3((unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
-                       ch.pieces.p, toff.p, P, d_qlen, d_tlen, in.Q->off.p, in.T->off.p, ch.fps.p, o.stub_oh, task_ref.p, pgeom.p);
+                       ch.pieces.p, toff.p, P, d_qlen, d_tlen, in.Q->off.p, in.T->off.p, ch.fps.p, o.stub_oh, ext_rows(o), task_ref.p, pgeom.p);
     HIP_CHECK(hipGetLastError());
     DBuf<TaskOut> tout(NT);
     DBuf<uint32_t> counters(2);
@@ -1773,17 +2107,57 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     // instances of the packed and the 64-diagonal kernel; HLMI_STUB_FULL_ROWS keeps the candidates' CIGARs: test hook)
     const bool bare = o.stub_oh >= 0 && packed && !getenv("HLMI_STUB_FULL_ROWS");
     as.bare = bare ? 1 : 0;
+    // LONG tasks (align_long_kernel).  Sizes of a wave's scratch areas from the options: a chain link spans at most max_gap
+    // bases and an extension ext_rows(o) rows.
+    if (long_rows_cap(o) > 32000) fail(HLMI_EINVAL, "max_gap %d: alignment tasks are limited to 32 000 rows", o.max_gap);
+    // An extension of <= EXT_MAX rows runs in the 64-diagonal kernels, which know no z-drop: it cannot matter there when a
+    // drop of more than zdrop (at most D per row, D = the dearest single step) plus the climb back above the old best cell
+    // (at most `match` per row) need more rows than EXT_MAX - otherwise every extension is a LONG task.
+    bool ext_all_long = false;
+    if (o.zdrop > 0) {
+        const int D = std::max(std::max(o.mismatch, o.ambi), o.gap_open + o.gap_ext);
+        const int rows_down = D > 0 ? (o.zdrop + D - 1) / D : EXT_MAX;
+        ext_all_long = (long long)o.match * (EXT_MAX - rows_down) > o.zdrop;
+    }
+    const uint32_t long_chunks_cap = (uint32_t)(long_rows_cap(o) + 31) / 32, long_runs_cap = (uint32_t)(2 * long_rows_cap(o) + 64);
+    constexpr unsigned LONG_BLOCKS_MAX = 256 * 4;
+    DBuf<uint32_t> long_planes, long_runs, long_ctl(2);
+    DBuf<uint8_t> long_flag;
+    DBuf<uint32_t> long_list, long_n(1);
+    size_t n_long_tb = 0, n_long_bare = 0;
+    // per DP launch: tasks and bases (rows + columns) - "align_n.<timer>", "align_bases.<timer>" of the statistics
+    static const char *const LB_NAMES[] = {"align_narrow_small", "align_narrow", "align_narrow_long", "align_wide", "align_wide_short",
+                                           "align_long", "align_score_narrow", "align_score_narrow_long", "align_score_wide",
+                                           "align_score_wide_short", "align_score_long", "align_ungapped"};
+    constexpr int N_LB = 12;
+    DBuf<unsigned long long> lb_bases(N_LB);
+    std::vector<double> lb_n(N_LB, 0.0);
+    lb_bases.zero();
+    auto note_list = [&](const char *timer, const Task *tk, const uint32_t *lst, size_t n) {
+        if (!n) return;
+        int slot = 0;
+        while (slot < N_LB && strcmp(LB_NAMES[slot], timer) != 0) ++slot;
+        if (slot == N_LB) return;
+        lb_n[slot] += (double)n;
+        hipLaunchKernelGGL(list_bases_kernel, dim3((unsigned)std::min<size_t>(cdiv(n, (size_t)WG), 1024)), dim3(WG), 0, stream(), tk, lst, n,
+                           lb_bases.p + slot);
+    };
     for (int attempt = 0;; ++attempt) {
         const size_t cap_runs = run_share + open_chunks;
         if (cap_runs >= (1ull << 32)) fail(HLMI_ENOMEM, "CIGAR run pool exceeds 4G entries");
         runs.alloc(cap_runs);
         counters.zero();
+        lb_bases.zero();
+        std::fill(lb_n.begin(), lb_n.end(), 0.0);
         AlignArgs aa{};
         aa.tasks = tasks.p; aa.n_tasks = NT;
         aa.geom = TaskGeom{task_ref.p, pgeom.p, ch.fps.p};
         aa.qcodes = in.Q->codes(); aa.tcodes = in.T->codes();
         aa.q_total = (long long)in.Q->total; aa.t_total = (long long)in.T->total;
         aa.end_bonus = o.end_bonus;
+        aa.ext_max = ext_rows(o);
+        aa.ext_all_long = ext_all_long ? 1 : 0;
+        aa.ungapped = o.bandwidth == 0 ? 1 : 0;
         aa.match = o.match; aa.mismatch = o.mismatch; aa.go = o.gap_open; aa.ge = o.gap_ext; aa.ambi = o.ambi;
         aa.go2 = o.gap_open2 > 0 ? o.gap_open2 : 0; aa.ge2 = o.gap_open2 > 0 ? o.gap_ext2 : 0;
         // the 16-diagonal kernels (gaps of at most 15 bases) know the first piece only
@@ -1823,10 +2197,65 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         DBuf<uint32_t> list1(NT), list2(NT), list3(NT), list4(NT);
         DBuf<uint32_t> list_n(4);
         aa.cls_bare = bare ? cls_bare.p : nullptr;
+        // LONG tasks of one class array (cls: with traceback, cls_bare: scores only): list, then align_long_kernel
+        // the tasks of one class outside the four of select_classes4_async -> long_list; returns their number
+        auto class_list = [&](const uint8_t *cls_arr, uint8_t v) -> size_t {
+            if (long_flag.n < NT) { long_flag.alloc(NT); long_list.alloc(NT); }
+            hipLaunchKernelGGL(class_flag_kernel, grid1(NT), dim3(WG), 0, stream(), cls_arr, NT, v, long_flag.p);
+            select_flagged_indices_async(long_flag.p, long_list.p, NT, long_n.p);
+            return (size_t)long_n.download(1)[0];
+        };
+        // bandwidth 0: everything the certificates left over, along the diagonal
+        auto run_ungapped = [&](const uint8_t *cls_arr, bool tb) -> size_t {
+            if (!aa.ungapped) return 0;
+            const size_t nl = class_list(cls_arr, CLS_UNGAPPED);
+            if (!nl) return 0;
+            aa.list = long_list.p; aa.n_list = nl;
+            note_list("align_ungapped", tasks.p, long_list.p, nl);
+            KTimer kt("align_ungapped");
+            const unsigned nb = (unsigned)std::min<size_t>(cdiv(nl, (size_t)WG), MAX_BLOCKS);
+            if (tb) hipLaunchKernelGGL(align_ungapped_kernel<true>, dim3(nb), dim3(WG), 0, stream(), aa, o.zdrop);
+            else hipLaunchKernelGGL(align_ungapped_kernel<false>, dim3(nb), dim3(WG), 0, stream(), aa, o.zdrop);
+            HIP_CHECK(hipGetLastError());
+            return nl;
+        };
+        auto run_long = [&](const uint8_t *cls_arr, bool tb) -> size_t {
+            if (aa.ungapped) return run_ungapped(cls_arr, tb);       // (no LONG class there: every DP task is CLS_UNGAPPED)
+            const size_t nl = class_list(cls_arr, CLS_LONG);
+            if (!nl) return 0;
+            const unsigned nb = (unsigned)std::min<size_t>((nl + WAVES - 1) / WAVES, LONG_BLOCKS_MAX);
+            const size_t n_waves = (size_t)nb * WAVES;
+            LongArgs la{};
+            if (tb) {
+                long_planes.alloc(n_waves * (size_t)N_WPLANES * long_chunks_cap * 64);
+                long_runs.alloc(n_waves * (size_t)long_runs_cap);
+                la.planes = long_planes.p; la.run_scratch = long_runs.p;
+            }
+            la.chunks_cap = long_chunks_cap; la.runs_cap = long_runs_cap; la.zdrop = o.zdrop;
+            long_ctl.zero();
+            la.next = long_ctl.p; la.too_long = long_ctl.p + 1;
+            aa.list = long_list.p; aa.n_list = nl;
+            note_list(tb ? "align_long" : "align_score_long", tasks.p, long_list.p, nl);
+            {
+                KTimer kt(tb ? "align_long" : "align_score_long");
+                const bool two = aa.go2 > 0;
+                if (tb) {
+                    if (two) hipLaunchKernelGGL((align_long_kernel<true, true>), dim3(nb), dim3(WG), 0, stream(), aa, la);
+                    else hipLaunchKernelGGL((align_long_kernel<false, true>), dim3(nb), dim3(WG), 0, stream(), aa, la);
+                } else {
+                    if (two) hipLaunchKernelGGL((align_long_kernel<true, false>), dim3(nb), dim3(WG), 0, stream(), aa, la);
+                    else hipLaunchKernelGGL((align_long_kernel<false, false>), dim3(nb), dim3(WG), 0, stream(), aa, la);
+                }
+            }
+            HIP_CHECK(hipGetLastError());
+            if (long_ctl.download(2)[1]) fail(HLMI_EINVAL, "an alignment task exceeds the scratch area of align_long_kernel");
+            return nl;
+        };
         // the tasks of stub candidates (cls_bare): score-only kernels over their own four lists
         size_t n_bare_tasks = 0;
         auto run_bare = [&]() {
             if (!bare) return;
+            { const size_t nl = run_long(cls_bare.p, false); n_bare_tasks += nl; n_long_bare += nl; }
             select_classes4_async(cls_bare.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
             const std::vector<uint32_t> hb = list_n.download(4);
             n_bare_tasks += (size_t)hb[0] + hb[1] + hb[2] + hb[3];
@@ -1841,21 +2270,25 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             auto pk_grid = [](size_t n) { return dim3((unsigned)std::max<size_t>(1, std::min<size_t>(((n + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32))); };
             auto w_grid = [](size_t n) { return dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + WAVES - 1) / WAVES, 256 * 16))); };
             if (hb[0]) {
+                note_list("align_score_narrow", tasks.p, list1.p, hb[0]);
                 KTimer kt("align_score_narrow");
                 aa.list = list1.p; aa.n_list = hb[0];
                 hipLaunchKernelGGL((align_narrow_pk_kernel<NR_SHORT, false>), pk_grid(hb[0]), dim3(64 * PK_WAVES), 0, stream(), aa);
             }
             if (hb[2]) {
+                note_list("align_score_narrow_long", tasks.p, list3.p, hb[2]);
                 KTimer kt("align_score_narrow_long");
                 aa.list = list3.p; aa.n_list = hb[2];
                 hipLaunchKernelGGL((align_narrow_pk_kernel<BLOCK_MAX, false>), pk_grid(hb[2]), dim3(64 * PK_WAVES), 0, stream(), aa);
             }
             if (hb[1]) {
+                note_list("align_score_wide", tasks.p, list2.p, hb[1]);
                 KTimer kt("align_score_wide");
                 aa.list = list2.p; aa.n_list = hb[1];
                 hipLaunchKernelGGL((align_kernel<EXT_MAX, false>), w_grid(hb[1]), dim3(WG), 0, stream(), aa);
             }
             if (hb[3]) {
+                note_list("align_score_wide_short", tasks.p, list4.p, hb[3]);
                 KTimer kt("align_score_wide_short");
                 aa.list = list4.p; aa.n_list = hb[3];
                 hipLaunchKernelGGL((align_kernel<WIDE_SHORT, false>), w_grid(hb[3]), dim3(WG), 0, stream(), aa);
@@ -1891,18 +2324,21 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             size_t n_small = 0;
             if (n1 >= 8) n_small = std::min<size_t>(n1, (size_t)astats.download(N_ALIGN_STATS)[ST_NARROW_SMALL]);
             if (n_small) {
+                note_list("align_narrow_small", tasks.p, list1.p, n_small);
                 KTimer kt("align_narrow_small");
                 aa.list = list1.p; aa.n_list = n_small;
                 const unsigned nb = (unsigned)std::min<size_t>(((n_small + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
                 hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SMALL>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
             }
             if (n1 > n_small) {
+                note_list("align_narrow", tasks.p, list1.p + n_small, n1 - n_small);
                 KTimer kt("align_narrow");
                 aa.list = list1.p + n_small; aa.n_list = n1 - n_small;
                 const unsigned nb = (unsigned)std::min<size_t>(((aa.n_list + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
                 hipLaunchKernelGGL(align_narrow_pk_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
             }
         } else if (n1) {
+            note_list("align_narrow", tasks.p, list1.p, n1);
             KTimer kt("align_narrow");
             aa.list = list1.p; aa.n_list = n1;
             const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
@@ -1911,11 +2347,13 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         if (n3 && packed && !getenv("HLMI_NARROW_LONG_UNPACKED")) {
             // blocks of more than NR_SHORT rows (divergent reads: C5 has as many of these as of the short ones) in the packed
             // form as well: eight tasks per wave at twice the plane LDS (25 KB per wave) instead of four
+            note_list("align_narrow_long", tasks.p, list3.p, n3);
             KTimer kt("align_narrow_long");
             aa.list = list3.p; aa.n_list = n3;
             const unsigned nb = (unsigned)std::min<size_t>(((n3 + 7) / 8 + PK_WAVES - 1) / PK_WAVES, 256 * 32);
             hipLaunchKernelGGL(align_narrow_pk_kernel<BLOCK_MAX>, dim3(nb ? nb : 1), dim3(64 * PK_WAVES), 0, stream(), aa);
         } else if (n3) {
+            note_list("align_narrow_long", tasks.p, list3.p, n3);
             KTimer kt("align_narrow_long");
             aa.list = list3.p; aa.n_list = n3;
             const unsigned nb = (unsigned)std::min<size_t>(((n3 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
@@ -1924,12 +2362,14 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         // pass 2b: the rest (wide blocks, end extensions) in the 64-diagonal band
         auto run_wide = [&](size_t n_long, size_t n_short) {
             if (n_long) {
+                note_list("align_wide", tasks.p, list2.p, n_long);
                 KTimer kt("align_wide");
                 aa.list = list2.p; aa.n_list = n_long;
                 const unsigned nb = (unsigned)std::min<size_t>((n_long + WAVES - 1) / WAVES, 256 * 16);
                 hipLaunchKernelGGL(align_kernel<EXT_MAX>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
             }
             if (n_short) {
+                note_list("align_wide_short", tasks.p, list4.p, n_short);
                 KTimer kt("align_wide_short");
                 aa.list = list4.p; aa.n_list = n_short;
                 const unsigned nb = (unsigned)std::min<size_t>((n_short + WAVES - 1) / WAVES, 256 * 16);
@@ -1937,6 +2377,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             }
         };
         run_wide(n2, n4);
+        n_long_tb += run_long(cls.p, true);
         run_bare();
         size_t n_wide_late = 0;
         if (o.stub_oh >= 0) {
@@ -1972,7 +2413,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                     select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
                     const std::vector<uint32_t> hl = list_n.download(4);
                     run_wide(hl[1], hl[3]);
-                    n_wide_late = (size_t)hl[1] + hl[3];
+                    const size_t nl = run_long(cls.p, true);
+                    n_long_tb += nl;
+                    n_wide_late = (size_t)hl[1] + hl[3] + nl;
                 }
                 as.plist = late_idx.p; as.n_pieces = n_late;
                 const unsigned nbl = (unsigned)std::min<size_t>(cdiv(n_late, (size_t)WAVES), 256 * 32);
@@ -1987,6 +2430,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         if (attempt == 0) {
             stat_add("align_tasks_narrow", (double)(n1 + n3)); stat_add("align_tasks_wide", (double)(n2 + n4 + (bare ? 0 : n_wide_late)));
             stat_add("align_tasks_score_only", (double)n_bare_tasks);
+            stat_add("align_tasks_long", (double)n_long_tb); stat_add("align_tasks_long_score_only", (double)n_long_bare);
         }
         HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> hc = counters.download(2);
@@ -2004,6 +2448,13 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         stat_add("align_bases_classify", (double)h[ST_BASES_SQUARE]);
         stat_add("align_bases_narrow", (double)h[ST_BASES_NARROW]);
         stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
+        stat_add("align_bases_long", (double)h[ST_BASES_LONG]);
+        const std::vector<unsigned long long> lb = lb_bases.download(N_LB);
+        for (int k = 0; k < N_LB; ++k)
+            if (lb_n[k] > 0) {
+                stat_add(std::string("align_n.") + LB_NAMES[k], lb_n[k]);
+                stat_add(std::string("align_bases.") + LB_NAMES[k], (double)lb[k]);
+            }
         stat_add("align_tasks_wide_one_piece", (double)h[ST_WIDE_ONE]);
         stat_add("align_ext_certified", (double)h[ST_EXT_CERT]);
         stat_add("align_ext_dp_bonus_row_elsewhere", (double)h[ST_EXT_DP_ROW]);

@@ -386,10 +386,12 @@ __global__ void group_hist_kernel(const uint32_t *gstart, size_t n_groups, size_
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
 
-__device__ __forceinline__ bool block_ok(int q0, int t0, int q1, int t1) {
+__device__ __forceinline__ bool block_ok(int q0, int t0, int q1, int t1, int shift_max) {
+    // any length (blocks above BLOCK_MAX rows / columns are LONG blocks of the alignment pass); only the
+    // diagonal shift is bounded - the band has BAND_W diagonals
     int m = q1 - q0, n = t1 - t0, d = n - m;
-    if (m < 0 || n < 0 || m > BLOCK_MAX || n > BLOCK_MAX) return false;
-    return (d < 0 ? -d : d) + 2 * BAND_PAD + 1 <= BAND_W;
+    if (m < 0 || n < 0) return false;
+    return (d < 0 ? -d : d) <= shift_max;       // (SHIFT_MAX; 0 with bandwidth 0: ungapped alignment)
 }
 
 struct ChainArgs {
@@ -408,6 +410,7 @@ struct ChainArgs {
     int *root;                        // chain id of every anchor (index of the chain's start inside the group)
     unsigned long long *peak;         // per chain, at its root: best f << 32 | ~(first index reaching it)
     int k, max_gap, bw, min_score, min_cnt;
+    int shift_max;                    // largest diagonal shift of one alignment block
     int pb, tb, vb;                   // key layout (SeedArgs)
     uint64_t pmask;                   // (1 << pb) - 1
     uint32_t qmask;                   // (1 << qpos bits) - 1
@@ -533,7 +536,7 @@ __device__ bool emit_chain(const ChainArgs &a, size_t b, size_t g_first, long lo
             if (q0 < 0 || t0 < 0) { int sh = q0 < t0 ? -q0 : -t0; q0 += sh; t0 += sh; }
             if (q0 < 0) q0 = 0;
             if (t0 < 0) t0 = 0;
-            if (block_ok(q0, t0, qe, te)) {
+            if (block_ok(q0, t0, qe, te, a.shift_max)) {
                 piece_fp0 = nf;
                 if (wr) { a.fps[fp_base + nf] = FixPt{(uint32_t)q0, (uint32_t)t0}; a.fps[fp_base + nf + 1] = FixPt{(uint32_t)qe, (uint32_t)te}; }
                 nf += 2;
@@ -550,7 +553,7 @@ __device__ bool emit_chain(const ChainArgs &a, size_t b, size_t g_first, long lo
         if (!m) { x = base + 64; continue; }                   // nothing in this window
         const int l = __ffsll((long long)m) - 1;
         const int te = __builtin_amdgcn_readlane(te_l, l), qe = __builtin_amdgcn_readlane(qe_l, l);
-        if (block_ok(cq, ct, qe, te)) {
+        if (block_ok(cq, ct, qe, te, a.shift_max)) {
             const int wend = end - base < 64 ? end - base : 64;
             if (wend - l < 8) {                                // few anchors left in the window: one at a time
                 if (wr) a.fps[fp_base + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
@@ -570,7 +573,7 @@ __device__ bool emit_chain(const ChainArgs &a, size_t b, size_t g_first, long lo
                 }
                 nxt = lo < wend ? lo : 64;
                 const int qn = __shfl(qe_l, nxt & 63, 64), tn = __shfl(te_l, nxt & 63, 64);
-                okm = __ballot(nxt < 64 && block_ok(qe_l, te_l, qn, tn));
+                okm = __ballot(nxt < 64 && block_ok(qe_l, te_l, qn, tn, a.shift_max));
             }
             unsigned long long vis = 0;                        // l and the fixed points that follow it in this window
             int e = l;
@@ -1325,6 +1328,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     DBuf<uint32_t> sbase(A), starts(A);
     ca.sbase = sbase.p; ca.root = root.p; ca.peak = peak.p; ca.starts = starts.p;
     ca.k = o.k; ca.max_gap = o.max_gap; ca.bw = o.bandwidth; ca.min_score = o.min_chain_score; ca.min_cnt = o.min_cnt;
+    ca.shift_max = o.bandwidth == 0 ? 0 : SHIFT_MAX;
     ca.q_lo = (uint32_t)q_lo;
     ca.pb = pb; ca.tb = tb; ca.vb = vb; ca.pmask = (1ull << pb) - 1; ca.qmask = (uint32_t)((1ull << qpb) - 1);
     ca.cap_pieces = (uint32_t)std::min<size_t>(A / 2 + 1024, 0xfffffff0u);

@@ -42,7 +42,8 @@ def spawn_ranks(n, cmd, env_extra=None, poll_s=0.2):
     base = dict(os.environ)
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                 HL_LAUNCHER="self")
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks (RCCL over xGMI)
+    # (HSA_ENABLE_IPC_MODE_LEGACY and the other runtime switches are INHERITED, never set here: a host whose driver only
+    #  supports dmabuf IPC exports HSA_ENABLE_IPC_MODE_LEGACY=0 for RCCL itself - as this pool does - and the ranks see it)
     if env_extra:
         base.update(env_extra)
     procs = []

@@ -116,10 +116,13 @@ typedef struct {
     int stub_oh;           /* >= 0: the rows go to a consumer that drops internal matches with this overhang bound
                               (filter_trans_ovlp_inline_v4.py:52-64 with -oh 3, slr2:51,55).  An alignment piece that is
                               certain to be reported (block score >= min_dp_score + end_bonus) and certain to fail that test
-                              whatever its end extensions find (an end more than 256 + stub_oh query and 320 + stub_oh target
-                              bases inside both sequences) is then reported WITHOUT end extensions: the consumer only counts
-                              it as a line of its 1000-line windows.  < 0: every piece is extended (hlmi_ava's default; the
-                              stage entry points use 3). */
+                              whatever its end extensions find (an end more than X + stub_oh query and X + 64 + stub_oh target
+                              bases inside both sequences, X = max(256, max_gap) = the reach of an end extension) is then
+                              reported WITHOUT end extensions: the consumer only counts it as a line of its 1000-line windows.
+                              < 0: every piece is extended (hlmi_ava's default; the stage entry points use 3). */
+    int zdrop;             /* > 0: an end extension (up to max(256, max_gap) rows) stops at the first of its rows 32, 64, ...
+                              whose best cell lies more than this below the best cell so far: 400 (long: minimap2's -z of the
+                              ava-pb preset); 0: no z-drop (short: extensions stay within 256 rows) */
 } hlmi_ava_opts;
 void hlmi_ava_opts_long(hlmi_ava_opts *o);    /* the constants of slr2:51 (ava-pb -Hk19 -m100 -g10000) */
 void hlmi_ava_opts_short(hlmi_ava_opts *o);   /* the constants of slr2:55 (--sr -k21 -w11 -s60 -m30 -n2 -A4 -B2 --end-bonus=100) */

@@ -16,18 +16,18 @@ class Opts(C.Structure):
                 ("min_mid_occ", C.c_int), ("mid_occ_frac", C.c_double),
                 ("match", C.c_int), ("mismatch", C.c_int), ("gap_open", C.c_int), ("gap_ext", C.c_int),
                 ("ambi", C.c_int), ("min_dp_score", C.c_int), ("end_bonus", C.c_int), ("pair_once", C.c_int),
-                ("gap_open2", C.c_int), ("gap_ext2", C.c_int), ("stub_oh", C.c_int)]
+                ("gap_open2", C.c_int), ("gap_ext2", C.c_int), ("stub_oh", C.c_int), ("zdrop", C.c_int)]
 
 
 def opts_long():
     """The constants of script/filter_overlap_slr2.py:51 (ava-pb -Hk19 -m100 -g10000)."""
-    return Opts(19, 5, 1, 100, 10000, 2000, 3, 10, 2e-4, 2, 4, 4, 2, 1, 80, 0, 1, 24, 1, -1)       # -O4,24 -E2,1 (preset defaults)
+    return Opts(19, 5, 1, 100, 10000, 2000, 3, 10, 2e-4, 2, 4, 4, 2, 1, 80, 0, 1, 24, 1, -1, 400)       # -O4,24 -E2,1 -z400 (preset defaults)
 
 
 def opts_short():
     """The constants of script/filter_overlap_slr2.py:55 (--sr -k21 -w11 -s60 -m30 -n2 -A4 -B2 --end-bonus=100; from the
     --sr preset: -g200 -r50 -O12 -E2 -f1000)."""
-    return Opts(21, 11, 0, 30, 200, 50, 2, 1000, 0.0, 4, 2, 12, 2, 1, 60, 100, 0, 32, 1, -1)     # --sr: -O12,32 -E2,1
+    return Opts(21, 11, 0, 30, 200, 50, 2, 1000, 0.0, 4, 2, 12, 2, 1, 60, 100, 0, 32, 1, -1, 0)     # --sr: -O12,32 -E2,1; extensions stay within 256 rows (max_gap 200): no z-drop
 
 
 _lib = None

@@ -28,40 +28,50 @@ typedef struct {
     int stub_oh;               /* >= 0: the rows go to a consumer that drops internal matches with this overhang bound
                                 * (filter_trans_ovlp_inline_v4.py:64, -oh 3): pieces that are certain to be reported and certain
                                 * to be dropped there are written without their end extensions; < 0: off */
+    int zdrop;                 /* > 0: an end extension stops after a row i (checked at every 32nd row) whose best cell lies more than
+                                * this below the best cell so far - minimap2's -z (400 for the ava-pb preset); 0: no z-drop */
 } ava_opts_t;   /* same layout as hlmi_ava_opts (include/hylight_mi.h) */
 
 /* ---- fixed constants of the spec -------------------------------------------- */
 #define CHAIN_PRED   64      /* predecessors examined per anchor                            */
 #define BLOCK_MIN    32      /* min distance between alignment fixed points                 */
-#define BLOCK_MAX    256     /* max rows / cols of one alignment block                      */
+#define BLOCK_MAX    256     /* rows / cols up to which a block takes the band rule below; longer blocks: LONG blocks */
 #define BAND_W       64      /* diagonals per block                                         */
 #define BAND_PAD     12      /* padding around [min(0,delta), max(0,delta)]                 */
 #define NARROW_W     16      /* blocks with |delta| <= NARROW_DELTA use a 16-diagonal band  */
 #define NARROW_PAD   5
 #define NARROW_DELTA 5
-#define EXT_MAX      256     /* max rows of an end extension                                */
+#define EXT_MAX      256     /* rows of an end extension: max(EXT_MAX, max_gap) (ext_rows())   */
+#define ZDROP_STEP   32      /* the z-drop test runs after rows 32, 64, ...                 */
 #define MAX_MID_OCC  1000000
 #define NEG_INF      (-(1 << 29))
 
-/* MEASUREMENT switches (tests/test_deviation_effects.py only; the specification is the defaults): how many final rows do
- * the bounded blocks and extensions change on divergent reads?  minimap2 fills gaps between anchors and extends chain
- * ends with a band derived from -r and stops at a z-drop; the specification bounds both so that a task fits LDS.
- *   ORACLE_BLOCK_MAX   rows / cols of one alignment block (256)
- *   ORACLE_SHIFT_MAX   diagonal shift of one block (BAND_W - 2 BAND_PAD - 1 = 39); wider blocks get a band of shift + 2 pad + 1
- *   ORACLE_EXT_MAX     rows of an end extension (256)
+/* Blocks and extensions.  minimap2 -c -g10000 fills the gap between two chained anchors whatever its
+ * length and extends chain ends until a z-drop or max_gap bases; so does the specification:
+ *   - a block may have any number of rows / columns (a chain link spans at most max_gap); only a diagonal shift above
+ *     BAND_W - 2 BAND_PAD - 1 = 39 between two fixed points still splits a chain into two pieces (the band has 64 diagonals);
+ *     blocks with more than BLOCK_MAX rows or columns (LONG blocks) take a band of 64 diagonals centred on the two corners;
+ *   - an end extension runs over up to max(EXT_MAX, max_gap) rows and stops at a z-drop (ava_opts_t::zdrop).
+ * MEASUREMENT switches (tests/test_deviation_effects.py only; the specification is the defaults):
+ *   ORACLE_BLOCK_MAX   rows / cols above which a block splits its chain (none; 256 = the specification up to round 3)
+ *   ORACLE_SHIFT_MAX   diagonal shift of one block (39); wider blocks get a band of shift + 2 pad + 1
+ *   ORACLE_EXT_MAX     rows of an end extension (max(256, max_gap); 256 = the specification up to round 3)
  *   ORACLE_EXT_BAND    diagonals of an end extension (64)
  */
-static int g_block_max = BLOCK_MAX, g_shift_max = BAND_W - 2 * BAND_PAD - 1, g_ext_max = EXT_MAX, g_ext_band = BAND_W;
+static int g_block_max = 1 << 30, g_shift_max = BAND_W - 2 * BAND_PAD - 1, g_ext_max = 0, g_ext_band = BAND_W;
 static int g_chain_mm2;
+static int g_ungapped;       /* bandwidth == 0 (minimap2 -r 0, script/HyLight.py:309): the DP band is the diagonal alone */
 static long g_n_pieces, g_n_stubs;      /* pieces reported / of them as stubs (oracle_last_counts; atomic adds) */
 static void read_switches(void) {
     const char *e;
-    g_block_max = (e = getenv("ORACLE_BLOCK_MAX")) ? atoi(e) : BLOCK_MAX;
+    g_block_max = (e = getenv("ORACLE_BLOCK_MAX")) ? atoi(e) : 1 << 30;
     g_shift_max = (e = getenv("ORACLE_SHIFT_MAX")) ? atoi(e) : BAND_W - 2 * BAND_PAD - 1;
-    g_ext_max = (e = getenv("ORACLE_EXT_MAX")) ? atoi(e) : EXT_MAX;
+    g_ext_max = (e = getenv("ORACLE_EXT_MAX")) ? atoi(e) : 0;
     g_ext_band = (e = getenv("ORACLE_EXT_BAND")) ? atoi(e) : BAND_W;
     g_chain_mm2 = getenv("ORACLE_CHAIN_MM2") ? 1 : 0;
 }
+/* rows an end extension may run over */
+static int ext_rows(const ava_opts_t *o) { return g_ext_max > 0 ? g_ext_max : (o->max_gap > EXT_MAX ? o->max_gap : EXT_MAX); }
 
 /* ---- sequences ---------------------------------------------------------------------------- */
 typedef struct {
@@ -334,15 +344,28 @@ static __thread int g_last_rank;
  * second piece. */
 static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, const uint8_t *t, int tstride, int n,
                    int dlo, int W, int mode, int end_row, int *bi, int *bj, uint32_t *rev_ops, int *n_rev) {
+    /* z-drop (extensions): after row i = 32, 64, ... the best cell of that row is held against the best cell so far; more
+     * than zdrop below it (or no cell of the row inside the rectangle any more) ends the extension: rows > i do not exist */
+    const int zdrop = mode == 1 ? o->zdrop : 0;
     const int two = o->gap_open2 > 0;
     const int go[2] = {o->gap_open, two ? o->gap_open2 : o->gap_open}, ge[2] = {o->gap_ext, two ? o->gap_ext2 : o->gap_ext};
     int rows = m + 1;
-    uint8_t *tb = (uint8_t *)malloc((size_t)rows * W);
-    int32_t *H = (int32_t *)malloc((size_t)rows * W * 4);
-    int32_t *E[2], *F[2];
-    for (int p = 0; p < 2; ++p) { E[p] = (int32_t *)malloc((size_t)rows * W * 4); F[p] = (int32_t *)malloc((size_t)rows * W * 4); }
+    /* the matrices live in one buffer per thread that only grows: a malloc per call is an mmap + munmap for every block of
+     * more than a few rows, and with many OpenMP threads those serialise in the kernel */
+    static __thread int32_t *arena;
+    static __thread size_t arena_cells;
+    const size_t cells = (size_t)rows * W;
+    if (cells > arena_cells) {
+        free(arena);
+        arena_cells = cells + cells / 2 + 4096;
+        arena = (int32_t *)malloc(arena_cells * 21 + 64);
+    }
+    int32_t *H = arena, *E[2], *F[2];
+    E[0] = H + cells; E[1] = E[0] + cells; F[0] = E[1] + cells; F[1] = F[0] + cells;
+    uint8_t *tb = (uint8_t *)(F[1] + cells);
     int best = NEG_INF, best_i = 0, best_j = 0, best_h = NEG_INF;   /* best: score + end bonus (ranking), best_h: score */
-    for (int i = 0; i <= m; ++i)
+    for (int i = 0; i <= m; ++i) {
+        int row_max = NEG_INF;
         for (int dd = 0; dd < W; ++dd) {
             int j = i + dlo + dd, idx = i * W + dd;
             int h = NEG_INF, e[2] = {NEG_INF, NEG_INF}, f[2] = {NEG_INF, NEG_INF};
@@ -375,6 +398,7 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
                     else { h = fb; b |= 2; }
                     if (h < NEG_INF) h = NEG_INF;
                 }
+                if (h > row_max) row_max = h;
                 if (mode == 1 && h > NEG_INF) {
                     int hb = h + (i == end_row ? o->end_bonus : 0);   /* reaching the query end earns the bonus */
                     if (hb > best || (hb == best && (i + j < best_i + best_j || (i + j == best_i + best_j && i < best_i)))) {
@@ -385,6 +409,8 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
             H[idx] = h; tb[idx] = b;
             for (int p = 0; p < 2; ++p) { E[p][idx] = e[p]; F[p][idx] = f[p]; }
         }
+        if (zdrop > 0 && i > 0 && i % ZDROP_STEP == 0 && (row_max == NEG_INF || best - row_max > zdrop)) break;
+    }
     int ei, ej, score;
     if (mode == 0) { ei = m; ej = n; score = H[m * W + (n - m - dlo)]; }
     else { ei = best_i; ej = best_j; score = best_h; }
@@ -414,8 +440,6 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
     g_last_rank = mode == 1 ? best : score;   /* extension: score + end bonus of the chosen cell */
     if (bi) *bi = ei;
     if (bj) *bj = ej;
-    free(tb); free(H);
-    for (int p = 0; p < 2; ++p) { free(E[p]); free(F[p]); }
     return score;
 }
 
@@ -429,20 +453,25 @@ typedef struct {
 static int block_ok(int q0, int t0, int q1, int t1) {
     int m = q1 - q0, n = t1 - t0, delta = n - m;
     if (m < 0 || n < 0 || m > g_block_max || n > g_block_max) return 0;
-    if ((delta < 0 ? -delta : delta) > g_shift_max) return 0;
+    if ((delta < 0 ? -delta : delta) > (g_ungapped ? 0 : g_shift_max)) return 0;
     return 1;
 }
 
 static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, int q0, int t0, int q1, int t1,
-                        piece_t *p, uint32_t *scratch) {
+                        piece_t *p) {
     int m = q1 - q0, n = t1 - t0, delta = n - m, nr;
+    uint32_t *scratch = (uint32_t *)malloc((size_t)(m + n + 2) * 4);
     /* band rule: near-diagonal blocks get the narrow band, the rest the wide one */
-    int narrow = (delta < 0 ? -delta : delta) <= NARROW_DELTA;
+    const int ad = delta < 0 ? -delta : delta;
+    const int lng = m > BLOCK_MAX || n > BLOCK_MAX;              /* LONG block: 64 diagonals centred on the corners' diagonals */
+    int narrow = !lng && ad <= NARROW_DELTA;
     int W = narrow ? NARROW_W : BAND_W;
-    if (!narrow && (delta < 0 ? -delta : delta) + 2 * BAND_PAD + 1 > W) W = (delta < 0 ? -delta : delta) + 2 * BAND_PAD + 1;   /* measurement only */
-    int dlo = (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : BAND_PAD);
+    if (!narrow && ad + 2 * BAND_PAD + 1 > W) W = ad + 2 * BAND_PAD + 1;   /* measurement only */
+    int dlo = (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : lng ? (W - 1 - ad) / 2 : BAND_PAD);
+    if (g_ungapped) { W = 1; dlo = 0; }                          /* (delta == 0: block_ok) the diagonal is the band */
     p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, W, 0, -1, 0, 0, scratch, &nr);
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
+    free(scratch);
 }
 
 /* one chain (anchors ascending) -> alignment pieces -> PAF rows */
@@ -471,35 +500,41 @@ static void emit_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi
     p->score = 0;
 }
 
-static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, piece_t *p, uint32_t *scratch) {
-    int m = p->qs < g_ext_max ? p->qs : g_ext_max, n = p->ts < g_ext_max + g_ext_band ? p->ts : g_ext_max + g_ext_band, bi, bj, nr;
+static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, piece_t *p) {
+    const int xm = ext_rows(o);
+    int m = p->qs < xm ? p->qs : xm, n = p->ts < xm + g_ext_band ? p->ts : xm + g_ext_band, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, -(g_ext_band / 2 - 1), g_ext_band, 1, p->qs <= g_ext_max ? p->qs : -1,
-                     &bi, &bj, scratch, &nr);
-    if (g_last_rank <= 0 || nr == 0) return;   /* nothing gained (the end bonus counts here, not in the score) */
+    uint32_t *scratch = (uint32_t *)malloc((size_t)(m + n + 2) * 4);
+    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, g_ungapped ? 0 : -(g_ext_band / 2 - 1), g_ungapped ? 1 : g_ext_band, 1,
+                     p->qs <= xm ? p->qs : -1, &bi, &bj, scratch, &nr);
+    if (g_last_rank <= 0 || nr == 0) { free(scratch); return; }   /* nothing gained (the end bonus counts here, not in the score) */
     /* rev_ops run from the far end towards the fixed point on reversed sequences = forward order */
     cigar_t pre = {0, 0, 0};
     for (int x = 0; x < nr; ++x) cig_push(&pre, (int)scratch[x], 1);
     for (int x = 0; x < p->cg.n; ++x) cig_push(&pre, (int)(p->cg.op[x] & 15), (int)(p->cg.op[x] >> 4));
     free(p->cg.op);
+    free(scratch);
     p->cg = pre;
     p->qs -= bi; p->ts -= bj; p->score += sc;
 }
 
-static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const uint8_t *t, int tl, piece_t *p,
-                         uint32_t *scratch) {
-    int m = ql - p->qe < g_ext_max ? ql - p->qe : g_ext_max;
-    int n = tl - p->te < g_ext_max + g_ext_band ? tl - p->te : g_ext_max + g_ext_band, bi, bj, nr;
+static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const uint8_t *t, int tl, piece_t *p) {
+    const int xm = ext_rows(o);
+    int m = ql - p->qe < xm ? ql - p->qe : xm;
+    int n = tl - p->te < xm + g_ext_band ? tl - p->te : xm + g_ext_band, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
-    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, -(g_ext_band / 2 - 1), g_ext_band, 1, ql - p->qe <= g_ext_max ? ql - p->qe : -1,
-                     &bi, &bj, scratch, &nr);
-    if (g_last_rank <= 0 || nr == 0) return;   /* nothing gained (the end bonus counts here, not in the score) */
-    for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
-    p->qe += bi; p->te += bj; p->score += sc;
+    uint32_t *scratch = (uint32_t *)malloc((size_t)(m + n + 2) * 4);
+    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, g_ungapped ? 0 : -(g_ext_band / 2 - 1), g_ungapped ? 1 : g_ext_band, 1,
+                     ql - p->qe <= xm ? ql - p->qe : -1, &bi, &bj, scratch, &nr);
+    if (g_last_rank > 0 && nr != 0) {          /* (else nothing gained: the end bonus counts here, not in the score) */
+        for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
+        p->qe += bi; p->te += bj; p->score += sc;
+    }
+    free(scratch);
 }
 
-/* Stub rule (ava_opts_t::stub_oh = h >= 0).  An end extension moves a piece end by at most EXT_MAX query and
- * EXT_MAX + BAND_W target bases.  A piece whose left end has qs > EXT_MAX + h and ts > EXT_MAX + BAND_W + h (or the same on
+/* Stub rule (ava_opts_t::stub_oh = h >= 0).  An end extension moves a piece end by at most X = ext_rows() query and
+ * X + BAND_W target bases.  A piece whose left end has qs > X + h and ts > X + BAND_W + h (or the same on
  * its right end, measured from the sequence ends) therefore keeps an overhang > h whatever the extensions find, and the
  * consumer's test `overhang > min(h, 0.8 maplen)` drops the row before it touches any state.  The row still counts as a
  * line of the consumer's 1000-line windows, so it has to be written exactly when the full specification writes it:
@@ -511,9 +546,9 @@ static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const ui
  * CIGAR "*"; the consumer's first test drops a row of length 0 without a division).  The product therefore computes only the
  * SCORES of a candidate's blocks and extensions. */
 static int is_stub_candidate(const ava_opts_t *o, const piece_t *p, int ql, int tl) {
-    if (o->stub_oh < 0 || g_ext_max != EXT_MAX || g_ext_band != BAND_W) return 0;
-    const int h = o->stub_oh;
-    return (p->qs > EXT_MAX + h && p->ts > EXT_MAX + BAND_W + h) || (ql - p->qe > EXT_MAX + h && tl - p->te > EXT_MAX + BAND_W + h);
+    if (o->stub_oh < 0 || g_ext_band != BAND_W) return 0;
+    const int h = o->stub_oh, X = ext_rows(o);
+    return (p->qs > X + h && p->ts > X + BAND_W + h) || (ql - p->qe > X + h && tl - p->te > X + BAND_W + h);
 }
 static int is_stub(const ava_opts_t *o, const piece_t *p, int ql, int tl) {
     const int bonus = o->end_bonus > 0 ? o->end_bonus : 0;
@@ -522,13 +557,13 @@ static int is_stub(const ava_opts_t *o, const piece_t *p, int ql, int tl) {
 }
 
 static void close_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa, const seqset_t *T, int ti,
-                        int strand, piece_t *p, uint32_t *scratch) {
+                        int strand, piece_t *p) {
     const int ql = Q->len[qi], tl = T->len[ti];
     const int cand = is_stub_candidate(o, p, ql, tl);      /* (on the unextended piece, as the stub test itself) */
     const int stub = is_stub(o, p, ql, tl);
     if (!stub) {
-        extend_left(o, qa, T->code[ti], p, scratch);
-        extend_right(o, qa, ql, T->code[ti], tl, p, scratch);
+        extend_left(o, qa, T->code[ti], p);
+        extend_right(o, qa, ql, T->code[ti], tl, p);
     }
     if (p->cg.n && p->score >= o->min_dp_score) {
         __atomic_fetch_add(&g_n_pieces, 1, __ATOMIC_RELAXED);
@@ -540,7 +575,6 @@ static void close_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
 static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi, const uint8_t *qa /* aligned orientation */,
                         const seqset_t *T, int ti, int strand, const anchor_t *a, const int *chain, int m) {
     const uint8_t *t = T->code[ti];
-    uint32_t *scratch = (uint32_t *)malloc((size_t)(2 * (g_ext_max + g_block_max) + 2 * (g_ext_band + g_shift_max + BAND_W) + 8) * 4);
     piece_t p;
     memset(&p, 0, sizeof p);
     int open = 0, cq = 0, ct = 0;   /* current fixed point */
@@ -555,28 +589,27 @@ static void align_chain(FILE *out, const ava_opts_t *o, const seqset_t *Q, int q
             if (t0 < 0) t0 = 0;
             if (!block_ok(q0, t0, qe, te)) continue;
             p.qs = q0; p.ts = t0; p.score = 0; p.cg.n = 0;
-            align_block(o, qa, t, q0, t0, qe, te, &p, scratch);
+            align_block(o, qa, t, q0, t0, qe, te, &p);
             cq = qe; ct = te; open = 1;
             continue;
         }
         if (!((qe - cq >= BLOCK_MIN && te - ct >= BLOCK_MIN) || x == m - 1)) continue;
         if (qe <= cq || te <= ct) continue;
         if (block_ok(cq, ct, qe, te)) {
-            align_block(o, qa, t, cq, ct, qe, te, &p, scratch);
+            align_block(o, qa, t, cq, ct, qe, te, &p);
             cq = qe; ct = te;
         } else {        /* split: close the piece here, reopen at this anchor */
             p.qe = cq; p.te = ct;
-            close_piece(out, o, Q, qi, qa, T, ti, strand, &p, scratch);
+            close_piece(out, o, Q, qi, qa, T, ti, strand, &p);
             open = 0;
             --x;        /* revisit this anchor as the start of a new piece */
         }
     }
     if (open) {
         p.qe = cq; p.te = ct;
-        close_piece(out, o, Q, qi, qa, T, ti, strand, &p, scratch);
+        close_piece(out, o, Q, qi, qa, T, ti, strand, &p);
     }
     free(p.cg.op);
-    free(scratch);
 }
 
 /* ---- S4: chaining of one (target, strand) group ------------------------------------------------ */
@@ -671,6 +704,7 @@ int oracle_ava(const char *target_fa, const char *query_fa, const ava_opts_t *o,
     if (!(o->k & 1) || o->k > 28 || o->w < 1 || o->w > 64) { seqset_free(T); seqset_free(Q); return -1; }
     assign_ranks(T, Q);
     read_switches();
+    g_ungapped = o->bandwidth == 0;
     g_n_pieces = g_n_stubs = 0;
     FILE *out = fopen(out_paf, "w");
     if (!out) { seqset_free(T); seqset_free(Q); return -2; }

@@ -5,8 +5,8 @@ test states how many candidate rows of the sample a deviation changes, so the li
   * fixed window of 64 predecessors  vs  minimap2's predecessor loop (up to 5000 iterations, --max-chain-skip 25)
   * one-piece vs two-piece gap cost (now implemented: -O4,24 -E2,1)
 
-  * bounded alignment blocks (256 x 256, diagonal shift 39) and end extensions (256 rows, 64 diagonals) vs wide ones, on a
-    sample of C5 - the divergent workload where the bounds bite (ORACLE_BLOCK_MAX / _SHIFT_MAX / _EXT_MAX / _EXT_BAND)
+  * the bound on the diagonal shift of one alignment block (39) - and, for the record, the round-3 bounds on block length
+    and extension rows that are gone - on a sample of C5, the divergent workload (ORACLE_BLOCK_MAX / _SHIFT_MAX / _EXT_MAX)
   * the stub rule (hlmi_ava_opts::stub_oh): no final row may change
 
 Sample: 6 target reads (one piece of an --nsplit chunk) x the first 2500 reads of C2 as queries; for C5 4 target reads x
@@ -128,27 +128,30 @@ def _run5(q, t, out, env=None, stub=-1):
 
 def test_c5_bounded_blocks_and_extensions(c5_sample):
     """minimap2 fills the gap between two chained anchors whatever its length (band from -r) and extends chain ends until a
-    z-drop; the specification cuts a chain into pieces at gaps above 256 bases or diagonal shifts above 39 and extends piece
-    ends by at most 256 rows.  Measured here: candidate rows and the stage's final rows (C5's constants and the main call's
-    len_over 6000) under the specification, with blocks up to 2048 / shift 500, with extensions up to 1024 rows x 128
-    diagonals.  The numbers for the larger sample quoted in DESIGN.md section 5 come from the same code."""
+    z-drop.  Up to round 3 the specification cut a chain into pieces at gaps above 256 bases and extended piece ends by at
+    most 256 rows; now blocks have any length and extensions run up to max_gap rows or a z-drop - what is left is the
+    bound on the diagonal SHIFT of one block (39: the band has 64 diagonals).  Measured here on a sample of C5 (divergent
+    reads): candidate rows and the stage's final rows (C5's constants) under the specification, under the round-3 bounds,
+    and with a shift bound of 2000 (= minimap2's -r for this preset) - the remaining bound changes nothing on this input."""
     from oracle import filters as F
     d, q, t, stage = c5_sample
     runs = {"spec": {},
-            "blocks<=2048": dict(ORACLE_BLOCK_MAX="2048", ORACLE_SHIFT_MAX="500"),
-            "ext<=1024": dict(ORACLE_EXT_MAX="1024", ORACLE_EXT_BAND="128")}
+            "round-3 bounds": dict(ORACLE_BLOCK_MAX="256", ORACLE_EXT_MAX="256"),
+            "blocks<=256 only": dict(ORACLE_BLOCK_MAX="256"),
+            "shift<=2000": dict(ORACLE_SHIFT_MAX="2000")}
     res = {}
     for tag, env in runs.items():
-        rows, pieces, _ = _run5(q, t, str(d / (tag.replace("<=", "") + ".paf")), env)
+        rows, pieces, _ = _run5(q, t, str(d / (tag.replace("<=", "").replace(" ", "_") + ".paf")), env)
         final = F.worker(rows, True, stage["len_over"], stage["mc"], stage["iden"])
         res[tag] = (rows, final)
         print(f"C5 sample, {tag}: candidate rows {len(rows)}, final rows (len_over {stage['len_over']}) {len(final)}")
-    spec_rows, spec_final = res["spec"]
-    assert len(spec_rows) > 1000
-    # the chains are cut into several pieces each: wide blocks give a fraction of the rows
-    assert len(res["blocks<=2048"][0]) < 0.6 * len(spec_rows)
-    # longer extensions do not change how many pieces there are
-    assert abs(len(res["ext<=1024"][0]) - len(spec_rows)) <= 0.02 * len(spec_rows)
+    spec_rows, _ = res["spec"]
+    assert len(spec_rows) > 300
+    # the round-3 bounds cut the chains into several pieces each
+    assert len(res["round-3 bounds"][0]) > 2 * len(spec_rows)
+    assert len(res["blocks<=256 only"][0]) == len(res["round-3 bounds"][0])          # (the cuts come from the blocks)
+    # the bound that is left does not bite here: the same rows
+    assert res["shift<=2000"][0] == spec_rows
 
 
 def test_c5_stub_rule_changes_no_final_row(c5_sample):
@@ -157,12 +160,19 @@ def test_c5_stub_rule_changes_no_final_row(c5_sample):
     full, pieces, stubs0 = _run5(q, t, str(d / "full.paf"))
     stub, pieces2, stubs = _run5(q, t, str(d / "stub.paf"), stub=3)
     print(f"C5 sample: {pieces} pieces reported, {stubs} of them without end extensions under the stub rule")
-    assert pieces == pieces2 == len(full) == len(stub) and stubs0 == 0 and stubs > 0.5 * pieces
+    assert pieces == pieces2 == len(full) == len(stub) and stubs0 == 0
     for len_over in (stage["len_over"], 6000):
         assert F.worker(stub, True, len_over, stage["mc"], stage["iden"]) == F.worker(full, True, len_over, stage["mc"], stage["iden"])
     # the window filter sees the same lines in the same places: equal survivors of v4 itself
     v4 = lambda rows: F.window_filter(rows, variant=4, min_len=30, min_iden=0.6, min_o=3)
     assert v4(stub) == v4(full)
+    # with the reach of the round-3 extensions (256 rows) most pieces of these cut-up chains are stubs: the rule holds there too
+    env = dict(ORACLE_BLOCK_MAX="256", ORACLE_EXT_MAX="256")
+    full3, p3, _ = _run5(q, t, str(d / "full3.paf"), env)
+    stub3, p3b, stubs3 = _run5(q, t, str(d / "stub3.paf"), env, stub=3)
+    assert p3 == p3b and stubs3 > 0.5 * p3
+    assert F.worker(stub3, True, stage["len_over"], stage["mc"], stage["iden"]) == F.worker(full3, True, stage["len_over"], stage["mc"], stage["iden"])
+    assert v4(stub3) == v4(full3)
 
 
 def test_extend_con_against_minimap2_when_one_is_installed(tmp_path):
