@@ -63,6 +63,7 @@ void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_pool_trim();            // give every cached block back to the driver
 size_t dev_available_bytes();    // free on the card + cached in the pool (0: unknown)
+size_t dev_peak_bytes(bool reset);   // high-water mark of the bytes in use through dev_alloc since the last reset
 
 // ------------------------------------------------------------------------------------------
 // device buffer (RAII)

@@ -109,6 +109,8 @@ namespace {
 std::multimap<size_t, void *> g_free_blocks;            // size -> block
 std::unordered_map<void *, size_t> g_block_size;         // every live or cached block
 size_t g_pooled_bytes = 0;
+size_t g_owned_bytes = 0;                                // every block in g_block_size (in use or cached)
+size_t g_peak_in_use = 0;                                // high-water mark of owned - cached (dev_peak_bytes)
 constexpr size_t POOL_CAP = 160ull << 30;                // keep at most this much cached (288 GB HBM)
 constexpr size_t GRAN = 2ull << 20;
 }  // namespace
@@ -135,6 +137,7 @@ void *dev_alloc(size_t bytes) {
         void *p = it->second;
         g_pooled_bytes -= it->first;
         g_free_blocks.erase(it);
+        g_peak_in_use = std::max(g_peak_in_use, g_owned_bytes - g_pooled_bytes);
         return p;
     }
     // a miss: make room first when the card is nearly full - cached blocks go, largest first, until the request fits (a failed
@@ -149,6 +152,7 @@ void *dev_alloc(size_t bytes) {
                 (void)hipFree(big->second);
                 g_block_size.erase(big->second);
                 g_pooled_bytes -= big->first;
+                g_owned_bytes -= big->first;
                 free_b += big->first;
                 g_free_blocks.erase(big);
             }
@@ -164,7 +168,16 @@ void *dev_alloc(size_t bytes) {
     }
     if (e != hipSuccess) fail(HLMI_ENOMEM, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
     g_block_size[p] = want;
+    g_owned_bytes += want;
+    g_peak_in_use = std::max(g_peak_in_use, g_owned_bytes - g_pooled_bytes);
     return p;
+}
+
+// high-water mark of the device memory in use through dev_alloc since the last reset (the stage reports it per run)
+size_t dev_peak_bytes(bool reset) {
+    const size_t v = g_peak_in_use;
+    if (reset) g_peak_in_use = g_owned_bytes - g_pooled_bytes;
+    return v;
 }
 
 size_t dev_available_bytes() {           // free on the card + cached here: what a run can still take
@@ -178,6 +191,7 @@ void dev_free(void *p) {
     if (it == g_block_size.end()) { (void)hipFree(p); return; }
     if (g_pooled_bytes + it->second > POOL_CAP) {
         (void)hipFree(p);
+        g_owned_bytes -= it->second;
         g_block_size.erase(it);
         return;
     }
@@ -189,6 +203,7 @@ void dev_pool_trim() {
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     for (auto &kv : g_free_blocks) {
         (void)hipFree(kv.second);
+        g_owned_bytes -= kv.first;
         g_block_size.erase(kv.second);
     }
     g_free_blocks.clear();

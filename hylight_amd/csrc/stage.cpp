@@ -173,6 +173,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     if (!m.d_qmz && m.Q.size()) fail(HLMI_ESTATE, "hlmi_job_run before a query sketch was installed");
     ktimer_discard();            // timers of earlier calls (sketching) do not belong to this pass
     stat_reset();
+    (void)dev_peak_bytes(true);  // the high-water mark of this pass starts from what is resident now (reads, sketch)
     const double t0 = now_s();
     struct ExitStamp { double t0; ~ExitStamp() { stat_set("t_with_cleanup_s", now_s() - t0); } } exit_stamp{t0};   // runs after the locals are gone
     // ---- this rank's chunks, in sub-runs ----------------------------------------------------------------------
@@ -357,6 +358,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     stat_set("t_format_sort_write_s", now_s() - t3);
     ktimer_flush();
     stat_set("t_total_s", now_s() - t0);
+    stat_set("hbm_peak_in_use_gb", (double)dev_peak_bytes(false) / 1e9);      // reads + sketch + the largest sub-run
 
     // the counts SURVEY.md 8d's byte formula is evaluated on (bench.py: roofline.stage)
     stat_set("bases_q", (double)m.n_bases_q);

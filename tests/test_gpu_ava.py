@@ -147,7 +147,7 @@ def test_ava_noisy_reads(tmp_path, seed, errs):
     api.ava(fa, fa, tmp_path / "g.paf")
     OA.ava(fa, fa, tmp_path / "o.paf")
     want = open(tmp_path / "o.paf").read()
-    assert len(want.splitlines()) > 20
+    assert len(want.splitlines()) > 10          # (whole overlaps: long gaps between anchors no longer cut the chains)
     assert open(tmp_path / "g.paf").read() == want
     st = api.last_stats()
     assert st["align_tasks_dp"] > 0.3 * st["align_tasks"]

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_line_has_every_contracted_field(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--workload", "C2", "--scale", "0.1"],
-                       env=dict(env, HL_BENCH_DIR=str(tmp_path)), capture_output=True, text=True, timeout=900)
+                       env=dict(env, HL_BENCH_DIR=str(tmp_path), HL_CPU_BUDGET_S="20"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1                                   # ONE JSON line
@@ -34,4 +34,8 @@ def test_bench_line_has_every_contracted_field(tmp_path):
     for k in ("value", "unit", "cores", "kind", "sample", "candidate_rows_per_s"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["candidate_rows_per_s"] > 0
+    # whole --nsplit chunks, and the GPU's rows for the first of them held against the oracle's inside the bench leg
+    assert cb["chunks"] and "WHOLE" in cb["sample"]
+    if cb["kind"] == "port":
+        assert cb["parity"]["gpu_rows_identical"] is True and cb["parity"]["gpu_worker_identical"] is True
     assert d["graph_build_s"] is not None and d["graph_rows_in"] > 0

@@ -35,7 +35,8 @@ def test_divergent_pass_is_deterministic_and_shardable(div):
     api.split_reads2(fa, fa, 30, d, again, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
     st = api.last_stats()
     assert st["align_tasks_dp"] > 0.4 * st["align_tasks"] and st["rows_after_v4"] > 20_000
-    assert ref.count("\n") > 20               # (the mutation filter of pass 2 leaves few pairs of this mix)
+    assert ref.count("\n") >= 3              # (whole-overlap rows: the support filter of pass 2 finds nearly every mismatch of these
+                                             #  reads supported and leaves a handful of pairs - 20-odd when the rows were fragments)
     assert open(again).read() == ref
     parts = []
     for rank in range(3):

@@ -1,18 +1,16 @@
 """GPU: BASELINE.json configs[4] (C5) and configs[3] (C4, long reads) at their FULL size - 500 000 reads on 50 strains x 2 Mb
 with --min_identity 0.90 --min_ovlp_len 1500, and 1 000 000 long reads on 100 strains x 2 Mb - each through the entry point
 a rank of the multi-GPU job uses (hlmi_job_run).  The complete read set is resident in HBM and sketched (all 5 / 10 Gbases
-are queries of every chunk); of the --nsplit target chunks the test runs as many as fit its time budget: one of C5's 60
-(the reference's unit of work, utils.py:54: one worker per chunk; 1/7.5 of one rank's share of an 8-rank job), four of
-C4's 1000 (1/31 of a rank's share).  The pair-once rule (strcmp(qname, tname) < 0) makes a chunk's work proportional to
-the rank of its targets' names: chunk 40 of C5 (reads r333k..r341k) sits in the middle.  A whole C5 pass is ~60 of these,
-i.e. ~2.5 minutes on one card.  The read sets are made by the block-parallel simulator
+are queries of every chunk).  Round 4: C5 as a COMPLETE pass (all 60 chunks; and as two rank shares whose merge equals it),
+C4's long reads as the share one rank of an 8-rank job computes (125 of the 1 000 chunks) - row predicates, rows == sum of
+the slices, no refused sub-run, the HBM high-water mark of the pass.  The read sets are made by the block-parallel simulator
 (hylight_amd/simulate.py:simulate_reads_to_fasta) in seconds."""
 import os
 import time
 
 import pytest
 
-from fullsize import check_rows
+from fullsize import check_rows, same_file
 from hylight_amd import api
 from hylight_amd import workloads as W
 from hylight_amd.stage import StageRunner
@@ -33,7 +31,14 @@ def _free_gb(path):
     return st.f_bavail * st.f_frsize / 2**30
 
 
-def test_c5_full_size_one_chunk(tmp_path):
+def _slice_rows(path):
+    with open(path) as f:
+        return sum(1 for _ in f)
+
+
+def test_c5_full_size_complete_pass(tmp_path):
+    """A COMPLETE pass over C5: all 60 --nsplit chunks x all 500 000 queries in one hlmi_job_run (the stage cuts it into
+    sub-runs by itself), then again as two rank shares (chunks c % 2) whose merged output must be the same file."""
     if _free_gb(tmp_path) < 12 or _host_gb() < 24:
         pytest.skip("needs 12 GB of scratch space and 24 GB of host memory")
     cfg = W.config("C5")
@@ -47,28 +52,40 @@ def test_c5_full_size_one_chunk(tmp_path):
     try:
         t_open = time.time() - t0
         assert r.job.num_queries == 500_000 and r.job.num_chunks == 60
-        out = str(tmp_path / "chunk40.paf")
+        out = str(tmp_path / "pass.paf")
         t0 = time.time()
         r.prepare()
         t_sketch = time.time() - t0
         t0 = time.time()
-        rows = r.run(out, share=(40, 60), **cfg["stage"])          # chunk c belongs to slice c % 60: exactly chunk 40
+        rows = r.run(out, share=(0, 1), **cfg["stage"])            # every chunk
         t_run = time.time() - t0
         st = api.last_stats()
+        print(f"C5 full size: simulate {t_sim:.1f} s, parse + upload {t_open:.1f} s, sketch of 5 Gbases {t_sketch:.2f} s, COMPLETE pass (60 chunks) "
+              f"{t_run:.1f} s -> {rows} overlaps; anchors {st['anchors']:.3g}, candidate rows {st['ava_rows']:.3g}, LONG tasks "
+              f"{st.get('align_tasks_long', 0):.3g}, sub-runs {st['subruns']:.0f} (refused {st.get('subruns_refused', 0):.0f}), "
+              f"HBM high-water mark {st['hbm_peak_in_use_gb']:.0f} GB", flush=True)
+        assert st["queries"] == 500_000 and st["chunks_run"] == 60 and st["targets"] == 500_000
+        assert st["minimizers_q"] > 1.2e9 and st["anchors"] > 1e11 and st["ava_rows"] > 1e8
+        assert st.get("subruns_refused", 0) == 0 and 0 < st["hbm_peak_in_use_gb"] < 288
+        assert rows == _slice_rows(out) == st["rows_out"]
+        check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 100)
+        # the same pass as the shares of a 2-rank job: rows == sum of the slices, merged file == the pass's file
+        parts = []
+        for k in range(2):
+            part = str(tmp_path / f"pass.part{k}")
+            r.run(part, share=(k, 2), **cfg["stage"])
+            parts.append(part)
+        assert sum(_slice_rows(p) for p in parts) == rows
+        api.merge_scored_paf(parts, str(tmp_path / "merged.paf"))
+        assert same_file(str(tmp_path / "merged.paf"), out)
     finally:
         r.close()
     os.remove(fa)
-    print(f"C5 full size: simulate {t_sim:.1f} s, parse + upload {t_open:.1f} s, sketch of 5 Gbases {t_sketch:.2f} s, one of 60 chunks "
-          f"{t_run:.1f} s -> {rows} overlaps; anchors {st['anchors']:.3g}, candidate rows {st['ava_rows']:.3g}, "
-          f"held-back end extensions {st['align_ext_held']:.3g} (run after all: {st['align_ext_late']:.3g})")
-    assert st["queries"] == 500_000 and st["chunks_run"] == 1 and 8_000 < st["targets"] < 8_700
-    assert st["minimizers_q"] > 1.2e9 and st["anchors"] > 2e9 and st["ava_rows"] > 3e7 and st["align_ext_held"] > st["ava_rows"]
-    assert rows == sum(1 for _ in open(out)) == st["rows_out"]
-    check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 20)
-    assert t_run < 120
 
 
-def test_c4_full_size_long_reads_four_chunks(tmp_path):
+def test_c4_full_size_long_reads_one_rank_share(tmp_path):
+    """configs[3]'s long reads at full size, the share ONE RANK of an 8-rank job computes: 125 of the 1 000 chunks (c % 8 == 3)
+    against all 1 000 000 queries."""
     if _free_gb(tmp_path) < 24 or _host_gb() < 48:
         pytest.skip("needs 24 GB of scratch space and 48 GB of host memory")
     cfg = W.config("C4")
@@ -87,20 +104,22 @@ def test_c4_full_size_long_reads_four_chunks(tmp_path):
         r.prepare()                                                # 10 Gbases: sketched in parts of 3 Gbases (csrc/stage.cpp)
         t_sketch = time.time() - t0
         t0 = time.time()
-        rows = r.run(out, share=(5, 250), **cfg["stage"])          # chunks 5, 255, 505, 755
+        rows = r.run(out, share=(3, 8), **cfg["stage"])
         t_run = time.time() - t0
         st = api.last_stats()
     finally:
         r.close()
     os.remove(fa)
-    print(f"C4 full size (long reads): simulate {t_sim:.1f} s, parse + upload {t_open:.1f} s, sketch of 10 Gbases {t_sketch:.2f} s, four of "
-          f"1000 chunks {t_run:.1f} s -> {rows} overlaps; anchors {st['anchors']:.3g}, candidate rows {st['ava_rows']:.3g}")
-    assert st["queries"] == 1_000_000 and st["chunks_run"] == 4 and 3_900 < st["targets"] < 4_100
-    assert st["anchors"] > 5e9 and st["minimizers_q"] > 2e9 and st["ava_rows"] > 1e7
-    assert rows == sum(1 for _ in open(out)) == st["rows_out"]
-    # (at 5 000x pooled depth the mc = 2 support filter leaves next to nothing of four chunks' 1.9e7 candidate rows)
+    print(f"C4 full size (long reads): simulate {t_sim:.1f} s, parse + upload {t_open:.1f} s, sketch of 10 Gbases {t_sketch:.2f} s, one rank's "
+          f"share ({st['chunks_run']:.0f} of 1000 chunks) {t_run:.1f} s -> {rows} overlaps; anchors {st['anchors']:.3g}, "
+          f"candidate rows {st['ava_rows']:.3g}, sub-runs {st['subruns']:.0f} (refused {st.get('subruns_refused', 0):.0f}), HBM high-water mark "
+          f"{st['hbm_peak_in_use_gb']:.0f} GB", flush=True)
+    assert st["queries"] == 1_000_000 and 120 <= st["chunks_run"] <= 125 and 120_000 < st["targets"] < 126_000
+    assert st["anchors"] > 1e11 and st["minimizers_q"] > 2e9 and st["ava_rows"] > 2e8
+    assert st.get("subruns_refused", 0) == 0 and 0 < st["hbm_peak_in_use_gb"] < 288
+    assert rows == _slice_rows(out) == st["rows_out"]
+    # (at 5 000x pooled depth the mc = 2 support filter leaves next to nothing of the candidate rows)
     check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 0)
-    assert t_run < 240
 
 
 def test_c4_full_size_short_reads_one_rank_share(tmp_path):

@@ -64,6 +64,32 @@ def test_snp_pileup_and_support(golden, mode):
         assert {f"{a}:{b}": v for (a, b), v in mut.items()} == g[f"mutation_mc{mc}"]
 
 
+@pytest.mark.parametrize("mode", ["long", "short"])
+def test_numpy_pair_counts_equal_the_definition(golden, mode):
+    """pair_counts_np (what worker() uses on full-size chunks) against the reference's own mutation counts and against the
+    per-event definition: the golden rows, and simulated all-vs-all rows with real CIGARs (truth_paf of the simulator)."""
+    long_mode = mode == "long"
+    g = json.loads(golden.text(f"fxA_snp_{mode}.json"))
+    rows = golden.lines("fxA_v4_sorted.paf")
+    for mc in (2, 3):
+        mut = F.pair_counts_np(rows, long_mode, mc)
+        assert mut is not None and {f"{a}:{b}": v for (a, b), v in mut.items()} == g[f"mutation_mc{mc}"]
+    from hylight_amd import simulate as S
+    reads, _ = S.simulate_reads(seed=91, n_strains=3, genome_len=25_000, n_reads=220, mean_len=4_000, min_len=1_500, max_len=9_000,
+                                snp_rate=0.02, err_sub=0.01, err_ins=0.004, err_del=0.004, keep_gpos=True)
+    sim = F.sort_intermediate(S.truth_paf(reads, pair_once=long_mode))
+    assert len(sim) > 2_000
+    for mc in (2, 3):
+        snp, partners, intervals = F.snp_pileup(sim, long_mode)
+        want = dict(F.supported_pair_counts(snp, partners, intervals, mc))
+        assert len(want) > 100 and F.pair_counts_np(sim, long_mode, mc) == want
+    # rows the numpy form refuses go the definitional way inside worker(): a CIGAR it does not know, an interval without extent
+    assert F.pair_counts_np(["a\t100\t0\t50\t+\tb\t100\t0\t50\t50\t50\t0\tcg:Z:25=1B24="], True, 2) is None
+    assert F.pair_counts_np(["a\t100\t0\t50\t+\tb\t100\t7\t7\t50\t50\t0\tcg:Z:50="], True, 2) is None
+    assert F.worker(golden.lines("fxA_ava.paf"), long_mode, 1000 if long_mode else 70, 2, 0.95, fast=False) == \
+        F.worker(golden.lines("fxA_ava.paf"), long_mode, 1000 if long_mode else 70, 2, 0.95, fast=True)
+
+
 def test_x_digit_sum(golden):
     for k, v in json.loads(golden.text("sum_before_X.json")).items():
         assert F.x_digit_sum(k) == v
