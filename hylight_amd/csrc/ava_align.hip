@@ -1410,6 +1410,76 @@ __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, in
     return n_runs;
 }
 
+// The same walk over planes in GLOBAL memory (align_long_kernel's scratch area): the nine words an iteration can need are
+// requested together - one round trip to the caches per event instead of two or three dependent ones.  Runs in emission
+// order into buf (cap entries).
+template <bool TWO>
+__device__ uint32_t long_walk(const uint32_t *pl, int chunks, int m0, int n0, int dlo, bool keep_order, uint32_t *buf, uint32_t cap,
+                              uint32_t *ends, int max_it) {
+    auto word = [&](int plane, int c, int lane) { return pl[((size_t)plane * chunks + c) * 64 + lane]; };
+    int i = m0, j = n0, state = 0;                    // state: 0 H, 1 E1, 2 F1, 3 E2, 4 F2
+    uint32_t cur_op = 0, cur_len = 0, n_runs = 0, e_first = 0, e_last = 0;
+    auto put = [&]() {
+        if (!n_runs) e_first = cur_op;
+        e_last = cur_op;
+        if (n_runs < cap) buf[n_runs] = cur_len << 4 | cur_op;
+        ++n_runs;
+    };
+    for (int it = 0; (i > 0 || j > 0) && it < max_it; ++it) {
+        uint32_t op, len;
+        if (i == 0) {                                          // row 0: H(0,j) is a gap from the corner
+            op = OP_D; len = (uint32_t)j; j = 0;
+        } else {
+            const int d = (j - i - dlo) & (BAND_W - 1);
+            const int c = (i - 1) >> 5, sh = 31 - ((i - 1) & 31);
+            const int i2 = i > 1 ? i - 2 : 0, c2 = i2 >> 5, sh2 = 31 - (i2 & 31);
+            const int dl = (d - 1) & 63, dr = (d + 1) & 63;
+            const uint32_t w_dg = word(WP_DIAG, c, d), w_ne = word(WP_NE, c, d), w_eg = word(WP_EGEF, c, d);
+            const uint32_t w_ep = TWO ? word(WP_EP, c, d) : 0u, w_fp = TWO ? word(WP_FP, c, d) : 0u;
+            const uint32_t w_ex1 = word(WP_EX1, c, dl), w_ex2 = TWO ? word(WP_EX2, c, dl) : 0u;
+            const uint32_t w_fx1 = word(WP_FX1, c2, dr), w_fx2 = TWO ? word(WP_FX2, c2, dr) : 0u;
+            int st = state;
+            if (st == 0) {
+                const uint32_t dg = w_dg >> sh;
+                if (dg & 1u) st = 0;
+                else if ((w_eg >> sh) & 1u) st = TWO && ((w_ep >> sh) & 1u) ? 3 : 1;
+                else st = TWO && ((w_fp >> sh) & 1u) ? 4 : 2;
+                if (st == 0) {
+                    const uint32_t ne = w_ne >> sh;
+                    const uint32_t inv = ~dg;
+                    const int r = inv ? __ffs((int)inv) - 1 : 32;                 // diagonal moves in a row (this word)
+                    const bool isx = (ne & 1u) != 0;
+                    const uint32_t flip = isx ? ~ne : ne;
+                    int l = flip ? __ffs((int)flip) - 1 : 32;
+                    l = l < r ? l : r;
+                    op = isx ? OP_X : OP_EQ; len = (uint32_t)l;
+                    i -= l; j -= l;
+                    state = 0;
+                    if (op == cur_op) cur_len += len;
+                    else { if (cur_len) put(); cur_op = op; cur_len = len; }
+                    continue;
+                }
+            }
+            if (st == 1 || st == 3) {                          // E_p of this cell extends the E_p of the cell to the left
+                const uint32_t ex = (st == 1 ? w_ex1 : w_ex2) >> sh;
+                op = OP_D; len = 1;
+                state = (ex & 1u) ? st : 0;
+                --j;
+            } else {                                           // F_p of this cell extends the F_p of the cell above
+                const uint32_t fx = (st == 2 ? w_fx1 : w_fx2) >> sh2;
+                op = OP_I; len = 1;
+                state = (i > 1 && (fx & 1u)) ? st : 0;
+                --i;
+            }
+        }
+        if (op == cur_op) cur_len += len;
+        else { if (cur_len) put(); cur_op = op; cur_len = len; }
+    }
+    if (cur_len) put();
+    if (ends) *ends = keep_order ? end_codes(e_first, e_last) : end_codes(e_last, e_first);
+    return n_runs;
+}
+
 // TB = false: scores (and, for extensions, the cell they stop in) only: tasks of stub candidates
 template <int ROWS_MAX, bool TB = true>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(TB && ROWS_MAX <= 128 ? 4 : 1, 8))) void align_kernel(AlignArgs a) {
@@ -1721,7 +1791,7 @@ __global__ __launch_bounds__(WG) void align_long_kernel(AlignArgs a, LongArgs la
             uint32_t n_runs = 0, off = 0, ends = 0;
             bool ok = true;
             if (lane == 0) {
-                n_runs = wide_walk<TWO>(pl, chunks, ei, ej, dlo, left, nullptr, 0, rs, la.runs_cap, &ends, 2 * (m + n) + 8);
+                n_runs = long_walk<TWO>(pl, chunks, ei, ej, dlo, left, rs, la.runs_cap, &ends, 2 * (m + n) + 8);
                 if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
                 a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0, ends | flag};
             }
@@ -2120,7 +2190,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         ext_all_long = (long long)o.match * (EXT_MAX - rows_down) > o.zdrop;
     }
     const uint32_t long_chunks_cap = (uint32_t)(long_rows_cap(o) + 31) / 32, long_runs_cap = (uint32_t)(2 * long_rows_cap(o) + 64);
-    constexpr unsigned LONG_BLOCKS_MAX = 256 * 4;
+    constexpr unsigned LONG_BLOCKS_MAX = 256 * 8;     // 8 workgroups of 4 waves per CU: the walks of the tasks wait on memory
     DBuf<uint32_t> long_planes, long_runs, long_ctl(2);
     DBuf<uint8_t> long_flag;
     DBuf<uint32_t> long_list, long_n(1);

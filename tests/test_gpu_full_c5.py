@@ -40,7 +40,12 @@ def test_c5_is_dp_bound_and_rows_are_valid(c5):
     # the gaps of more than 256 bases between chained anchors (divergent strains) are LONG blocks now, not cuts of the chain:
     # every overlap is one row, with its CIGAR (round 3: fragments, most of them stub candidates with score-only tasks)
     assert st["align_tasks_long"] > 1e6 and st["align_tasks_long"] > 0.02 * st["ava_rows"]
-    check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 500)
+    # With whole-overlap rows in the pile-up every sequencing error of a read (1 % substitutions in C5's recipe) is an X against
+    # all its partners, i.e. a SUPPORTED key (slr2:370-405), and the pair rate test of pass 2 (> 0.0025, slr2:90-96) drops the
+    # pairs: the reference's filter is made for corrected reads, C5's final output is (nearly) empty - the work is in the
+    # candidate rows.  (Rounds 1-3 kept ~500 rows here: fragments whose partners' fragments never met in the pile-up.)
+    assert st["rows_after_v4"] > 1e5 and st["snp_events"] > 1e8
+    check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 0)
     assert rows == sum(1 for _ in open(out))
 
 
