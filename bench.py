@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--scale", type=float, default=None,
                     help="shrink reads and genomes together (quick checks; not a bench line).  Default 1, C4s: 0.1")
     ap.add_argument("--slices", type=int, default=0, help="slices of the --nsplit chunks per pass (0: workload default)")
+    ap.add_argument("--slice0", type=int, default=0, help="slice the first step takes (steps walk on from there; under the pair-once "
+                    "rule a chunk's work grows with its index: the middle of the file is the mean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -323,7 +325,9 @@ def main():
         return out_paf if shares == 1 else f"{out_paf}.slice{k}"
 
     def step(i):
-        if i % shares == 0:                 # a new pass over the read set: sketch + exchange are part of it
+        new_pass = i % shares == 0 or i == 0
+        i += args.slice0
+        if new_pass:                        # a new pass over the read set: sketch + exchange are part of it
             t = time.time()
             for rn, _ in runners:
                 rn.prepare(force=True)

@@ -157,7 +157,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         plan_seeds(in, ix, plan);
     }
     size_t anchor_batch = ANCHOR_BATCH;
-    if (const char *e = getenv("HLMI_ANCHOR_BATCH_M")) anchor_batch = (size_t)std::max(1, atoi(e)) << 20;   // tuning hook
+    if (const char *e = hook("HLMI_ANCHOR_BATCH_M")) anchor_batch = (size_t)std::max(1, atoi(e)) << 20;   // tuning hook
     // batches of equal anchor counts (not full ones and a remainder: the last launches of a step would be small ones),
     // and no more queries than keep the anchor a single 64-bit word (seed_and_chain: "fits")
     uint64_t total_anchors = 0;
@@ -182,7 +182,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         const int spare = 64 - (bits_for(nT > 1 ? nT - 1 : 1) + 1 + bits_for(max_tlen) + bits_for(std::max<uint64_t>(ql[k98], 1)) + 8);
         // (never below 8192: a batch of many short reads rather takes the wider anchor form than ends early)
         size_t q_floor = 8192;
-        if (const char *e = getenv("HLMI_QCAP_MIN")) q_floor = (size_t)std::max(1, atoi(e));      // tuning hook
+        if (const char *e = hook("HLMI_QCAP_MIN")) q_floor = (size_t)std::max(1, atoi(e));      // tuning hook
         // (when even q_floor queries do not fit the one-word form, the batch takes the word + small-key form anyway - the
         //  (target, strand) bits travel apart - and only its own widths bound the batch: on the full C4, 4 000 targets per
         //  sub-run, batches of 8 192 queries held a third of the anchors a batch is sized for)

@@ -17,6 +17,7 @@
 // oracle/ava_oracle.c:band_dp.  VALU bound by nature: reads ~1 B per
 // DP row per sequence from HBM.
 #include <algorithm>
+#include <memory>
 #include <type_traits>
 
 #include "ava_internal.h"
@@ -344,7 +345,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 if (m > BLOCK_MAX || n > BLOCK_MAX) c = CLS_LONG;     // LONG block: no certificate is tried (no shared minimizer over
                                                                       // more than 256 bases: the sequences differ there)
                 else { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
-            } else if (m > EXT_MAX || a.ext_all_long) c = CLS_LONG;   // (after the certificates of the second pass)
+            } else if ((m < n - tk.dlo ? m : n - tk.dlo) > EXT_MAX || a.ext_all_long) c = CLS_LONG;
+            // (an extension's rows end where its band leaves the target: min(m, n - dlo) - a dovetail's extension into the
+            //  few bases the shorter side has left is a short task whatever the other side's length; LONG after the
+            //  certificates of the second pass)
             if (c == 2 && (m < n - tk.dlo ? m : n - tk.dlo) <= WIDE_SHORT) c = 4;      // rows the 64-diagonal kernel really runs
         }
         if (PASS == 1 && live) {                                      // second / third certificate: the other pass
@@ -775,6 +779,15 @@ __global__ void task_rows_key_kernel(const Task *tasks, const uint32_t *list, si
     if (i < n) key[i] = (uint32_t)tasks[list[i]].m >> 2;
 }
 
+
+// sort key of the LONG task list: rows the task really runs, descending
+__global__ void task_rows_desc_key_kernel(const Task *tasks, const uint32_t *list, size_t n, uint32_t *key) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Task &t = tasks[list[i]];
+    const int rows = (int)t.m < (int)t.n - (int)t.dlo ? (int)t.m : (int)t.n - (int)t.dlo;
+    key[i] = 0xffffu - (uint32_t)(rows < 0 ? 0 : rows);
+}
 
 // ---- pass 2a: DP of near-diagonal blocks, FOUR tasks per wave (one per row of 16 lanes) --------------------------
 // Same recurrences and tie rules as align_kernel with W = 16; every cross-lane step is a DPP row operation, so
@@ -2099,16 +2112,36 @@ __global__ void late_tasks_kernel(const uint32_t *plist, size_t n, const Piece *
     tasks[2 * j + 1] = task_off[i] + pieces[i].n_fp;
 }
 
-// sum of (rows + columns) over the tasks of one DP launch: the algorithmic bytes of that launch (bench.py's roofline table)
-__global__ __launch_bounds__(WG) void list_bases_kernel(const Task *tasks, const uint32_t *list, size_t n, unsigned long long *out) {
-    unsigned long long v = 0;
+// (rows + columns) of the DP tasks per kernel that runs them, after a classification pass: the algorithmic bytes of the DP
+// launches (bench.py's roofline table).  Slots: LB_NAMES in align_span.
+__global__ __launch_bounds__(WG) void class_bases_kernel(const uint8_t *cls, const uint8_t *cls_bare, const Task *tasks, size_t n,
+                                                          unsigned long long *out) {
+    __shared__ unsigned long long s_sum[12];
+    if (threadIdx.x < 12) s_sum[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = cls[i], cb = cls_bare ? cls_bare[i] : 0;
+        if (!c && !cb) continue;
+        const Task &t = tasks[i];
+        int slot;
+        if (c) slot = c == 1 ? ((int)t.m < NR_SMALL ? 0 : 1) : c == 3 ? 2 : c == 2 ? 3 : c == 4 ? 4 : c == CLS_LONG ? 5 : 11;
+        else slot = cb == 1 ? 6 : cb == 3 ? 7 : cb == 2 ? 8 : cb == 4 ? 9 : cb == CLS_LONG ? 10 : 11;
+        atomicAdd(&s_sum[slot], (unsigned long long)((int)t.m + (int)t.n));
+    }
+    __syncthreads();
+    if (threadIdx.x < 12 && s_sum[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_sum[threadIdx.x]);
+}
+
+// LONG task list: how many of the tasks are end extensions, and their rows (statistics: align_long_ext / align_long_ext_rows)
+__global__ __launch_bounds__(WG) void list_ext_kernel(const Task *tasks, const uint32_t *list, size_t n, unsigned long long *out) {
+    unsigned long long c = 0, r = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const Task &t = tasks[list[i]];
-        v += (unsigned long long)((int)t.m + (int)t.n);
+        if (t.kind & 3) { ++c; r += (unsigned long long)(int)t.m; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); }
+    if ((threadIdx.x & 63) == 0 && c) { atomicAdd(out, c); atomicAdd(out + 1, r); }
 }
 
 // flag[i] = (cls[i] == v): the list of one class outside the four of select_classes4_async
@@ -2163,7 +2196,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     as.qlen = d_qlen; as.tlen = d_tlen; as.rank_q = in.d_rank_q; as.rank_t = in.d_rank_t; as.chunk_of_t = in.d_chunk_of_t;
     as.pg = pgeom.p; as.stub_score = o.min_dp_score + std::max(0, o.end_bonus);
     as.stage_cap = (uint32_t)ASM_STAGE;
-    if (const char *e = getenv("HLMI_ASM_STAGE_CAP")) as.stage_cap = (uint32_t)std::min(ASM_STAGE, std::max(0, atoi(e)));
+    if (const char *e = hook("HLMI_ASM_STAGE_CAP")) as.stage_cap = (uint32_t)std::min(ASM_STAGE, std::max(0, atoi(e)));
     DBuf<uint32_t> nops(P);
     DBuf<uint8_t> valid(P), late(o.stub_oh >= 0 ? P : 0);
     DBuf<uint32_t> late_idx(o.stub_oh >= 0 ? P : 0);
@@ -2172,10 +2205,10 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     // packed form of the near-diagonal DP (two tasks per lane, 16-bit scores): block scores must stay within +-4096 of the bias
     const int worst = std::max(std::max(o.match, o.mismatch), std::max(o.ambi, o.gap_open + o.gap_ext));
     const bool packed = worst > 0 && (long long)worst * (BLOCK_MAX + NARROW_W + 2) <= 4000 && o.match >= 0 && o.mismatch >= 0 &&
-                        o.ambi >= 0 && o.gap_open >= 0 && o.gap_ext >= 0 && !getenv("HLMI_NARROW_UNPACKED");
+                        o.ambi >= 0 && o.gap_open >= 0 && o.gap_ext >= 0 && !hook("HLMI_NARROW_UNPACKED");
     // stub rule, second half: nobody reads the content of a stub candidate's row, so its tasks report scores only (score-only
     // instances of the packed and the 64-diagonal kernel; HLMI_STUB_FULL_ROWS keeps the candidates' CIGARs: test hook)
-    const bool bare = o.stub_oh >= 0 && packed && !getenv("HLMI_STUB_FULL_ROWS");
+    const bool bare = o.stub_oh >= 0 && packed && !hook("HLMI_STUB_FULL_ROWS");
     as.bare = bare ? 1 : 0;
     // LONG tasks (align_long_kernel).  Sizes of a wave's scratch areas from the options: a chain link spans at most max_gap
     // bases and an extension ext_rows(o) rows.
@@ -2191,7 +2224,23 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     }
     const uint32_t long_chunks_cap = (uint32_t)(long_rows_cap(o) + 31) / 32, long_runs_cap = (uint32_t)(2 * long_rows_cap(o) + 64);
     constexpr unsigned LONG_BLOCKS_MAX = 256 * 8;     // 8 workgroups of 4 waves per CU: the walks of the tasks wait on memory
-    DBuf<uint32_t> long_planes, long_runs, long_ctl(2);
+    // The LONG tasks of a batch are few (C3: ~10 000 per batch) and serial in their rows: alone on the card their launch lasts as
+    // long as its longest task.  They run on the side stream beside the batch's other DP kernels; every launch keeps its own
+    // list / scratch / control words until the streams are joined (join_long) in front of whatever reads the task results.
+    struct LongLaunch { DBuf<uint32_t> list, planes, runs, ctl; };
+    std::vector<std::unique_ptr<LongLaunch>> long_launches;
+    hipEvent_t long_done = nullptr;
+    bool long_pending = false;
+    struct SideGuard {                                   // an exception on the way out must not free buffers the side stream still uses
+        ~SideGuard() { (void)hipStreamSynchronize(side_stream()); }
+    } side_guard;
+    auto join_long = [&]() {
+        if (!long_pending) return;
+        if (!long_done) HIP_CHECK(hipEventCreateWithFlags(&long_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(long_done, side_stream()));
+        HIP_CHECK(hipStreamWaitEvent(stream(), long_done, 0));
+        long_pending = false;
+    };
     DBuf<uint8_t> long_flag;
     DBuf<uint32_t> long_list, long_n(1);
     size_t n_long_tb = 0, n_long_bare = 0;
@@ -2200,7 +2249,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                                            "align_long", "align_score_narrow", "align_score_narrow_long", "align_score_wide",
                                            "align_score_wide_short", "align_score_long", "align_ungapped"};
     constexpr int N_LB = 12;
-    DBuf<unsigned long long> lb_bases(N_LB);
+    DBuf<unsigned long long> lb_bases(N_LB + 2);              // (+ 2: end extensions among the LONG tasks, their rows)
     std::vector<double> lb_n(N_LB, 0.0);
     lb_bases.zero();
     auto note_list = [&](const char *timer, const Task *tk, const uint32_t *lst, size_t n) {
@@ -2208,9 +2257,8 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         int slot = 0;
         while (slot < N_LB && strcmp(LB_NAMES[slot], timer) != 0) ++slot;
         if (slot == N_LB) return;
-        lb_n[slot] += (double)n;
-        hipLaunchKernelGGL(list_bases_kernel, dim3((unsigned)std::min<size_t>(cdiv(n, (size_t)WG), 1024)), dim3(WG), 0, stream(), tk, lst, n,
-                           lb_bases.p + slot);
+        lb_n[slot] += (double)n;             // (their bases: class_bases_kernel, once per classification pass)
+        (void)tk; (void)lst;
     };
     for (int attempt = 0;; ++attempt) {
         const size_t cap_runs = run_share + open_chunks;
@@ -2242,17 +2290,17 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             // match + 2 ext, paths with a further gap another open + ext + match (three positions fit the run buffer)
             const int k = aa.kmax + 1, U = den, T = num;
             // fifth certificate: one substitution gains less than a further inserted + deleted base costs
-            aa.kgap1 = aa.kmax >= 0 && U < o.gap_open + 2 * o.gap_ext + o.match && !getenv("HLMI_NO_GAP1_CERT") ? 1 : 0;
+            aa.kgap1 = aa.kmax >= 0 && U < o.gap_open + 2 * o.gap_ext + o.match && !hook("HLMI_NO_GAP1_CERT") ? 1 : 0;
             aa.kshift = aa.kmax >= 0 && k <= 3 && k * U > T && k * U < T + o.match + std::min(2 * o.gap_ext, o.gap_open + o.gap_ext) &&
-                        !getenv("HLMI_NO_SHIFT_CERT") ? 1 : 0;
+                        !hook("HLMI_NO_SHIFT_CERT") ? 1 : 0;
         }
-        aa.trim_ok = getenv("HLMI_NO_SUFFIX_TRIM") ? 0 : 1;
-        aa.one_ok = getenv("HLMI_NO_ONE_PIECE_CERT") ? 0 : 1;
+        aa.trim_ok = hook("HLMI_NO_SUFFIX_TRIM") ? 0 : 1;
+        aa.one_ok = hook("HLMI_NO_ONE_PIECE_CERT") ? 0 : 1;
         {   // sixth certificate (classify_kernel: extensions with one or two substitutions); G = cheapest one-base gap
             const int U = o.match + o.mismatch;
             int G = o.gap_open + o.gap_ext;
             if (aa.go2 > 0) G = std::min(G, aa.go2 + aa.ge2);
-            const bool sane = aa.kmax >= 0 && o.match > 0 && o.mismatch >= 0 && !getenv("HLMI_NO_EXT_CERT");
+            const bool sane = aa.kmax >= 0 && o.match > 0 && o.mismatch >= 0 && !hook("HLMI_NO_EXT_CERT");
             aa.kext_plain = sane && G >= U && U < 2 * G + o.match ? 1 : 0;
             aa.kext_bonus = 0;
             for (int k = 1; k <= 2; ++k)
@@ -2261,7 +2309,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         aa.out = tout.p; aa.runs = runs.p; aa.cap_runs = (uint32_t)cap_runs; aa.counters = counters.p;
         as.runs = runs.p;
         aa.run_buf_cap = 0xffffffffu;
-        if (const char *e = getenv("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
+        if (const char *e = hook("HLMI_RUN_BUF_CAP")) aa.run_buf_cap = (uint32_t)std::max(0, atoi(e));
         // pass 1: classify every task, finish the diagonal fast path right away
         DBuf<uint8_t> cls(NT), f1(NT), cls_bare(bare ? NT : 0);
         DBuf<uint32_t> list1(NT), list2(NT), list3(NT), list4(NT);
@@ -2291,41 +2339,66 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         };
         auto run_long = [&](const uint8_t *cls_arr, bool tb) -> size_t {
             if (aa.ungapped) return run_ungapped(cls_arr, tb);       // (no LONG class there: every DP task is CLS_UNGAPPED)
-            const size_t nl = class_list(cls_arr, CLS_LONG);
+            const size_t nl = class_list(cls_arr, CLS_LONG);         // (waits for the stream: the task records are written)
             if (!nl) return 0;
+            note_list(tb ? "align_long" : "align_score_long", tasks.p, long_list.p, nl);
+            hipLaunchKernelGGL(list_ext_kernel, dim3((unsigned)std::min<size_t>(cdiv(nl, (size_t)WG), 1024)), dim3(WG), 0, stream(), tasks.p,
+                               long_list.p, nl, lb_bases.p + N_LB);
+            long_launches.emplace_back(new LongLaunch());
+            LongLaunch &L = *long_launches.back();
+            {   // longest first: the work queue then ends with the short tasks
+                DBuf<uint32_t> key(nl);
+                hipLaunchKernelGGL(task_rows_desc_key_kernel, grid1(nl), dim3(WG), 0, stream(), tasks.p, long_list.p, nl, key.p);
+                L.list.alloc(nl);
+                HIP_CHECK(hipMemcpyAsync(L.list.p, long_list.p, nl * 4, hipMemcpyDeviceToDevice, stream()));
+                sort_pairs_u32_u32(key, L.list, nl, 0, 16);
+            }
             const unsigned nb = (unsigned)std::min<size_t>((nl + WAVES - 1) / WAVES, LONG_BLOCKS_MAX);
             const size_t n_waves = (size_t)nb * WAVES;
             LongArgs la{};
             if (tb) {
-                long_planes.alloc(n_waves * (size_t)N_WPLANES * long_chunks_cap * 64);
-                long_runs.alloc(n_waves * (size_t)long_runs_cap);
-                la.planes = long_planes.p; la.run_scratch = long_runs.p;
+                L.planes.alloc(n_waves * (size_t)N_WPLANES * long_chunks_cap * 64);
+                L.runs.alloc(n_waves * (size_t)long_runs_cap);
+                la.planes = L.planes.p; la.run_scratch = L.runs.p;
             }
             la.chunks_cap = long_chunks_cap; la.runs_cap = long_runs_cap; la.zdrop = o.zdrop;
-            long_ctl.zero();
-            la.next = long_ctl.p; la.too_long = long_ctl.p + 1;
-            aa.list = long_list.p; aa.n_list = nl;
-            note_list(tb ? "align_long" : "align_score_long", tasks.p, long_list.p, nl);
+            L.ctl.alloc(2);
+            L.ctl.zero();
+            sync();                                                  // list, keys and control words are in place: over to the side stream
+            la.next = L.ctl.p; la.too_long = L.ctl.p + 1;
+            AlignArgs al = aa;
+            al.list = L.list.p; al.n_list = nl;
             {
-                KTimer kt(tb ? "align_long" : "align_score_long");
+                hipStream_t ls = hook("HLMI_LONG_MAIN_STREAM") ? stream() : side_stream();      // (tuning: no second stream)
+                KTimer kt(tb ? "align_long" : "align_score_long", ls);
                 const bool two = aa.go2 > 0;
                 if (tb) {
-                    if (two) hipLaunchKernelGGL((align_long_kernel<true, true>), dim3(nb), dim3(WG), 0, stream(), aa, la);
-                    else hipLaunchKernelGGL((align_long_kernel<false, true>), dim3(nb), dim3(WG), 0, stream(), aa, la);
+                    if (two) hipLaunchKernelGGL((align_long_kernel<true, true>), dim3(nb), dim3(WG), 0, ls, al, la);
+                    else hipLaunchKernelGGL((align_long_kernel<false, true>), dim3(nb), dim3(WG), 0, ls, al, la);
                 } else {
-                    if (two) hipLaunchKernelGGL((align_long_kernel<true, false>), dim3(nb), dim3(WG), 0, stream(), aa, la);
-                    else hipLaunchKernelGGL((align_long_kernel<false, false>), dim3(nb), dim3(WG), 0, stream(), aa, la);
+                    if (two) hipLaunchKernelGGL((align_long_kernel<true, false>), dim3(nb), dim3(WG), 0, ls, al, la);
+                    else hipLaunchKernelGGL((align_long_kernel<false, false>), dim3(nb), dim3(WG), 0, ls, al, la);
                 }
             }
             HIP_CHECK(hipGetLastError());
-            if (long_ctl.download(2)[1]) fail(HLMI_EINVAL, "an alignment task exceeds the scratch area of align_long_kernel");
+            long_pending = true;
             return nl;
+        };
+        // after a join and a wait for the stream: did a LONG task exceed its scratch area?
+        auto check_long = [&]() {
+            for (auto &L : long_launches)
+                if (L->ctl.n && L->ctl.download(2)[1]) fail(HLMI_EINVAL, "an alignment task exceeds the scratch area of align_long_kernel");
         };
         // the tasks of stub candidates (cls_bare): score-only kernels over their own four lists
         size_t n_bare_tasks = 0;
-        auto run_bare = [&]() {
+        auto run_bare_long = [&]() {
             if (!bare) return;
-            { const size_t nl = run_long(cls_bare.p, false); n_bare_tasks += nl; n_long_bare += nl; }
+            const size_t nl = run_long(cls_bare.p, false);
+            n_bare_tasks += nl; n_long_bare += nl;
+        };
+        auto run_bare = [&](bool with_long) {             // (the lists of the four classes are rebuilt here: after the kernels that use them)
+            if (!bare) return;
+            if (with_long) run_bare_long();
             select_classes4_async(cls_bare.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
             const std::vector<uint32_t> hb = list_n.download(4);
             n_bare_tasks += (size_t)hb[0] + hb[1] + hb[2] + hb[3];
@@ -2376,6 +2449,8 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             hipLaunchKernelGGL(classify_kernel<2>, dim3(nb2), dim3(WG), 0, stream(), aa, cls.p, astats.p);
         }
         HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(class_bases_kernel, dim3((unsigned)std::min<size_t>(cdiv(NT, (size_t)WG), 2048)), dim3(WG), 0, stream(), cls.p,
+                           bare ? cls_bare.p : nullptr, tasks.p, NT, lb_bases.p);
         select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);      // the four DP task lists
         const std::vector<uint32_t> hn = list_n.download(4);
         const size_t n1 = hn[0], n2 = hn[1], n3 = hn[2], n4 = hn[3];
@@ -2387,6 +2462,11 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             hipLaunchKernelGGL(task_rows_key_kernel, grid1(nl), dim3(WG), 0, stream(), tasks.p, lst.p, nl, key.p);
             sort_pairs_u32_u32(key, lst, nl, 0, 7);
         }
+        // the LONG tasks first, on the side stream, and the score-only tasks of the stub candidates: everything below runs beside them
+        // (the candidates' few LONG tasks first: list building behind a running align_long_kernel is slowed down tenfold - the
+        //  long kernel's first round of tasks fills every SIMD)
+        run_bare_long();
+        n_long_tb += run_long(cls.p, true);
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
         if (n1 && packed) {
             // the list is in ascending row order: its head (fewer than NR_SMALL rows, counted by the classifier)
@@ -2414,7 +2494,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             const unsigned nb = (unsigned)std::min<size_t>(((n1 + 3) / 4 + WAVES - 1) / WAVES, 256 * 16);
             hipLaunchKernelGGL(align_narrow_kernel<NR_SHORT>, dim3(nb ? nb : 1), dim3(WG), 0, stream(), aa);
         }
-        if (n3 && packed && !getenv("HLMI_NARROW_LONG_UNPACKED")) {
+        if (n3 && packed && !hook("HLMI_NARROW_LONG_UNPACKED")) {
             // blocks of more than NR_SHORT rows (divergent reads: C5 has as many of these as of the short ones) in the packed
             // form as well: eight tasks per wave at twice the plane LDS (25 KB per wave) instead of four
             note_list("align_narrow_long", tasks.p, list3.p, n3);
@@ -2447,8 +2527,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             }
         };
         run_wide(n2, n4);
-        n_long_tb += run_long(cls.p, true);
-        run_bare();
+        run_bare(false);
         size_t n_wide_late = 0;
         if (o.stub_oh >= 0) {
             // Stub rule (hlmi_ava_opts::stub_oh; proof at oracle/ava_oracle.c:is_stub).  The end extensions of the stub
@@ -2457,6 +2536,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             // reaches the query end) stays without - its row can only be dropped by the consumer's overhang test; the others
             // get their extensions in a second round.
             as.plist = nullptr; as.n_pieces = P; as.late = late.p;
+            join_long();
             {
                 KTimer kt("assemble_count");
                 hipLaunchKernelGGL(assemble_kernel<false>, dim3(nba), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
@@ -2475,9 +2555,11 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                     const unsigned nb2 = (unsigned)std::min<size_t>(cdiv(2 * n_late, (size_t)WG), MAX_BLOCKS);
                     hipLaunchKernelGGL(classify_kernel<2>, dim3(nb2 ? nb2 : 1), dim3(WG), 0, stream(), aa, cls.p, astats.p);
                 }
+                hipLaunchKernelGGL(class_bases_kernel, dim3((unsigned)std::min<size_t>(cdiv(NT, (size_t)WG), 2048)), dim3(WG), 0, stream(), cls.p,
+                                   bare ? cls_bare.p : nullptr, tasks.p, NT, lb_bases.p);
                 if (bare) {                        // (every late task belongs to a candidate)
                     const size_t before = n_bare_tasks;
-                    run_bare();
+                    run_bare(true);
                     n_wide_late = n_bare_tasks - before;
                 } else {
                     select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
@@ -2489,6 +2571,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                 }
                 as.plist = late_idx.p; as.n_pieces = n_late;
                 const unsigned nbl = (unsigned)std::min<size_t>(cdiv(n_late, (size_t)WAVES), 256 * 32);
+                join_long();
                 {
                     KTimer kt("assemble_count");
                     hipLaunchKernelGGL(assemble_kernel<false>, dim3(nbl), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
@@ -2503,7 +2586,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             stat_add("align_tasks_long", (double)n_long_tb); stat_add("align_tasks_long_score_only", (double)n_long_bare);
         }
         HIP_CHECK(hipGetLastError());
+        join_long();
         std::vector<uint32_t> hc = counters.download(2);
+        check_long();
         if (!hc[1]) break;
         if (attempt >= 3) fail(HLMI_ENOMEM, "CIGAR run pool overflow");
         run_share *= 4;
@@ -2519,7 +2604,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         stat_add("align_bases_narrow", (double)h[ST_BASES_NARROW]);
         stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
         stat_add("align_bases_long", (double)h[ST_BASES_LONG]);
-        const std::vector<unsigned long long> lb = lb_bases.download(N_LB);
+        const std::vector<unsigned long long> lb = lb_bases.download(N_LB + 2);
+        stat_add("align_long_ext", (double)lb[N_LB]);
+        stat_add("align_long_ext_rows", (double)lb[N_LB + 1]);
         for (int k = 0; k < N_LB; ++k)
             if (lb_n[k] > 0) {
                 stat_add(std::string("align_n.") + LB_NAMES[k], lb_n[k]);
@@ -2575,7 +2662,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     const size_t P = ch.n_pieces;
     if (!P) return;
     size_t span_tasks = 64u << 20;               // (x 12 runs, x 4 once when a span overflows its pool: below 2^32)
-    if (const char *e = getenv("HLMI_ALIGN_SPAN_TASKS")) span_tasks = (size_t)std::max(64, atoi(e));      // test hook
+    if (const char *e = hook("HLMI_ALIGN_SPAN_TASKS")) span_tasks = (size_t)std::max(64, atoi(e));      // test hook
     const size_t NT = ch.n_fp + P;
     if (NT <= span_tasks) {
         AlignOut ao;

@@ -1181,7 +1181,7 @@ void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint3
         std::swap(ix.rk, rkey);
     }
     ix.rank_bits = bits_for(n_names + 1);
-    if (2 * o.k + ix.rank_bits > 64 || getenv("HLMI_NO_RANK_WORD")) ix.rank_bits = 0;      // (the variable: test hook)
+    if (2 * o.k + ix.rank_bits > 64 || hook("HLMI_NO_RANK_WORD")) ix.rank_bits = 0;      // (the variable: test hook)
     ix.ck.alloc(n && ix.rank_bits ? n : 1);
     if (n && ix.rank_bits)
         hipLaunchKernelGGL(compose_ck_kernel, grid1(n), dim3(WG), 0, stream(), ix.key.p, ix.rk.p, n, ix.rank_bits, ix.ck.p);
@@ -1254,12 +1254,12 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     // (HLMI_ANCHOR_PAIRS=1 forces the key + value form: test hook for the path wide inputs take)
     // else, when the word holds everything but the (target, strand) bits, those go to a 2- or 4-byte key of their own: the
     // sort moves 10 or 12 bytes per anchor instead of 16 (HLMI_ANCHOR_SPLIT=1 forces this form, test hook)
-    const bool pairs = getenv("HLMI_ANCHOR_PAIRS") != nullptr;
+    const bool pairs = hook("HLMI_ANCHOR_PAIRS") != nullptr;
     // (the word's query position is read back through 32 bits: 24 position bits above the 8 of the span)
-    const bool fits = qbits + tb + 1 + pb + qpb + 8 <= 64 && qpb <= 24 && !pairs && !getenv("HLMI_ANCHOR_SPLIT");
+    const bool fits = qbits + tb + 1 + pb + qpb + 8 <= 64 && qpb <= 24 && !pairs && !hook("HLMI_ANCHOR_SPLIT");
     const bool split = !fits && !pairs && qbits + pb + qpb + 8 <= 64 && qpb <= 24;
     const int vb = fits || split ? qpb + 8 : 0;
-    const char *force = getenv("HLMI_ANCHOR_SPLIT");         // "4": the wide key also where two bytes would do
+    const char *force = hook("HLMI_ANCHOR_SPLIT");         // "4": the wide key also where two bytes would do
     const int sk = split ? (tb + 1 <= 16 && !(force && force[0] == '4') ? 2 : 4) : 0;
     SeedArgs sa = make_seed_args(in, ix, plan, d_qlen, q_lo, q_hi);
     sa.pb = pb; sa.tb = tb; sa.vb = vb; sa.sk = sk;
@@ -1310,7 +1310,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (G) {
         hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p);
         sort_pairs_u32_u32(gkey.p, gorder.p, G, 0, 16);
-        if (INSTR && getenv("HLMI_GROUP_HIST")) {
+        if (INSTR && hook("HLMI_GROUP_HIST")) {
             DBuf<unsigned long long> hist(64);
             hist.zero();
             hipLaunchKernelGGL(group_hist_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, hist.p);
@@ -1338,17 +1338,17 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     ca.pieces = out.pieces.p; ca.fps = out.fps.p; ca.counters = counters.p;
     // packed DP state: scores (< longest query + one span) must stay below 2^22, positions * 4 inside 31 bits
     const bool packed = o.bandwidth + 2 <= PEN_TAB && max_qlen + 256 < (1ull << 22) && pb <= 28 && o.max_gap < (1 << 24) &&
-                        !getenv("HLMI_CHAIN_UNPACKED");
+                        !hook("HLMI_CHAIN_UNPACKED");
     ca.n_list = G;
     const dim3 block(64 * CHAIN_WAVES);
     auto grid_for = [](size_t n_list) { return dim3((unsigned)std::max<size_t>(1, cdiv(n_list, (size_t)CHAIN_GROUPS * CHAIN_WAVES))); };
-    if (packed && G && !getenv("HLMI_CHAIN_NO_DP16")) {
+    if (packed && G && !hook("HLMI_CHAIN_NO_DP16")) {
         // every wave first runs the 16-predecessor DP over its four groups, which also proves per group whether the
         // 64-predecessor DP of the specification would have given the same scores and predecessors (dp16_groups); the
         // chain bookkeeping of a proven group reads those, only the groups without the proof run the full DP
         DBuf<uint32_t> fp(A);
         ca.fp = fp.p;
-        if (INSTR && getenv("HLMI_CHAIN_DP16_CHECK")) {     // self-check: every group through the full DP, compared with the proven ones
+        if (INSTR && hook("HLMI_CHAIN_DP16_CHECK")) {     // self-check: every group through the full DP, compared with the proven ones
             DBuf<uint8_t> verdict(G), ok_of_group(G);
             DBuf<unsigned long long> n_bad(8);
             n_bad.zero();
@@ -1365,7 +1365,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
                                hb[4] >> 32, (int)(uint32_t)hb[4], hb[5] >> 32, (int)(uint32_t)hb[5]);
         } else {
             DBuf<unsigned long long> prof(8);
-            if (INSTR && getenv("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
+            if (INSTR && hook("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
             {
                 KTimer kt("chain");
                 hipLaunchKernelGGL((chain_kernel<3, 2>), grid_for(G), block, 0, stream(), ca);

@@ -22,6 +22,7 @@ namespace {
 template <typename F>
 int guarded(F &&f) {
     try {
+        hooks_refresh();         // test hooks / tuning switches of this call (the one place the environment is read)
         f();
         ktimer_flush();          // kernel timers of this call end here: none leaks into the next call's statistics
         return HLMI_OK;

@@ -48,6 +48,10 @@ hipStream_t stream();            // the library's compute stream
 int host_threads();
 
 // stats of the last stage (exported through hlmi_last_stats_json)
+// Test hooks and tuning switches: the value of a switch the library knows (nullptr: unset).  The table
+// is filled from the environment at the start of every C-ABI call (hooks_refresh, capi.cpp:guarded) - nothing else reads it.
+const char *hook(const char *name);
+void hooks_refresh();
 void stat_reset();
 void stat_set(const std::string &k, double v);
 void stat_add(const std::string &k, double v);
@@ -102,13 +106,14 @@ struct DBuf {
     std::vector<T> download() const { return download(n); }
 };
 
+hipStream_t side_stream();       // second stream (runtime.cpp): LONG alignment tasks beside the batch's other DP kernels
 inline void sync() { HIP_CHECK(hipStreamSynchronize(stream())); }
 
 // Scoped HIP-event timer on the library stream: per-kernel device time for bench.py's roofline line
 // (torch.cuda.Event would only see torch's stream).  Durations are summed per name by ktimer_flush()
 // into stats "kernel_ms.<name>" / "kernel_launches.<name>".
 struct KTimer {
-    explicit KTimer(const char *name);
+    explicit KTimer(const char *name, hipStream_t on = nullptr);     // on: the stream the kernel runs on (default: stream())
     ~KTimer();
     size_t slot;
 };

@@ -1024,7 +1024,7 @@ void filter_stage_device(const PafRec *d_recs, size_t n, const uint32_t *d_ops,
     pair_mut.zero();
     // ---- a5 + a6: per-read pile-up in LDS (the sort-based form below stays as the form very deep reads take) ---------
     bool piled = false;
-    if (!getenv("HLMI_SNP_SORT")) {
+    if (!hook("HLMI_SNP_SORT")) {
         DBuf<uint64_t> ekey(2 * m);
         DBuf<uint32_t> eval(2 * m);
         hipLaunchKernelGGL(pile_entries_kernel, grid1(m), dim3(WG), 0, stream(), d_recs, grows.p, sel.p, m, lm, ekey.p, eval.p);

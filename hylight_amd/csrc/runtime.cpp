@@ -10,6 +10,7 @@ namespace hlmi {
 namespace {
 thread_local std::string g_last_error;
 hipStream_t g_stream = nullptr;
+hipStream_t g_side = nullptr;
 bool g_ready = false;
 int g_threads = 8;
 std::map<std::string, double> g_stats;
@@ -44,6 +45,11 @@ void init_device(int device, int threads) {
 void shutdown_device() {
     std::lock_guard<std::mutex> lk(g_mu);
     dev_pool_trim();
+    if (g_side) {
+        (void)hipStreamSynchronize(g_side);
+        (void)hipStreamDestroy(g_side);
+    }
+    g_side = nullptr;
     if (g_stream) {
         (void)hipStreamSynchronize(g_stream);
         (void)hipStreamDestroy(g_stream);
@@ -57,26 +63,40 @@ void require_device() {
 }
 
 hipStream_t stream() { return g_stream; }
+// second stream: the few LONG alignment tasks of a batch (serial rows, a tail of minutes of wave time on a handful of CUs) run
+// here beside the batch's other DP kernels; the caller joins it with an event before anything reads their results
+hipStream_t side_stream() {
+    if (!g_side) {
+        // highest priority: its few waves are the tail of the batch - they should never wait for an issue slot behind the
+        // thousands of waves of the kernels they run beside
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); greatest = 0; }
+        HIP_CHECK(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, greatest));
+    }
+    return g_side;
+}
 
 namespace {
-struct KRec { std::string name; hipEvent_t a, b; };
+struct KRec { std::string name; hipEvent_t a, b; hipStream_t s; };
 std::vector<KRec> g_krecs;
 }  // namespace
 
-KTimer::KTimer(const char *name) {
+KTimer::KTimer(const char *name, hipStream_t on) {
     KRec r;
     r.name = name;
+    r.s = on ? on : g_stream;
     HIP_CHECK(hipEventCreate(&r.a));
     HIP_CHECK(hipEventCreate(&r.b));
-    HIP_CHECK(hipEventRecord(r.a, g_stream));
+    HIP_CHECK(hipEventRecord(r.a, r.s));
     slot = g_krecs.size();
     g_krecs.push_back(r);
 }
-KTimer::~KTimer() { (void)hipEventRecord(g_krecs[slot].b, g_stream); }
+KTimer::~KTimer() { (void)hipEventRecord(g_krecs[slot].b, g_krecs[slot].s); }
 
 void ktimer_flush() {
     if (g_krecs.empty()) return;
     if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (g_side) (void)hipStreamSynchronize(g_side);
     for (auto &r : g_krecs) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -93,6 +113,7 @@ size_t ktimer_mark() { return g_krecs.size(); }
 void ktimer_rollback(size_t mark) {            // forget the timers started after `mark` (a run that was given up)
     if (mark >= g_krecs.size()) return;
     if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (g_side) (void)hipStreamSynchronize(g_side);
     for (size_t i = mark; i < g_krecs.size(); ++i) { (void)hipEventDestroy(g_krecs[i].a); (void)hipEventDestroy(g_krecs[i].b); }
     g_krecs.resize(mark);
 }
@@ -100,8 +121,58 @@ void ktimer_rollback(size_t mark) {            // forget the timers started afte
 void ktimer_discard() {
     if (g_krecs.empty()) return;
     if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (g_side) (void)hipStreamSynchronize(g_side);
     for (auto &r : g_krecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_krecs.clear();
+}
+
+// ---- test hooks and tuning switches ------------------------------------------
+// The names the library knows, in ONE table.  hooks_refresh() - called at the start of every C-ABI call (capi.cpp:guarded) -
+// is the only place that reads the environment; the code paths ask hook(name).
+namespace {
+const char *const HOOK_NAMES[] = {
+    "HLMI_ALIGN_SPAN_TASKS",
+    "HLMI_ANCHOR_BATCH_M",
+    "HLMI_ANCHOR_PAIRS",
+    "HLMI_ANCHOR_SPLIT",
+    "HLMI_ASM_STAGE_CAP",
+    "HLMI_CHAIN_DP16_CHECK",
+    "HLMI_CHAIN_NO_DP16",
+    "HLMI_CHAIN_PROF",
+    "HLMI_CHAIN_UNPACKED",
+    "HLMI_GROUP_HIST",
+    "HLMI_HOST_TIMERS",
+    "HLMI_LONG_MAIN_STREAM",
+    "HLMI_NARROW_LONG_UNPACKED",
+    "HLMI_NARROW_UNPACKED",
+    "HLMI_NO_EXT_CERT",
+    "HLMI_NO_GAP1_CERT",
+    "HLMI_NO_ONE_PIECE_CERT",
+    "HLMI_NO_RANK_WORD",
+    "HLMI_NO_SHIFT_CERT",
+    "HLMI_NO_STUB",
+    "HLMI_NO_SUFFIX_TRIM",
+    "HLMI_QCAP_MIN",
+    "HLMI_RUN_BUF_CAP",
+    "HLMI_SKETCH_PART_MBASES",
+    "HLMI_SNP_SORT",
+    "HLMI_STUB_FULL_ROWS",
+    "HLMI_SUBRUN_MAX_MANCHORS",
+    "HLMI_SUBRUN_MAX_OUT_MB",
+    "HLMI_SUBRUN_MBASES"};
+std::unordered_map<std::string, std::string> g_hooks;
+}  // namespace
+void hooks_refresh() {
+    g_hooks.clear();
+    for (const char *n : HOOK_NAMES)
+        if (const char *v = getenv(n)) g_hooks[n] = v;
+}
+const char *hook(const char *name) {
+    bool known = false;
+    for (const char *n : HOOK_NAMES) known = known || strcmp(n, name) == 0;
+    if (!known) fail(HLMI_EINVAL, "hook %s is not in the table of runtime.cpp", name);
+    auto it = g_hooks.find(name);
+    return it == g_hooks.end() ? nullptr : it->second.c_str();
 }
 
 // ---- pooled device allocator -----------------------------------------------------------------------
@@ -218,7 +289,7 @@ static double wall_s() {
 // Draining the stream at both ends costs a launch bubble each time (eight per query batch): the host_s.* statistics
 // are collected only when HLMI_HOST_TIMERS is set.
 static bool host_timers_on() {
-    static const bool on = getenv("HLMI_HOST_TIMERS") != nullptr;
+    const bool on = hook("HLMI_HOST_TIMERS") != nullptr;
     return on;
 }
 HostTimer::HostTimer(const char *n) : name(n), t0(0) {

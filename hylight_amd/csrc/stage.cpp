@@ -48,7 +48,7 @@ Job::Job(const char *reads_fa, const char *ref_fa, int nsplit, bool long_mode)
     m.opts = long_mode ? ava_opts_long() : ava_opts_short();   // filter_overlap_slr2.py:51 / :55
     // both command lines pipe the rows into `filter_trans_ovlp_inline_v4.py -len 30 -oh 3`: pieces that are certain to
     // fail its overhang test are reported without end extensions (hlmi_ava_opts::stub_oh; HLMI_NO_STUB: test hook)
-    m.opts.stub_oh = getenv("HLMI_NO_STUB") ? -1 : FilterCfg().v4_min_o;
+    m.opts.stub_oh = hook("HLMI_NO_STUB") ? -1 : FilterCfg().v4_min_o;
     read_seqs(reads_fa, m.Q);
     const bool same = std::string(reads_fa) == ref_fa;
     if (!same) read_seqs(ref_fa, m.T);
@@ -96,7 +96,7 @@ int64_t Job::sketch_range(int64_t lo, int64_t hi, void *dev_mz, int64_t cap, voi
     // The sketch kernels index bases with 32 bits: a range of more than SKETCH_PART bases (BASELINE configs[3]: a million
     // long reads are 10 Gbases) is sketched in parts of consecutive reads, each appended to the output.
     uint64_t part_bases = 3ull << 30;
-    if (const char *e = getenv("HLMI_SKETCH_PART_MBASES")) part_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
+    if (const char *e = hook("HLMI_SKETCH_PART_MBASES")) part_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
     const uint64_t bases = m.Q.off[hi] - m.Q.off[lo];
     if (lo == 0 && (size_t)hi == m.Q.size() && bases <= part_bases)     // the reads are already resident in HBM
         return sketch_device_into(m.dQ, m.opts.k, m.opts.w, m.opts.hpc, 0, (Mz *)dev_mz, cap, (uint32_t *)dev_counts);
@@ -132,7 +132,7 @@ void Job::set_query_sketch(const void *dev_mz, int64_t n, const void *dev_counts
 void Job::sketch_all_queries() {
     Impl &m = *impl_;
     uint64_t part_bases = 3ull << 30;
-    if (const char *e = getenv("HLMI_SKETCH_PART_MBASES")) part_bases = (uint64_t)std::max(1, atoi(e)) << 20;
+    if (const char *e = hook("HLMI_SKETCH_PART_MBASES")) part_bases = (uint64_t)std::max(1, atoi(e)) << 20;
     if (m.Q.off.back() <= part_bases) {
         sketch_device(m.dQ, m.opts.k, m.opts.w, m.opts.hpc, 0, m.own);
     } else {                                     // in parts of consecutive reads, each sketched to its exact size, then joined
@@ -199,12 +199,12 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
     double subrun_anchors_max = 4.0e10, subrun_out_max = 1.5 * SUBRUN_OUT_BYTES;
     // test hooks: the refusal / retry path below with small inputs (millions of anchors / MB of output)
-    if (const char *e = getenv("HLMI_SUBRUN_MAX_MANCHORS")) subrun_anchors_max = 1e6 * std::max(1e-3, atof(e));
-    if (const char *e = getenv("HLMI_SUBRUN_MAX_OUT_MB")) subrun_out_max = 1e6 * std::max(1e-3, atof(e));
+    if (const char *e = hook("HLMI_SUBRUN_MAX_MANCHORS")) subrun_anchors_max = 1e6 * std::max(1e-3, atof(e));
+    if (const char *e = hook("HLMI_SUBRUN_MAX_OUT_MB")) subrun_out_max = 1e6 * std::max(1e-3, atof(e));
     const double subrun_anchors = std::min(SUBRUN_ANCHORS, subrun_anchors_max / 2), subrun_out = std::min(SUBRUN_OUT_BYTES, subrun_out_max / 1.5);
     uint64_t budget_bases = 128ull << 20;
-    if (const char *e = getenv("HLMI_SUBRUN_MBASES")) budget_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
-    const bool fixed_budget = getenv("HLMI_SUBRUN_MBASES") != nullptr;
+    if (const char *e = hook("HLMI_SUBRUN_MBASES")) budget_bases = (uint64_t)std::max(1, atoi(e)) << 20;   // test hook
+    const bool fixed_budget = hook("HLMI_SUBRUN_MBASES") != nullptr;
     if (!fixed_budget && m.est_anchors_per_base > 0) {
         const double by_anchors = subrun_anchors / m.est_anchors_per_base;
         const double by_bytes = m.est_out_per_base > 0 ? subrun_out / m.est_out_per_base : by_anchors;
