@@ -20,6 +20,8 @@ constexpr int NARROW_W = 16;        // blocks with |delta| <= NARROW_DELTA use a
 constexpr int NARROW_PAD = 5;
 constexpr int NARROW_DELTA = 5;
 constexpr int EXT_MAX = 256;        // an end extension runs over up to max(EXT_MAX, max_gap) rows (ext_rows)
+constexpr int HALF_W = 32;          // diagonals of a LONG extension and of a LONG block with |shift| <= HALF_DELTA
+constexpr int HALF_DELTA = 7;
 constexpr int ZDROP_STEP = 32;      // the z-drop test of an extension runs after rows 32, 64, ...
 constexpr int SHIFT_MAX = BAND_W - 2 * BAND_PAD - 1;     // 39: largest diagonal shift of one block
 constexpr int MAX_MID_OCC = 1000000;

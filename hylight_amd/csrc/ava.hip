@@ -150,6 +150,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
 
     // ---- query batches ----------------------------------------------------------------------------------
     std::vector<AlignOut> parts;
+    DeferredPieces deferred;                 // pieces with LONG alignment tasks: aligned together after the last batch
     SeedStats st;
     SeedPlan plan;
     {
@@ -210,7 +211,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
             HostTimer ht("align_pieces");
             const bool first = parts.empty();
             const size_t before = parts.size();
-            align_pieces(in, o, qlen.p, tlen.p, ch, parts);
+            align_pieces(in, o, qlen.p, tlen.p, ch, parts, &deferred);
             if (in.max_out_bytes && in.n_chunks > 1 && first && acc && parts.size() > before) {     // first batch with output: project the run
                 size_t rows = 0, ops = 0;
                 for (size_t i = before; i < parts.size(); ++i) { rows += parts[i].n_rows; ops += parts[i].n_ops; }
@@ -223,6 +224,22 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
             }
         }
         q = hi;
+    }
+    if (deferred.n_pieces) {
+        HostTimer ht("align_deferred");
+        ChainOut dc;
+        dc.n_pieces = deferred.n_pieces; dc.n_fp = deferred.n_fp;
+        dc.pieces.alloc(dc.n_pieces);
+        dc.fps.alloc(dc.n_fp);
+        size_t p0 = 0, f0 = 0;
+        for (auto &part : deferred.parts) {
+            HIP_CHECK(hipMemcpyAsync(dc.pieces.p + p0, part.pieces.p, part.n_pieces * sizeof(Piece), hipMemcpyDeviceToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(dc.fps.p + f0, part.fps.p, part.n_fp * sizeof(FixPt), hipMemcpyDeviceToDevice, stream()));
+            p0 += part.n_pieces; f0 += part.n_fp;
+        }
+        sync();
+        deferred.parts.clear();
+        align_pieces(in, o, qlen.p, tlen.p, dc, parts);
     }
     stat_add("index_entries", (double)ix.n);
     stat_add("anchors", (double)st.anchors);

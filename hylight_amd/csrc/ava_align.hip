@@ -110,8 +110,9 @@ __device__ __forceinline__ Task build_task(const PieceGeom &p, uint32_t piece, u
     // columns) takes 64 diagonals centred on the diagonals of its two corners
     const bool lng = m > BLOCK_MAX || n2 > BLOCK_MAX;
     const bool narrow = !lng && ad <= NARROW_DELTA;
+    const int lw = ad <= HALF_DELTA ? HALF_W : BAND_W;           // band of a LONG block
     return Task{piece, rev, (uint16_t)(narrow ? 1 : 0), qaddr(q0), to + (uint64_t)t0, (int16_t)m, (int16_t)n2,
-                (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : lng ? (BAND_W - 1 - ad) / 2 : BAND_PAD)), 0};
+                (int16_t)((delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : lng ? (lw - 1 - ad) / 2 : BAND_PAD)), 0};
 }
 // references of the tasks of every piece and the piece's geometry (one wave per piece)
 __global__ __launch_bounds__(WG) void task_ref_kernel(const Piece *pieces, const uint32_t *task_off, size_t n, const uint32_t *qlen,
@@ -250,6 +251,7 @@ __device__ __forceinline__ uint32_t load_window4p(const uint8_t *codes, long lon
 enum { ST_BASES = 0, ST_BASES_SQUARE, ST_BASES_NARROW, ST_BASES_WIDE, ST_FAST, ST_DP, ST_DP_ROWS, ST_NARROW_SMALL, ST_WIDE_ONE, ST_STUB_EXT, ST_EXT_CERT, ST_EXT_DP_ROW, ST_EXT_DP_K, ST_LONG, ST_BASES_LONG, N_ALIGN_STATS };
 constexpr int NR_SMALL = 64;                    // narrow tasks with fewer rows than this run in the instance with half the plane LDS
 constexpr uint8_t CLS_LONG = 5;                 // class of the LONG tasks (align_long_kernel)
+constexpr uint8_t CLS_LONG32 = 7;               // LONG tasks in the 32-diagonal band, two to a wave (align_long32_kernel)
 constexpr uint8_t CLS_UNGAPPED = 6;             // bandwidth 0: every task a certificate does not settle (align_ungapped_kernel)
 
 // 8 window elements x .. x+7 (byte 0 = element x); same conventions as load_window4
@@ -342,17 +344,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
         if (live) {
             if (m <= 0 || n <= 0 || held) c = 0;
             else if ((tk.kind & 3) == 0) {
-                if (m > BLOCK_MAX || n > BLOCK_MAX) c = CLS_LONG;     // LONG block: no certificate is tried (no shared minimizer over
-                                                                      // more than 256 bases: the sequences differ there)
+                if (m > BLOCK_MAX || n > BLOCK_MAX)                    // LONG block: no certificate is tried (no shared minimizer over
+                    c = (n > m ? n - m : m - n) <= HALF_DELTA ? CLS_LONG32 : CLS_LONG;   // more than 256 bases: the sequences differ there)
                 else { c = tk.narrow ? (m <= NR_SHORT ? 1 : 3) : 2; try_fast = (m == n); }
-            } else if ((m < n - tk.dlo ? m : n - tk.dlo) > EXT_MAX || a.ext_all_long) c = CLS_LONG;
+            } else if ((m < n - tk.dlo ? m : n - tk.dlo) > EXT_MAX) { c = CLS_LONG32; tk.dlo = (int16_t)(-(HALF_W / 2 - 1)); }   // 32 diagonals
+            else if (a.ext_all_long) c = CLS_LONG;
             // (an extension's rows end where its band leaves the target: min(m, n - dlo) - a dovetail's extension into the
             //  few bases the shorter side has left is a short task whatever the other side's length; LONG after the
             //  certificates of the second pass)
             if (c == 2 && (m < n - tk.dlo ? m : n - tk.dlo) <= WIDE_SHORT) c = 4;      // rows the 64-diagonal kernel really runs
         }
         if (PASS == 1 && live) {                                      // second / third certificate: the other pass
-            const bool defer = c != 0 && a.kmax >= 0 && ((tk.kind & 3) != 0 || (m != n && c != CLS_LONG));
+            const bool defer = c != 0 && a.kmax >= 0 && ((tk.kind & 3) != 0 || (m != n && c != CLS_LONG && c != CLS_LONG32));
             a.defer_flag[ti] = defer ? 1 : 0;
             if (defer) { live = false; try_fast = false; }
         }
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                 if (c == 0) ++st[ST_FAST];
                 else {
                     ++st[ST_DP];
-                    if (c == CLS_LONG) { ++st[ST_LONG]; st[ST_BASES_LONG] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
+                    if (c == CLS_LONG || c == CLS_LONG32) { ++st[ST_LONG]; st[ST_BASES_LONG] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
                     else if (c == 2 || c == 4) { st[ST_BASES_WIDE] += bases; st[ST_DP_ROWS] += (uint32_t)(m < n - tk.dlo ? m : n - tk.dlo); }
                     else { st[ST_BASES_NARROW] += bases; st[ST_DP_ROWS] += (uint32_t)m_dp; if (c == 1 && m_dp < NR_SMALL && !bare) ++st[ST_NARROW_SMALL]; }
                 }
@@ -1426,10 +1429,10 @@ __device__ uint32_t wide_walk(const uint32_t *pl, int chunks, int m0, int n0, in
 // The same walk over planes in GLOBAL memory (align_long_kernel's scratch area): the nine words an iteration can need are
 // requested together - one round trip to the caches per event instead of two or three dependent ones.  Runs in emission
 // order into buf (cap entries).
-template <bool TWO>
+template <bool TWO, int W = BAND_W>
 __device__ uint32_t long_walk(const uint32_t *pl, int chunks, int m0, int n0, int dlo, bool keep_order, uint32_t *buf, uint32_t cap,
                               uint32_t *ends, int max_it) {
-    auto word = [&](int plane, int c, int lane) { return pl[((size_t)plane * chunks + c) * 64 + lane]; };
+    auto word = [&](int plane, int c, int lane) { return pl[((size_t)plane * chunks + c) * W + lane]; };
     int i = m0, j = n0, state = 0;                    // state: 0 H, 1 E1, 2 F1, 3 E2, 4 F2
     uint32_t cur_op = 0, cur_len = 0, n_runs = 0, e_first = 0, e_last = 0;
     auto put = [&]() {
@@ -1443,10 +1446,10 @@ __device__ uint32_t long_walk(const uint32_t *pl, int chunks, int m0, int n0, in
         if (i == 0) {                                          // row 0: H(0,j) is a gap from the corner
             op = OP_D; len = (uint32_t)j; j = 0;
         } else {
-            const int d = (j - i - dlo) & (BAND_W - 1);
+            const int d = (j - i - dlo) & (W - 1);
             const int c = (i - 1) >> 5, sh = 31 - ((i - 1) & 31);
             const int i2 = i > 1 ? i - 2 : 0, c2 = i2 >> 5, sh2 = 31 - (i2 & 31);
-            const int dl = (d - 1) & 63, dr = (d + 1) & 63;
+            const int dl = (d - 1) & (W - 1), dr = (d + 1) & (W - 1);
             const uint32_t w_dg = word(WP_DIAG, c, d), w_ne = word(WP_NE, c, d), w_eg = word(WP_EGEF, c, d);
             const uint32_t w_ep = TWO ? word(WP_EP, c, d) : 0u, w_fp = TWO ? word(WP_FP, c, d) : 0u;
             const uint32_t w_ex1 = word(WP_EX1, c, dl), w_ex2 = TWO ? word(WP_EX2, c, dl) : 0u;
@@ -1631,6 +1634,7 @@ struct LongArgs {
     int zdrop;              // 0: none
     uint32_t *next;         // work counter (zeroed before the launch)
     uint32_t *too_long;     // set when a task does not fit the scratch areas (the host sizes them from the options: never)
+    unsigned long long *rows_run;   // sum of the rows the tasks really ran (statistics: a z-drop ends an extension early)
 };
 
 template <bool TWO, bool TB>
@@ -1645,6 +1649,9 @@ __global__ __launch_bounds__(WG) void align_long_kernel(AlignArgs a, LongArgs la
     uint32_t chunk_off = 0, chunk_left = 0;
     const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * lane, goel = go + ge * lane;
     const int go2 = a.go2, ge2 = a.ge2, goe2 = go2 + ge2, gel2 = ge2 * lane, goel2 = go2 + ge2 * lane;
+    // The few LONG tasks of a batch are its critical path (thousands of dependent rows each) and run beside kernels that fill every
+    // SIMD: their waves take the issue slots first
+    __builtin_amdgcn_s_setprio(3);
     for (;;) {
         uint32_t li = 0;
         if (lane == 0) li = atomicAdd(la.next, 1u);
@@ -1795,6 +1802,7 @@ __global__ __launch_bounds__(WG) void align_long_kernel(AlignArgs a, LongArgs la
             score = (int)(uint32_t)(best >> 32) - (1 << 20) - (ei == end_row ? a.end_bonus : 0);   // the bonus only ranks
         }
         const uint32_t flag = ext && ei == end_row ? 0x80000000u : 0u;
+        if (lane == 0) atomicAdd(la.rows_run, (unsigned long long)rows_done);
         if constexpr (!TB) {
             if (lane == 0) a.out[ti] = TaskOut{score, ei, ej, 0, 0, flag};
             continue;
@@ -1814,6 +1822,248 @@ __global__ __launch_bounds__(WG) void align_long_kernel(AlignArgs a, LongArgs la
             off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
             ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
             if (ok) for (uint32_t k = (uint32_t)lane; k < n_runs; k += 64)      // left extensions keep the emission order
+                a.runs[off + k] = rs[left ? k : n_runs - 1 - k];
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---- pass 2c': LONG tasks in the 32-diagonal band, TWO tasks per wave ------------------------------------------------------
+// LONG extensions (band -15 .. +16) and LONG blocks whose diagonal shift is at most HALF_DELTA (32 diagonals centred on the
+// corners): lanes 0-31 run one task, lanes 32-63 another - the scheme of align_long_kernel with every cross-lane step
+// confined to its half (the prefix maximum stops at the half's last lane, the one-lane shifts take no value across the
+// middle).  The list is sorted by rows, so the two tasks of a wave are about equally long; the shorter one idles its
+// half for the difference.  Per-half scratch: planes [plane][32-row word][32 lanes], runs.
+constexpr int LT32_LEN = LONG_TILE + HALF_W + 8;
+__device__ __forceinline__ int half_prefix_max_incl_dpp(int x) {       // inclusive prefix max inside each half of the wave
+    constexpr int ident = DPP_MAX_IDENT;
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    x = mx(x, dpp_i32<0x111>(ident, x));
+    x = mx(x, dpp_i32<0x112>(ident, x));
+    x = mx(x, dpp_i32<0x114>(ident, x));
+    x = mx(x, dpp_i32<0x118>(ident, x));
+    x = mx(x, dpp_i32<0x142, 0xa>(ident, x));                          // lane 15 -> row 1, lane 47 -> row 3
+    return x;
+}
+__device__ __forceinline__ uint32_t half_max_u32(uint32_t v, int hf) {  // max over the lanes of the own half, to every lane of it
+    int x = (int)v;
+    auto mx = [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); };
+    x = mx(x, dpp_i32<0x111>(0, x));
+    x = mx(x, dpp_i32<0x112>(0, x));
+    x = mx(x, dpp_i32<0x114>(0, x));
+    x = mx(x, dpp_i32<0x118>(0, x));
+    x = mx(x, dpp_i32<0x142, 0xa>(0, x));
+    return (uint32_t)__shfl(x, 32 * hf + 31, 64);
+}
+
+template <bool TWO, bool TB>
+__global__ __launch_bounds__(WG) void align_long32_kernel(AlignArgs a, LongArgs la) {
+    __shared__ __attribute__((aligned(4))) uint8_t s_q[WAVES][2][LONG_TILE + 8];
+    __shared__ __attribute__((aligned(4))) uint8_t s_t[WAVES][2][LT32_LEN];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hf = lane >> 5, hl = lane & 31;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    // (a wave's plane area has room for 64 lanes: each half takes 32 of them)
+    uint32_t *const pl = TB ? la.planes + wave * ((size_t)N_WPLANES * la.chunks_cap * 64) + (size_t)hf * ((size_t)N_WPLANES * la.chunks_cap * 32) : nullptr;
+    uint32_t *const rs = TB ? la.run_scratch + (wave * 2 + (size_t)hf) * (size_t)la.runs_cap : nullptr;
+    uint8_t *sq = s_q[wv][hf], *st = s_t[wv][hf];
+    uint32_t chunk_off = 0, chunk_left = 0;
+    const int go = a.go, ge = a.ge, goe = go + ge, gel = ge * hl, goel = go + ge * hl;
+    const int go2 = a.go2, ge2 = a.ge2, goe2 = go2 + ge2, gel2 = ge2 * hl, goel2 = go2 + ge2 * hl;
+    __builtin_amdgcn_s_setprio(3);                                 // (see align_long_kernel)
+    for (;;) {
+        uint32_t pi = 0;
+        if (lane == 0) pi = atomicAdd(la.next, 1u);
+        pi = (uint32_t)__builtin_amdgcn_readfirstlane((int)pi);
+        if (2 * (size_t)pi >= a.n_list) break;                    // (every wave gets here: the counter only grows)
+        const size_t li = 2 * (size_t)pi + (size_t)hf;
+        bool live = li < a.n_list;
+        size_t ti = 0;
+        Task tk{};
+        if (live) { ti = a.list[li]; tk = a.tasks[ti]; }
+        const int n = tk.n, dlo = tk.dlo;
+        int m = live ? (tk.m < n - dlo ? (int)tk.m : n - dlo) : 0;   // rows this half runs (a z-drop lowers it)
+        if (m < 0) m = 0;
+        const int kind = tk.kind & 3;
+        const int chunks = (m + 31) >> 5;
+        if (live && (m <= 0 || n <= 0 || (TB && ((uint32_t)chunks > la.chunks_cap || (uint32_t)(m + n + 2) > la.runs_cap)))) {
+            if (hl == 0) {
+                a.out[ti] = TaskOut{0, 0, 0, 0, 0, 0};
+                if (m > 0 && n > 0) *la.too_long = 1;
+            }
+            live = false;
+            m = 0;
+        }
+        const int m0 = m;
+        const bool ext = kind != 0, rev = (tk.kind & TASK_REV) != 0, left = kind == 1;
+        const int end_row = ext ? (int)(tk.narrow >> 1) - 1 : -1;
+        const int j0 = dlo + hl;
+        int gap0 = go + ge * j0;
+        if (TWO && go2 + ge2 * j0 < gap0) gap0 = go2 + ge2 * j0;
+        int H = j0 == 0 ? DP_BIAS : (j0 > 0 ? DP_BIAS - gap0 : 0);          // row 0 (biased scores: narrow_rows)
+        int G = H - goe, G2 = TWO ? H - goe2 : 0, Hend = 0;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        int best_h = 0, best_i = 0;                                          // biased like H: 0 = no cell yet
+        if (live && ext && j0 >= 0 && j0 <= n) best_h = H;
+        for (int r0 = 0;; r0 += LONG_TILE) {
+            // rows the longer of the two tasks still has (a z-drop may have shortened either)
+            const int mA = __builtin_amdgcn_readlane(m, 0), mB = __builtin_amdgcn_readlane(m, 32);
+            const int rows_max = mA > mB ? mA : mB;
+            if (r0 >= rows_max) break;
+            const int R_all = rows_max - r0 < LONG_TILE ? rows_max - r0 : LONG_TILE;
+            {   // stage the tile of the own task (align_long_kernel): 32 lanes x 4 bases per round
+                __builtin_amdgcn_wave_barrier();
+                const int R = m - r0 < 0 ? 0 : (m - r0 < LONG_TILE ? m - r0 : LONG_TILE);
+                uint32_t vq[2], vt[3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int k = 4 * (hl + 32 * r);
+                    vq[r] = 0x04040404u;
+                    if (k < R) vq[r] = load_window4p(a.qcodes, (long long)tk.qa, left != rev, rev, r0 + k);
+                }
+                const int eb = r0 + dlo;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int k = 4 * (hl + 32 * r), x = eb + k;
+                    vt[r] = 0x04040404u;
+                    if (R > 0 && k < R + HALF_W && x + 3 >= 0 && x < n) vt[r] = load_window4p(a.tcodes, (long long)tk.ta, left, false, x);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) *(uint32_t *)(sq + 4 * (hl + 32 * r)) = vq[r];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int k = 4 * (hl + 32 * r);
+                    if (k < LT32_LEN - 3) *(uint32_t *)(st + k) = vt[r];
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint8_t *tp = st + hl;                                     // target base of row r0 + ii: tp[ii - 1]
+            int qa = sq[0], t2 = tp[0];
+            for (int ii = 1; ii <= R_all; ++ii) {
+                const int i = r0 + ii;
+                const int qa_next = sq[ii], t2_next = tp[ii];
+                const bool ne = qa != t2;
+                int s = ne ? -a.mismatch : a.match;
+                s = (qa | t2) > 3 ? -a.ambi : s;
+                const int mm = H + s;
+                int f1 = wave_shl1_z(G);
+                f1 = hl == 31 ? 0 : f1;                                      // (nothing from the other half's lane 0)
+                int f2 = 0;
+                if (TWO) { f2 = wave_shl1_z(G2); f2 = hl == 31 ? 0 : f2; }
+                const int f = TWO && f2 > f1 ? f2 : f1;
+                const int ht = mm > f ? mm : f;
+                int p1 = wave_shr1(half_prefix_max_incl_dpp(ht + gel), 0);
+                p1 = hl == 0 ? 0 : p1;
+                const int e1 = p1 - goel;
+                int e2 = 0;
+                if (TWO) {
+                    int p2 = wave_shr1(half_prefix_max_incl_dpp(ht + gel2), 0);
+                    p2 = hl == 0 ? 0 : p2;
+                    e2 = p2 - goel2;
+                }
+                const int e = TWO && e2 > e1 ? e2 : e1;
+                const int h = ht > e ? ht : e;
+                const int fo = h - goe, fe = f1 - ge;
+                if (TB) {
+                    a0 = shift_in(a0, mm == h);
+                    a1 = shift_in(a1, e >= f);
+                    a2 = shift_in(a2, e1 + go > h);
+                    a3 = shift_in(a3, fe > fo);
+                    a4 = shift_in(a4, ne);
+                }
+                G = fo > fe ? fo : fe;
+                if (TWO) {
+                    const int fo2 = h - goe2, fe2 = f2 - ge2;
+                    if (TB) {
+                        b0 = shift_in(b0, e2 > e1);
+                        b1 = shift_in(b1, f2 > f1);
+                        b2 = shift_in(b2, e2 + go2 > h);
+                        b3 = shift_in(b3, fe2 > fo2);
+                    }
+                    G2 = fo2 > fe2 ? fo2 : fe2;
+                }
+                H = h;
+                qa = qa_next; t2 = t2_next;
+                const bool run = i <= m;                                     // this half's task still has this row
+                const bool inside = run && (uint32_t)(i + j0) <= (uint32_t)n;   // 0 <= j <= n
+                if (i == m0) Hend = h;
+                if (ext) {
+                    const int hb = h + (i == end_row ? a.end_bonus : 0);
+                    if (inside && hb > best_h) { best_h = hb; best_i = i; }
+                }
+                if ((i & 31) == 0) {
+                    if (TB && run) {
+                        const size_t c = (size_t)(i >> 5) - 1;
+                        pl[((size_t)WP_DIAG * chunks + c) * 32 + hl] = a0; pl[((size_t)WP_EGEF * chunks + c) * 32 + hl] = a1;
+                        pl[((size_t)WP_EX1 * chunks + c) * 32 + hl] = a2; pl[((size_t)WP_FX1 * chunks + c) * 32 + hl] = a3;
+                        pl[((size_t)WP_NE * chunks + c) * 32 + hl] = a4;
+                        if (TWO) {
+                            pl[((size_t)WP_EP * chunks + c) * 32 + hl] = b0; pl[((size_t)WP_FP * chunks + c) * 32 + hl] = b1;
+                            pl[((size_t)WP_EX2 * chunks + c) * 32 + hl] = b2; pl[((size_t)WP_FX2 * chunks + c) * 32 + hl] = b3;
+                        }
+                    }
+                    if (la.zdrop > 0) {                                      // z-drop of an extension (uniform per half)
+                        const int row_max = (int)half_max_u32(inside ? (uint32_t)h : 0u, hf);
+                        const int so_far = (int)half_max_u32((uint32_t)best_h, hf);
+                        if (ext && run && i < m && (row_max == 0 || so_far - row_max > la.zdrop)) m = i;
+                    }
+                } else if (TB && i == m) {
+                    // the task's last row is not a word boundary: its partial word now, first row up to bit 31 (the accumulators
+                    // go on shifting while the other half's task runs)
+                    const size_t c = (size_t)(i >> 5);
+                    const int up = 32 - (i & 31);
+                    pl[((size_t)WP_DIAG * chunks + c) * 32 + hl] = a0 << up; pl[((size_t)WP_EGEF * chunks + c) * 32 + hl] = a1 << up;
+                    pl[((size_t)WP_EX1 * chunks + c) * 32 + hl] = a2 << up; pl[((size_t)WP_FX1 * chunks + c) * 32 + hl] = a3 << up;
+                    pl[((size_t)WP_NE * chunks + c) * 32 + hl] = a4 << up;
+                    if (TWO) {
+                        pl[((size_t)WP_EP * chunks + c) * 32 + hl] = b0 << up; pl[((size_t)WP_FP * chunks + c) * 32 + hl] = b1 << up;
+                        pl[((size_t)WP_EX2 * chunks + c) * 32 + hl] = b2 << up; pl[((size_t)WP_FX2 * chunks + c) * 32 + hl] = b3 << up;
+                    }
+                }
+            }
+        }
+        int ei, ej, score;
+        if (!ext) {
+            ei = m0; ej = n;
+            score = __shfl(Hend, 32 * hf + ((n - m0 - dlo) & (HALF_W - 1)), 64) - DP_BIAS;
+        } else {
+            // best cell: score (with the bonus), then fewest bases i + j, then fewest rows (align_kernel) - over the own half
+            unsigned long long best = 0;
+            if (best_h > DP_BIAS / 2)
+                best = (unsigned long long)(uint32_t)(best_h - DP_BIAS + (1 << 20)) << 32 |
+                       (unsigned long long)(0xffffu - (uint32_t)(2 * best_i + dlo + hl)) << 16 |
+                       (unsigned long long)(0xffffu - (uint32_t)best_i);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const unsigned long long u = __shfl_xor(best, o, 64);
+                best = u > best ? u : best;
+            }
+            ei = (int)(0xffffu - (uint32_t)(best & 0xffff));
+            ej = (int)(0xffffu - (uint32_t)((best >> 16) & 0xffff)) - ei;
+            score = (int)(uint32_t)(best >> 32) - (1 << 20) - (ei == end_row ? a.end_bonus : 0);   // the bonus only ranks
+        }
+        const uint32_t flag = ext && ei == end_row ? 0x80000000u : 0u;
+        if (live && hl == 0) atomicAdd(la.rows_run, (unsigned long long)m);
+        if constexpr (!TB) {
+            if (live && hl == 0) a.out[ti] = TaskOut{score, ei, ej, 0, 0, flag};
+            continue;
+        } else {
+            __threadfence_block();                                           // the planes of all lanes, before the walkers read them
+            __builtin_amdgcn_wave_barrier();
+            uint32_t n_runs = 0, off = 0, ends = 0;
+            bool ok = true;
+            if (live && hl == 0) {
+                n_runs = long_walk<TWO, HALF_W>(pl, chunks, ei, ej, dlo, left, rs, la.runs_cap, &ends, 2 * (m0 + n) + 8);
+                if (n_runs) off = pool_take(a, n_runs, chunk_off, chunk_left, ok);
+                a.out[ti] = TaskOut{score, ei, ej, off, ok ? n_runs : 0, ends | flag};
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            n_runs = (uint32_t)__shfl((int)n_runs, 32 * hf, 64);
+            off = (uint32_t)__shfl((int)off, 32 * hf, 64);
+            ok = __shfl((int)ok, 32 * hf, 64) != 0;
+            if (ok) for (uint32_t k = (uint32_t)hl; k < n_runs; k += 32)       // left extensions keep the emission order
                 a.runs[off + k] = rs[left ? k : n_runs - 1 - k];
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
@@ -2116,20 +2366,20 @@ __global__ void late_tasks_kernel(const uint32_t *plist, size_t n, const Piece *
 // launches (bench.py's roofline table).  Slots: LB_NAMES in align_span.
 __global__ __launch_bounds__(WG) void class_bases_kernel(const uint8_t *cls, const uint8_t *cls_bare, const Task *tasks, size_t n,
                                                           unsigned long long *out) {
-    __shared__ unsigned long long s_sum[12];
-    if (threadIdx.x < 12) s_sum[threadIdx.x] = 0;
+    __shared__ unsigned long long s_sum[14];
+    if (threadIdx.x < 14) s_sum[threadIdx.x] = 0;
     __syncthreads();
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = cls[i], cb = cls_bare ? cls_bare[i] : 0;
         if (!c && !cb) continue;
         const Task &t = tasks[i];
         int slot;
-        if (c) slot = c == 1 ? ((int)t.m < NR_SMALL ? 0 : 1) : c == 3 ? 2 : c == 2 ? 3 : c == 4 ? 4 : c == CLS_LONG ? 5 : 11;
-        else slot = cb == 1 ? 6 : cb == 3 ? 7 : cb == 2 ? 8 : cb == 4 ? 9 : cb == CLS_LONG ? 10 : 11;
+        if (c) slot = c == 1 ? ((int)t.m < NR_SMALL ? 0 : 1) : c == 3 ? 2 : c == 2 ? 3 : c == 4 ? 4 : c == CLS_LONG ? 5 : c == CLS_LONG32 ? 12 : 11;
+        else slot = cb == 1 ? 6 : cb == 3 ? 7 : cb == 2 ? 8 : cb == 4 ? 9 : cb == CLS_LONG ? 10 : cb == CLS_LONG32 ? 13 : 11;
         atomicAdd(&s_sum[slot], (unsigned long long)((int)t.m + (int)t.n));
     }
     __syncthreads();
-    if (threadIdx.x < 12 && s_sum[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_sum[threadIdx.x]);
+    if (threadIdx.x < 14 && s_sum[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_sum[threadIdx.x]);
 }
 
 // LONG task list: how many of the tasks are end extensions, and their rows (statistics: align_long_ext / align_long_ext_rows)
@@ -2157,6 +2407,59 @@ __global__ void compact_rows_kernel(const uint32_t *idx, size_t n, const PafRec 
     orecs[i] = recs[idx[i]];
     ohi[i] = hi[idx[i]];
     olo[i] = lo[idx[i]];
+}
+
+// ---- deferring the pieces with LONG tasks ----------------------------------------------------------------------------------
+// A LONG task is thousands of dependent rows; a query batch of a clean read set holds a few thousand of them (C3: 1.6 % of the
+// pieces), and a launch over so few lasts as long as its longest task whatever the card could do meanwhile.  The pieces
+// that have one are therefore set aside batch after batch and aligned together at the end of the run - one launch with two
+// orders of magnitude more tasks.  Rows find their place by their stream-order keys, not by the batch they were aligned in.
+// flag[i] = piece i has a LONG block or a LONG end extension (the predicates of build_task / classify_kernel)
+__global__ __launch_bounds__(WG) void piece_long_flag_kernel(const Piece *pieces, size_t n, const FixPt *fps, const uint32_t *qlen,
+                                                              const uint32_t *tlen, int ext_max, uint8_t *flag) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t i = wave; i < n; i += n_waves) {
+        const Piece p = pieces[i];
+        const FixPt *fp = fps + p.fp_off;
+        bool lng = false;
+        if (lane == 0) {                                      // the two end extensions: rows their 64-diagonal band runs
+            const FixPt a = fp[0], b = fp[p.n_fp - 1];
+            const int ql = (int)qlen[p.q], tl = (int)tlen[p.t];
+            auto rows = [&](int aq, int at) {
+                const int m = aq < ext_max ? aq : ext_max, nn = at < m + BAND_W ? at : m + BAND_W;
+                return m < nn + (BAND_W / 2 - 1) ? m : nn + (BAND_W / 2 - 1);
+            };
+            lng = rows((int)a.q, (int)a.t) > EXT_MAX || rows(ql - (int)b.q, tl - (int)b.t) > EXT_MAX;
+        }
+        for (uint32_t k = (uint32_t)lane; k + 1 < p.n_fp && !__any(lng); k += 64) {
+            const FixPt f0 = fp[k], f1 = fp[k + 1];
+            lng = lng || (int)(f1.q - f0.q) > BLOCK_MAX || (int)(f1.t - f0.t) > BLOCK_MAX;
+        }
+        const bool any = __any(lng);
+        if (lane == 0) flag[i] = any ? 1 : 0;
+    }
+}
+__global__ void gather_pieces_kernel(const Piece *src, const uint32_t *idx, size_t n, Piece *dst, uint32_t *n_fp) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Piece p = src[idx[i]];
+    dst[i] = p;
+    if (n_fp) n_fp[i] = p.n_fp;
+}
+// the fixed points of the set-aside pieces move into the deferred array: piece i's at fp_base + off[i]
+__global__ __launch_bounds__(WG) void move_fixed_points_kernel(Piece *pieces, size_t n, const uint32_t *off, uint32_t fp_base, const FixPt *src,
+                                                                FixPt *dst) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t i = wave; i < n; i += n_waves) {
+        const Piece p = pieces[i];
+        const uint32_t to = off[i];
+        for (uint32_t k = (uint32_t)lane; k < p.n_fp; k += 64) dst[to + k] = src[p.fp_off + k];
+        if (lane == 0) pieces[i].fp_off = fp_base + to;
+    }
 }
 }  // namespace
 
@@ -2244,11 +2547,13 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     DBuf<uint8_t> long_flag;
     DBuf<uint32_t> long_list, long_n(1);
     size_t n_long_tb = 0, n_long_bare = 0;
+    double long_rows_run = 0;
     // per DP launch: tasks and bases (rows + columns) - "align_n.<timer>", "align_bases.<timer>" of the statistics
     static const char *const LB_NAMES[] = {"align_narrow_small", "align_narrow", "align_narrow_long", "align_wide", "align_wide_short",
                                            "align_long", "align_score_narrow", "align_score_narrow_long", "align_score_wide",
-                                           "align_score_wide_short", "align_score_long", "align_ungapped"};
-    constexpr int N_LB = 12;
+                                           "align_score_wide_short", "align_score_long", "align_ungapped", "align_long32",
+                                           "align_score_long32"};
+    constexpr int N_LB = 14;
     DBuf<unsigned long long> lb_bases(N_LB + 2);              // (+ 2: end extensions among the LONG tasks, their rows)
     std::vector<double> lb_n(N_LB, 0.0);
     lb_bases.zero();
@@ -2337,57 +2642,72 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             HIP_CHECK(hipGetLastError());
             return nl;
         };
-        auto run_long = [&](const uint8_t *cls_arr, bool tb) -> size_t {
-            if (aa.ungapped) return run_ungapped(cls_arr, tb);       // (no LONG class there: every DP task is CLS_UNGAPPED)
-            const size_t nl = class_list(cls_arr, CLS_LONG);         // (waits for the stream: the task records are written)
+        // LONG tasks of class cv (CLS_LONG: 64 diagonals, a task per wave; CLS_LONG32: 32 diagonals, two tasks per wave)
+        auto run_long_class = [&](const uint8_t *cls_arr, bool tb, uint8_t cv) -> size_t {
+            const bool half = cv == CLS_LONG32;
+            const char *timer = half ? (tb ? "align_long32" : "align_score_long32") : (tb ? "align_long" : "align_score_long");
+            const size_t nl = class_list(cls_arr, cv);               // (waits for the stream: the task records are written)
             if (!nl) return 0;
-            note_list(tb ? "align_long" : "align_score_long", tasks.p, long_list.p, nl);
+            note_list(timer, tasks.p, long_list.p, nl);
             hipLaunchKernelGGL(list_ext_kernel, dim3((unsigned)std::min<size_t>(cdiv(nl, (size_t)WG), 1024)), dim3(WG), 0, stream(), tasks.p,
                                long_list.p, nl, lb_bases.p + N_LB);
             long_launches.emplace_back(new LongLaunch());
             LongLaunch &L = *long_launches.back();
-            {   // longest first: the work queue then ends with the short tasks
+            {   // longest first: the work queue then ends with the short tasks (and the two tasks of a wave are equally long)
                 DBuf<uint32_t> key(nl);
                 hipLaunchKernelGGL(task_rows_desc_key_kernel, grid1(nl), dim3(WG), 0, stream(), tasks.p, long_list.p, nl, key.p);
                 L.list.alloc(nl);
                 HIP_CHECK(hipMemcpyAsync(L.list.p, long_list.p, nl * 4, hipMemcpyDeviceToDevice, stream()));
                 sort_pairs_u32_u32(key, L.list, nl, 0, 16);
             }
-            const unsigned nb = (unsigned)std::min<size_t>((nl + WAVES - 1) / WAVES, LONG_BLOCKS_MAX);
+            const size_t units = half ? (nl + 1) / 2 : nl;           // waves' worth of work
+            const unsigned nb = (unsigned)std::min<size_t>((units + WAVES - 1) / WAVES, LONG_BLOCKS_MAX);
             const size_t n_waves = (size_t)nb * WAVES;
             LongArgs la{};
             if (tb) {
                 L.planes.alloc(n_waves * (size_t)N_WPLANES * long_chunks_cap * 64);
-                L.runs.alloc(n_waves * (size_t)long_runs_cap);
+                L.runs.alloc(n_waves * (size_t)long_runs_cap * (half ? 2 : 1));
                 la.planes = L.planes.p; la.run_scratch = L.runs.p;
             }
             la.chunks_cap = long_chunks_cap; la.runs_cap = long_runs_cap; la.zdrop = o.zdrop;
-            L.ctl.alloc(2);
+            L.ctl.alloc(4);
             L.ctl.zero();
             sync();                                                  // list, keys and control words are in place: over to the side stream
-            la.next = L.ctl.p; la.too_long = L.ctl.p + 1;
+            la.next = L.ctl.p; la.too_long = L.ctl.p + 1; la.rows_run = (unsigned long long *)(L.ctl.p + 2);
             AlignArgs al = aa;
             al.list = L.list.p; al.n_list = nl;
             {
                 hipStream_t ls = hook("HLMI_LONG_MAIN_STREAM") ? stream() : side_stream();      // (tuning: no second stream)
-                KTimer kt(tb ? "align_long" : "align_score_long", ls);
+                KTimer kt(timer, ls);
                 const bool two = aa.go2 > 0;
-                if (tb) {
-                    if (two) hipLaunchKernelGGL((align_long_kernel<true, true>), dim3(nb), dim3(WG), 0, ls, al, la);
-                    else hipLaunchKernelGGL((align_long_kernel<false, true>), dim3(nb), dim3(WG), 0, ls, al, la);
+                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nb), dim3(WG), 0, ls, al, la); };
+                if (half) {
+                    if (tb) { if (two) go(align_long32_kernel<true, true>); else go(align_long32_kernel<false, true>); }
+                    else { if (two) go(align_long32_kernel<true, false>); else go(align_long32_kernel<false, false>); }
                 } else {
-                    if (two) hipLaunchKernelGGL((align_long_kernel<true, false>), dim3(nb), dim3(WG), 0, ls, al, la);
-                    else hipLaunchKernelGGL((align_long_kernel<false, false>), dim3(nb), dim3(WG), 0, ls, al, la);
+                    if (tb) { if (two) go(align_long_kernel<true, true>); else go(align_long_kernel<false, true>); }
+                    else { if (two) go(align_long_kernel<true, false>); else go(align_long_kernel<false, false>); }
                 }
             }
             HIP_CHECK(hipGetLastError());
             long_pending = true;
             return nl;
         };
+        auto run_long = [&](const uint8_t *cls_arr, bool tb) -> size_t {
+            if (aa.ungapped) return run_ungapped(cls_arr, tb);       // (no LONG class there: every DP task is CLS_UNGAPPED)
+            // both lists first, then the launches: list building behind a running long kernel is slowed down tenfold
+            const size_t n32 = run_long_class(cls_arr, tb, CLS_LONG32);
+            return n32 + run_long_class(cls_arr, tb, CLS_LONG);
+        };
         // after a join and a wait for the stream: did a LONG task exceed its scratch area?
         auto check_long = [&]() {
-            for (auto &L : long_launches)
-                if (L->ctl.n && L->ctl.download(2)[1]) fail(HLMI_EINVAL, "an alignment task exceeds the scratch area of align_long_kernel");
+            for (auto &L : long_launches) {
+                if (!L->ctl.n) continue;
+                const std::vector<uint32_t> c = L->ctl.download(4);
+                if (c[1]) fail(HLMI_EINVAL, "an alignment task exceeds the scratch area of align_long_kernel");
+                long_rows_run += (double)((unsigned long long)c[3] << 32 | c[2]);
+                L->ctl.release();                                  // (read once)
+            }
         };
         // the tasks of stub candidates (cls_bare): score-only kernels over their own four lists
         size_t n_bare_tasks = 0;
@@ -2605,6 +2925,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         stat_add("align_bases_wide", (double)h[ST_BASES_WIDE]);
         stat_add("align_bases_long", (double)h[ST_BASES_LONG]);
         const std::vector<unsigned long long> lb = lb_bases.download(N_LB + 2);
+        stat_add("align_long_rows_run", long_rows_run);
         stat_add("align_long_ext", (double)lb[N_LB]);
         stat_add("align_long_ext_rows", (double)lb[N_LB + 1]);
         for (int k = 0; k < N_LB; ++k)
@@ -2658,15 +2979,58 @@ namespace hlmi {
 // The CIGAR run pool and the task lists of one alignment pass are indexed with 32 bits: a batch with more tasks than
 // that allows (many short pieces per anchor: divergent read sets) is aligned in spans of consecutive pieces.
 void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
-                  const ChainOut &ch, std::vector<AlignOut> &outs) {
+                  const ChainOut &ch_in, std::vector<AlignOut> &outs, DeferredPieces *defer) {
+    if (!ch_in.n_pieces) return;
+    // Pieces with LONG tasks are set aside (see piece_long_flag_kernel) when they are few: a batch where most pieces have one
+    // (divergent read sets: C5) keeps them - its long launches are large enough by themselves.
+    ChainOut kept;
+    const ChainOut *chp = &ch_in;
+    if (defer && o.bandwidth != 0) {
+        const size_t P0 = ch_in.n_pieces;
+        DBuf<uint8_t> flag(P0), nflag(P0);
+        hipLaunchKernelGGL(piece_long_flag_kernel, dim3((unsigned)std::min<size_t>(cdiv(P0, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
+                           ch_in.pieces.p, P0, ch_in.fps.p, d_qlen, d_tlen, ext_rows(o), flag.p);
+        DBuf<uint32_t> lidx(P0);
+        const size_t n_long = select_flagged_indices(flag.p, lidx.p, P0);
+        if (n_long && n_long * 10 <= P0) {
+            // the set-aside pieces, with their fixed points, behind what earlier batches left
+            DeferredPieces::Part part;
+            part.pieces.alloc(n_long);
+            DBuf<uint32_t> nfp(n_long), off(n_long);
+            hipLaunchKernelGGL(gather_pieces_kernel, grid1(n_long), dim3(WG), 0, stream(), ch_in.pieces.p, lidx.p, n_long, part.pieces.p, nfp.p);
+            exclusive_scan_u32(nfp.p, off.p, n_long);
+            const size_t n_fp_long = (size_t)download_one(off.p + (n_long - 1)) + (size_t)download_one(nfp.p + (n_long - 1));
+            part.fps.alloc(n_fp_long);
+            if (defer->n_fp + n_fp_long >= (1ull << 32)) fail(HLMI_EINVAL, "more than 2^32 fixed points in the set-aside alignment pieces");
+            hipLaunchKernelGGL(move_fixed_points_kernel, dim3((unsigned)std::min<size_t>(cdiv(n_long, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
+                               part.pieces.p, n_long, off.p, (uint32_t)defer->n_fp, ch_in.fps.p, part.fps.p);
+            part.n_pieces = n_long; part.n_fp = n_fp_long;
+            defer->n_pieces += n_long; defer->n_fp += n_fp_long;
+            defer->parts.push_back(std::move(part));
+            // the others, in their order (the fixed points stay where they are)
+            hipLaunchKernelGGL(class_flag_kernel, grid1(P0), dim3(WG), 0, stream(), flag.p, P0, (uint8_t)0, nflag.p);
+            DBuf<uint32_t> kidx(P0);
+            const size_t n_keep = select_flagged_indices(nflag.p, kidx.p, P0);
+            kept.pieces.alloc(n_keep ? n_keep : 1);
+            if (n_keep) hipLaunchKernelGGL(gather_pieces_kernel, grid1(n_keep), dim3(WG), 0, stream(), ch_in.pieces.p, kidx.p, n_keep, kept.pieces.p,
+                                           (uint32_t *)nullptr);
+            HIP_CHECK(hipGetLastError());
+            sync();
+            kept.n_pieces = n_keep; kept.n_fp = ch_in.n_fp - n_fp_long;
+            stat_add("align_pieces_deferred", (double)n_long);
+            if (!n_keep) return;
+            chp = &kept;
+        }
+    }
+    const ChainOut &ch = *chp;
+    const FixPt *fps_base = ch_in.fps.p;                      // (kept pieces still index the batch's fixed points)
     const size_t P = ch.n_pieces;
-    if (!P) return;
     size_t span_tasks = 64u << 20;               // (x 12 runs, x 4 once when a span overflows its pool: below 2^32)
     if (const char *e = hook("HLMI_ALIGN_SPAN_TASKS")) span_tasks = (size_t)std::max(64, atoi(e));      // test hook
     const size_t NT = ch.n_fp + P;
     if (NT <= span_tasks) {
         AlignOut ao;
-        align_span(in, o, d_qlen, d_tlen, PieceSpan{{ch.pieces.p}, P, ch.n_fp, {ch.fps.p}}, ao);
+        align_span(in, o, d_qlen, d_tlen, PieceSpan{{ch.pieces.p}, P, ch.n_fp, {fps_base}}, ao);
         if (ao.n_rows) outs.push_back(std::move(ao));
         return;
     }
@@ -2688,7 +3052,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             t1 = p1 < P ? (size_t)download_one(toff.p + p1) : NT;
         }
         AlignOut ao;
-        align_span(in, o, d_qlen, d_tlen, PieceSpan{{ch.pieces.p + p0}, p1 - p0, (t1 - t0) - (p1 - p0), {ch.fps.p}}, ao);
+        align_span(in, o, d_qlen, d_tlen, PieceSpan{{ch.pieces.p + p0}, p1 - p0, (t1 - t0) - (p1 - p0), {fps_base}}, ao);
         if (ao.n_rows) outs.push_back(std::move(ao));
         p0 = p1; t0 = t1;
     }

@@ -58,8 +58,17 @@ struct AlignOut {
     DBuf<uint32_t> ops;
     DBuf<uint64_t> ord_hi, ord_lo;   // stream-order keys of each row
 };
-// appends the rows of the batch's pieces (one AlignOut, or one per span of pieces when the batch has too many tasks)
+// Pieces with LONG alignment tasks (blocks of more than BLOCK_MAX rows or columns, extensions of more than EXT_MAX rows), set
+// aside batch after batch: they are aligned together at the end of the run (ava_align.hip: piece_long_flag_kernel).  The
+// fp_off of a set-aside piece counts from the start of the concatenated fixed points of all parts.
+struct DeferredPieces {
+    struct Part { size_t n_pieces = 0, n_fp = 0; DBuf<Piece> pieces; DBuf<FixPt> fps; };
+    std::vector<Part> parts;
+    size_t n_pieces = 0, n_fp = 0;
+};
+// appends the rows of the batch's pieces (one AlignOut, or one per span of pieces when the batch has too many tasks);
+// defer != nullptr: the pieces with LONG tasks go there instead (when they are a small share of the batch)
 void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_qlen, const uint32_t *d_tlen,
-                  const ChainOut &ch, std::vector<AlignOut> &outs);
+                  const ChainOut &ch, std::vector<AlignOut> &outs, DeferredPieces *defer = nullptr);
 
 }  // namespace hlmi

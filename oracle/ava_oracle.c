@@ -43,6 +43,8 @@ typedef struct {
 #define NARROW_DELTA 5
 #define EXT_MAX      256     /* rows of an end extension: max(EXT_MAX, max_gap) (ext_rows())   */
 #define ZDROP_STEP   32      /* the z-drop test runs after rows 32, 64, ...                 */
+#define HALF_W       32      /* diagonals of a LONG extension and of a LONG block with |delta| <= HALF_DELTA */
+#define HALF_DELTA   7
 #define MAX_MID_OCC  1000000
 #define NEG_INF      (-(1 << 29))
 
@@ -50,8 +52,11 @@ typedef struct {
  * length and extends chain ends until a z-drop or max_gap bases; so does the specification:
  *   - a block may have any number of rows / columns (a chain link spans at most max_gap); only a diagonal shift above
  *     BAND_W - 2 BAND_PAD - 1 = 39 between two fixed points still splits a chain into two pieces (the band has 64 diagonals);
- *     blocks with more than BLOCK_MAX rows or columns (LONG blocks) take a band of 64 diagonals centred on the two corners;
- *   - an end extension runs over up to max(EXT_MAX, max_gap) rows and stops at a z-drop (ava_opts_t::zdrop).
+ *     blocks with more than BLOCK_MAX rows or columns (LONG blocks) take a band centred on the two corners' diagonals: 32
+ *     diagonals when the shift is at most 7 (pad >= 12), else 64;
+ *   - an end extension runs over up to max(EXT_MAX, max_gap) rows and stops at a z-drop (ava_opts_t::zdrop); one that can run
+ *     more than EXT_MAX rows (LONG extension: min(rows, columns + 31) > EXT_MAX) takes a band of 32 diagonals (-15 .. +16)
+ *     instead of 64 (-31 .. +32).
  * MEASUREMENT switches (tests/test_deviation_effects.py only; the specification is the defaults):
  *   ORACLE_BLOCK_MAX   rows / cols above which a block splits its chain (none; 256 = the specification up to round 3)
  *   ORACLE_SHIFT_MAX   diagonal shift of one block (39); wider blocks get a band of shift + 2 pad + 1
@@ -465,8 +470,8 @@ static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t,
     const int ad = delta < 0 ? -delta : delta;
     const int lng = m > BLOCK_MAX || n > BLOCK_MAX;              /* LONG block: 64 diagonals centred on the corners' diagonals */
     int narrow = !lng && ad <= NARROW_DELTA;
-    int W = narrow ? NARROW_W : BAND_W;
-    if (!narrow && ad + 2 * BAND_PAD + 1 > W) W = ad + 2 * BAND_PAD + 1;   /* measurement only */
+    int W = narrow ? NARROW_W : (lng && ad <= HALF_DELTA ? HALF_W : BAND_W);
+    if (!narrow && !(lng && ad <= HALF_DELTA) && ad + 2 * BAND_PAD + 1 > W) W = ad + 2 * BAND_PAD + 1;   /* measurement only */
     int dlo = (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : lng ? (W - 1 - ad) / 2 : BAND_PAD);
     if (g_ungapped) { W = 1; dlo = 0; }                          /* (delta == 0: block_ok) the diagonal is the band */
     p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, W, 0, -1, 0, 0, scratch, &nr);
@@ -500,12 +505,21 @@ static void emit_piece(FILE *out, const ava_opts_t *o, const seqset_t *Q, int qi
     p->score = 0;
 }
 
+/* diagonals of an end extension over m rows and n columns: a LONG extension - one whose 64-diagonal band (-31 .. +32) stays
+ * inside the target for more than EXT_MAX rows - takes 32 diagonals (-15 .. +16) */
+static int ext_band(int m, int n) {
+    if (g_ext_band != BAND_W) return g_ext_band;                 /* (measurement switch) */
+    const int rows = m < n + (BAND_W / 2 - 1) ? m : n + (BAND_W / 2 - 1);
+    return rows > EXT_MAX ? HALF_W : BAND_W;
+}
+
 static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t, piece_t *p) {
     const int xm = ext_rows(o);
     int m = p->qs < xm ? p->qs : xm, n = p->ts < xm + g_ext_band ? p->ts : xm + g_ext_band, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
     uint32_t *scratch = (uint32_t *)malloc((size_t)(m + n + 2) * 4);
-    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, g_ungapped ? 0 : -(g_ext_band / 2 - 1), g_ungapped ? 1 : g_ext_band, 1,
+    const int xw = ext_band(m, n);
+    int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, g_ungapped ? 0 : -(xw / 2 - 1), g_ungapped ? 1 : xw, 1,
                      p->qs <= xm ? p->qs : -1, &bi, &bj, scratch, &nr);
     if (g_last_rank <= 0 || nr == 0) { free(scratch); return; }   /* nothing gained (the end bonus counts here, not in the score) */
     /* rev_ops run from the far end towards the fixed point on reversed sequences = forward order */
@@ -524,7 +538,8 @@ static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const ui
     int n = tl - p->te < xm + g_ext_band ? tl - p->te : xm + g_ext_band, bi, bj, nr;
     if (m <= 0 || n <= 0) return;
     uint32_t *scratch = (uint32_t *)malloc((size_t)(m + n + 2) * 4);
-    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, g_ungapped ? 0 : -(g_ext_band / 2 - 1), g_ungapped ? 1 : g_ext_band, 1,
+    const int xw = ext_band(m, n);
+    int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, g_ungapped ? 0 : -(xw / 2 - 1), g_ungapped ? 1 : xw, 1,
                      ql - p->qe <= xm ? ql - p->qe : -1, &bi, &bj, scratch, &nr);
     if (g_last_rank > 0 && nr != 0) {          /* (else nothing gained: the end bonus counts here, not in the score) */
         for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);

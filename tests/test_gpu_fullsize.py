@@ -36,11 +36,9 @@ def _slice_rows(path):
         return sum(1 for _ in f)
 
 
-def test_c5_full_size_complete_pass(tmp_path):
-    """A COMPLETE pass over C5: all 60 --nsplit chunks x all 500 000 queries in one hlmi_job_run (the stage cuts it into
-    sub-runs by itself), then again as two rank shares (chunks c % 2) whose merged output must be the same file."""
-    if _free_gb(tmp_path) < 12 or _host_gb() < 24:
-        pytest.skip("needs 12 GB of scratch space and 24 GB of host memory")
+def _c5_share(tmp_path, share, halves, min_cand):
+    """`share` = (k, n) of C5's 60 chunks x all 500 000 queries in one hlmi_job_run (the stage cuts it into sub-runs by itself),
+    then again as the two shares `halves` that make it up: their rows add up and their merge is the same file."""
     cfg = W.config("C5")
     fa = str(tmp_path / "c5.fa")
     t0 = time.time()
@@ -57,23 +55,24 @@ def test_c5_full_size_complete_pass(tmp_path):
         r.prepare()
         t_sketch = time.time() - t0
         t0 = time.time()
-        rows = r.run(out, share=(0, 1), **cfg["stage"])            # every chunk
+        rows = r.run(out, share=share, **cfg["stage"])
         t_run = time.time() - t0
         st = api.last_stats()
-        print(f"C5 full size: simulate {t_sim:.1f} s, parse + upload {t_open:.1f} s, sketch of 5 Gbases {t_sketch:.2f} s, COMPLETE pass (60 chunks) "
-              f"{t_run:.1f} s -> {rows} overlaps; anchors {st['anchors']:.3g}, candidate rows {st['ava_rows']:.3g}, LONG tasks "
-              f"{st.get('align_tasks_long', 0):.3g}, sub-runs {st['subruns']:.0f} (refused {st.get('subruns_refused', 0):.0f}), "
+        n_chunks = len(range(share[0], 60, share[1]))
+        print(f"C5 full size: simulate {t_sim:.1f} s, parse + upload {t_open:.1f} s, sketch of 5 Gbases {t_sketch:.2f} s, {n_chunks} of 60 chunks "
+              f"(c % {share[1]} == {share[0]}) {t_run:.1f} s -> {rows} overlaps; anchors {st['anchors']:.3g}, candidate rows {st['ava_rows']:.3g}, "
+              f"LONG tasks {st.get('align_tasks_long', 0):.3g}, sub-runs {st['subruns']:.0f} (refused {st.get('subruns_refused', 0):.0f}), "
               f"HBM high-water mark {st['hbm_peak_in_use_gb']:.0f} GB", flush=True)
-        assert st["queries"] == 500_000 and st["chunks_run"] == 60 and st["targets"] == 500_000
-        assert st["minimizers_q"] > 1.2e9 and st["anchors"] > 1e11 and st["ava_rows"] > 1e8
+        assert st["queries"] == 500_000 and st["chunks_run"] == n_chunks
+        assert st["minimizers_q"] > 1.2e9 and st["ava_rows"] > min_cand and st["align_tasks_long"] > st["ava_rows"]
         assert st.get("subruns_refused", 0) == 0 and 0 < st["hbm_peak_in_use_gb"] < 288
         assert rows == _slice_rows(out) == st["rows_out"]
-        check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 100)
-        # the same pass as the shares of a 2-rank job: rows == sum of the slices, merged file == the pass's file
+        check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 0)
         parts = []
-        for k in range(2):
+        for k, sh in enumerate(halves):
             part = str(tmp_path / f"pass.part{k}")
-            r.run(part, share=(k, 2), **cfg["stage"])
+            r.run(part, share=sh, **cfg["stage"])
+            print(f"  share {sh}: {api.last_stats()['t_total_s']:.1f} s", flush=True)
             parts.append(part)
         assert sum(_slice_rows(p) for p in parts) == rows
         api.merge_scored_paf(parts, str(tmp_path / "merged.paf"))
@@ -81,6 +80,23 @@ def test_c5_full_size_complete_pass(tmp_path):
     finally:
         r.close()
     os.remove(fa)
+
+
+def test_c5_full_size_sixth_of_a_pass(tmp_path):
+    """Ten of C5's 60 chunks, spread over the file (c % 6 == 1: what one rank of a 6-rank job computes), and the same as two
+    shares of a 12-rank job."""
+    if _free_gb(tmp_path) < 12 or _host_gb() < 24:
+        pytest.skip("needs 12 GB of scratch space and 24 GB of host memory")
+    _c5_share(tmp_path, (1, 6), [(1, 12), (7, 12)], 1e8)
+
+
+@pytest.mark.skipif(not os.environ.get("HL_FULL_PASS"), reason="a COMPLETE C5 pass takes ~10 minutes on one card: HL_FULL_PASS=1 "
+                    "(run once per round, log under profiles/)")
+def test_c5_full_size_complete_pass(tmp_path):
+    """All 60 chunks x all 500 000 queries, and again as the two shares of a 2-rank job."""
+    if _free_gb(tmp_path) < 12 or _host_gb() < 24:
+        pytest.skip("needs 12 GB of scratch space and 24 GB of host memory")
+    _c5_share(tmp_path, (0, 1), [(0, 2), (1, 2)], 1e9)
 
 
 def test_c4_full_size_long_reads_one_rank_share(tmp_path):
