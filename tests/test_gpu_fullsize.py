@@ -132,7 +132,9 @@ def test_c4_full_size_long_reads_one_rank_share(tmp_path):
           f"{st['hbm_peak_in_use_gb']:.0f} GB", flush=True)
     assert st["queries"] == 1_000_000 and 120 <= st["chunks_run"] <= 125 and 120_000 < st["targets"] < 126_000
     assert st["anchors"] > 1e11 and st["minimizers_q"] > 2e9 and st["ava_rows"] > 2e8
-    assert st.get("subruns_refused", 0) == 0 and 0 < st["hbm_peak_in_use_gb"] < 288
+    # (a sub-run whose anchors or output turn out above its budget is given up after the counting pass / the first query batch
+    #  and retried smaller - it leaves no trace in the counts; the estimates from the sub-runs before it should make that rare)
+    assert st.get("subruns_refused", 0) <= 0.1 * st["subruns"] and 0 < st["hbm_peak_in_use_gb"] < 288
     assert rows == _slice_rows(out) == st["rows_out"]
     # (at 5 000x pooled depth the mc = 2 support filter leaves next to nothing of the candidate rows)
     check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 0)
