@@ -1,7 +1,8 @@
 """GPU: BASELINE.json configs[4] (C5) and configs[3] (C4, long reads) at their FULL size - 500 000 reads on 50 strains x 2 Mb
 with --min_identity 0.90 --min_ovlp_len 1500, and 1 000 000 long reads on 100 strains x 2 Mb - each through the entry point
 a rank of the multi-GPU job uses (hlmi_job_run).  The complete read set is resident in HBM and sketched (all 5 / 10 Gbases
-are queries of every chunk).  Round 4: C5 as a COMPLETE pass (all 60 chunks; and as two rank shares whose merge equals it),
+are queries of every chunk).  Round 4: C5 as one rank's share of an 8-rank job (8 chunks; and as two shares whose merge equals it; the COMPLETE pass
+of 60 chunks with HL_FULL_PASS=1),
 C4's long reads as the share one rank of an 8-rank job computes (125 of the 1 000 chunks) - row predicates, rows == sum of
 the slices, no refused sub-run, the HBM high-water mark of the pass.  The read sets are made by the block-parallel simulator
 (hylight_amd/simulate.py:simulate_reads_to_fasta) in seconds."""
@@ -82,12 +83,12 @@ def _c5_share(tmp_path, share, halves, min_cand):
     os.remove(fa)
 
 
-def test_c5_full_size_sixth_of_a_pass(tmp_path):
-    """Ten of C5's 60 chunks, spread over the file (c % 6 == 1: what one rank of a 6-rank job computes), and the same as two
-    shares of a 12-rank job."""
+def test_c5_full_size_one_rank_share(tmp_path):
+    """Eight of C5's 60 chunks, spread over the file (c % 8 == 1: what one rank of an 8-rank job computes), and the same as two
+    shares of a 16-rank job."""
     if _free_gb(tmp_path) < 12 or _host_gb() < 24:
         pytest.skip("needs 12 GB of scratch space and 24 GB of host memory")
-    _c5_share(tmp_path, (1, 6), [(1, 12), (7, 12)], 1e8)
+    _c5_share(tmp_path, (1, 8), [(1, 16), (9, 16)], 1e8)
 
 
 @pytest.mark.skipif(not os.environ.get("HL_FULL_PASS"), reason="a COMPLETE C5 pass takes ~10 minutes on one card: HL_FULL_PASS=1 "
