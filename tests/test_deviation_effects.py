@@ -154,6 +154,34 @@ def test_c5_bounded_blocks_and_extensions(c5_sample):
     assert res["shift<=2000"][0] == spec_rows
 
 
+def test_fixed_predecessor_window_on_divergent_and_short_reads(c5_sample, tmp_path):
+    """The fixed 64-predecessor window against minimap2's published predecessor loop (--max-chain-skip 25, 5000 iterations;
+    ORACLE_CHAIN_MM2) where chains are sparse: the C5 sample (divergent long reads) and short reads against contig pieces
+    with the short-mode constants (-n 2 -m 30).  On the samples of DESIGN.md section 5 (6 targets x 1 500 C5 queries; 6
+    contigs x 200 000 short reads) every row is the same: 2 937 / 2 937 and 503 078 / 503 078."""
+    from hylight_amd import simulate as S, workloads as W
+    d, q, t, _ = c5_sample
+    a = _run5(q, t, str(d / "w64.paf"))[0]
+    b = _run5(q, t, str(d / "mm2.paf"), {"ORACLE_CHAIN_MM2": "1"})[0]
+    r = _compare(a, b)
+    print("C5 sample, fixed window vs minimap2-style loop:", r)
+    assert r["rows_a"] > 300 and r["identical"] >= 0.995 * max(r["rows_a"], r["rows_b"])
+    cfg = W.config("C4", 0.002)
+    _, _, strains = W.make_long(dict(cfg, sim=dict(cfg["sim"], n_reads=10)), str(tmp_path / "unused.fa"))
+    W.make_short(cfg, strains, str(tmp_path / "short.fa"))
+    contigs = [S.Read(f"longr_con_{k}", g[:40_000].copy(), None, k, 0, 40_000, False) for k, g in enumerate(strains[:4])]
+    S.write_fasta(contigs, str(tmp_path / "con.fa"))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom oracle import ava as OA\nOA.ava(%r, %r, sys.argv[1], OA.opts_short())\n"
+            % (ROOT, str(tmp_path / "con.fa"), str(tmp_path / "short.fa")))
+    out = {}
+    for tag, env in (("w64", {}), ("mm2", {"ORACLE_CHAIN_MM2": "1"})):
+        subprocess.run([sys.executable, "-c", code, str(tmp_path / (tag + ".paf"))], check=True, env=dict(os.environ, **env))
+        out[tag] = open(tmp_path / (tag + ".paf")).read().split("\n")[:-1]
+    r = _compare(out["w64"], out["mm2"])
+    print("short reads vs contigs, fixed window vs minimap2-style loop:", r)
+    assert r["rows_a"] > 2_000 and r["identical"] >= 0.995 * max(r["rows_a"], r["rows_b"])
+
+
 def test_c5_stub_rule_changes_no_final_row(c5_sample):
     from oracle import filters as F
     d, q, t, stage = c5_sample
