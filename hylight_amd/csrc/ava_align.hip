@@ -2785,8 +2785,13 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         // the LONG tasks first, on the side stream, and the score-only tasks of the stub candidates: everything below runs beside them
         // (the candidates' few LONG tasks first: list building behind a running align_long_kernel is slowed down tenfold - the
         //  long kernel's first round of tasks fills every SIMD)
-        run_bare_long();
-        n_long_tb += run_long(cls.p, true);
+        // (the classifier counted them: most batches of a clean read set have none left once their pieces are set aside, and
+        //  building an empty list is four passes over the class arrays)
+        unsigned long long long_seen = astats.download(N_ALIGN_STATS)[ST_LONG];
+        if (long_seen || aa.ungapped) {
+            run_bare_long();
+            n_long_tb += run_long(cls.p, true);
+        }
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
         if (n1 && packed) {
             // the list is in ascending row order: its head (fewer than NR_SMALL rows, counted by the classifier)
@@ -2879,13 +2884,15 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                                    bare ? cls_bare.p : nullptr, tasks.p, NT, lb_bases.p);
                 if (bare) {                        // (every late task belongs to a candidate)
                     const size_t before = n_bare_tasks;
-                    run_bare(true);
+                    const bool more_long = astats.download(N_ALIGN_STATS)[ST_LONG] > long_seen || aa.ungapped;
+                    run_bare(more_long);
                     n_wide_late = n_bare_tasks - before;
                 } else {
                     select_classes4_async(cls.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
                     const std::vector<uint32_t> hl = list_n.download(4);
                     run_wide(hl[1], hl[3]);
-                    const size_t nl = run_long(cls.p, true);
+                    const bool more_long = astats.download(N_ALIGN_STATS)[ST_LONG] > long_seen || aa.ungapped;
+                    const size_t nl = more_long ? run_long(cls.p, true) : 0;
                     n_long_tb += nl;
                     n_wide_late = (size_t)hl[1] + hl[3] + nl;
                 }
