@@ -370,6 +370,13 @@ def main():
         tot = torch.tensor([float(rows)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         rows = int(tot[0])
+    # the one exchange step of the path, per rank: seconds of sketch + all-gather per pass start, bytes received, rounds
+    mine = dict(rank=rank, sketch_exchange_s=[round(x, 4) for x in t_prepare], bytes_received=int(getattr(runner, "exchange_bytes", 0)),
+                rounds=int(getattr(runner, "exchange_rounds", 0)))
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -449,6 +456,7 @@ def main():
                 step_ms=[round(1e3 * x, 1) for x in step_s],
                 e2e=dict(open_parse_upload_s=round(t_open, 3), pass_s=round(pass_s, 3), pass_overlaps=int(pass_rows),
                          sketch_exchange_s=[round(x, 4) for x in t_prepare]),
+                exchange=dict(world=(dist.get_world_size() if world > 1 else 1), backend=(backend if world > 1 else None), per_rank=per_rank),
                 stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})
     # second half of the BASELINE metric: overlap-graph build seconds (PAF on disk -> GFA on disk), not part of `value`
     if not args.no_graph and not short_calls:

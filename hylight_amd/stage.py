@@ -33,6 +33,7 @@ class StageRunner:
         self.job = job if job is not None else api.Job(reads_fa, ref_fa, nsplit, long_mode)
         self._keep = None
         self.exchange_rounds = 0
+        self.exchange_bytes = 0          # bytes this rank received in the last exchange (minimizers + per-read counts)
 
     def close(self):
         self.job.close()
@@ -105,6 +106,7 @@ class StageRunner:
                 if q_of[r]:
                     all_cnt[qbase:qbase + q_of[r]].copy_(crecv[r * max_q:r * max_q + q_of[r]])
                 qbase += q_of[r]
+            self.exchange_bytes = 16 * (total - n) + 4 * (nq - (hi - lo))
         if dev == "cuda":
             torch.cuda.synchronize()
         self._keep = (all_mz, all_cnt)          # the library reads these buffers during run()
