@@ -2681,9 +2681,8 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                 KTimer kt(timer, ls);
                 const bool two = aa.go2 > 0;
                 auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nb), dim3(WG), 0, ls, al, la); };
-                if (half) {
-                    if (tb) { if (two) go(align_long32_kernel<true, true>); else go(align_long32_kernel<false, true>); }
-                    else { if (two) go(align_long32_kernel<true, false>); else go(align_long32_kernel<false, false>); }
+                if (half) {        // (the 32-diagonal band knows the first piece of the gap cost alone: section 5 of DESIGN.md)
+                    if (tb) go(align_long32_kernel<false, true>); else go(align_long32_kernel<false, false>);
                 } else {
                     if (tb) { if (two) go(align_long_kernel<true, true>); else go(align_long_kernel<false, true>); }
                     else { if (two) go(align_long_kernel<true, false>); else go(align_long_kernel<false, false>); }

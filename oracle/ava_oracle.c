@@ -343,6 +343,7 @@ static inline int sub_score(const ava_opts_t *o, int a, int b) {
  * Cells: H = max(M, E, F) with priority M, E, F on ties; E (gap in query, consumes target, 'D'),
  * F (gap in target, consumes query, 'I'); open preferred over extend on ties. */
 static __thread int g_last_rank;
+static __thread int g_one_piece;      /* set by the callers of band_dp for a task in the 32-diagonal band of the LONG tasks */
 /* Two-piece gap cost (minimap2 -O4,24 -E2,1: filter_overlap_slr2.py:51 leaves the ava-pb preset's values in place): every
  * gap state exists once per piece, E = max(E1, E2), F = max(F1, F2) with the first piece on ties.  Traceback byte:
  * bits 0-1 source of H (0 M, 1 E, 2 F), bit 2 / 3 E1 / F1 extended, bit 4 / 5 E2 / F2 extended, bit 6 / 7 E / F is the
@@ -352,7 +353,9 @@ static int band_dp(const ava_opts_t *o, const uint8_t *q, int qstride, int m, co
     /* z-drop (extensions): after row i = 32, 64, ... the best cell of that row is held against the best cell so far; more
      * than zdrop below it (or no cell of the row inside the rectangle any more) ends the extension: rows > i do not exist */
     const int zdrop = mode == 1 ? o->zdrop : 0;
-    const int two = o->gap_open2 > 0;
+    /* the 32-diagonal band of the LONG tasks knows the first piece alone: a gap long enough for the second one (>= 20 bases
+     * with -O4,24 -E2,1) does not fit a band of +-15 around its diagonal except right across it */
+    const int two = o->gap_open2 > 0 && !g_one_piece;
     const int go[2] = {o->gap_open, two ? o->gap_open2 : o->gap_open}, ge[2] = {o->gap_ext, two ? o->gap_ext2 : o->gap_ext};
     int rows = m + 1;
     /* the matrices live in one buffer per thread that only grows: a malloc per call is an mmap + munmap for every block of
@@ -474,7 +477,9 @@ static void align_block(const ava_opts_t *o, const uint8_t *q, const uint8_t *t,
     if (!narrow && !(lng && ad <= HALF_DELTA) && ad + 2 * BAND_PAD + 1 > W) W = ad + 2 * BAND_PAD + 1;   /* measurement only */
     int dlo = (delta < 0 ? delta : 0) - (narrow ? NARROW_PAD : lng ? (W - 1 - ad) / 2 : BAND_PAD);
     if (g_ungapped) { W = 1; dlo = 0; }                          /* (delta == 0: block_ok) the diagonal is the band */
+    g_one_piece = lng && ad <= HALF_DELTA && !g_ungapped;
     p->score += band_dp(o, q + q0, 1, m, t + t0, 1, n, dlo, W, 0, -1, 0, 0, scratch, &nr);
+    g_one_piece = 0;
     for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
     free(scratch);
 }
@@ -519,8 +524,10 @@ static void extend_left(const ava_opts_t *o, const uint8_t *q, const uint8_t *t,
     if (m <= 0 || n <= 0) return;
     uint32_t *scratch = (uint32_t *)malloc((size_t)(m + n + 2) * 4);
     const int xw = ext_band(m, n);
+    g_one_piece = xw == HALF_W && g_ext_band == BAND_W && !g_ungapped;
     int sc = band_dp(o, q + p->qs - 1, -1, m, t + p->ts - 1, -1, n, g_ungapped ? 0 : -(xw / 2 - 1), g_ungapped ? 1 : xw, 1,
                      p->qs <= xm ? p->qs : -1, &bi, &bj, scratch, &nr);
+    g_one_piece = 0;
     if (g_last_rank <= 0 || nr == 0) { free(scratch); return; }   /* nothing gained (the end bonus counts here, not in the score) */
     /* rev_ops run from the far end towards the fixed point on reversed sequences = forward order */
     cigar_t pre = {0, 0, 0};
@@ -539,8 +546,10 @@ static void extend_right(const ava_opts_t *o, const uint8_t *q, int ql, const ui
     if (m <= 0 || n <= 0) return;
     uint32_t *scratch = (uint32_t *)malloc((size_t)(m + n + 2) * 4);
     const int xw = ext_band(m, n);
+    g_one_piece = xw == HALF_W && g_ext_band == BAND_W && !g_ungapped;
     int sc = band_dp(o, q + p->qe, 1, m, t + p->te, 1, n, g_ungapped ? 0 : -(xw / 2 - 1), g_ungapped ? 1 : xw, 1,
                      ql - p->qe <= xm ? ql - p->qe : -1, &bi, &bj, scratch, &nr);
+    g_one_piece = 0;
     if (g_last_rank > 0 && nr != 0) {          /* (else nothing gained: the end bonus counts here, not in the score) */
         for (int x = nr - 1; x >= 0; --x) cig_push(&p->cg, (int)scratch[x], 1);
         p->qe += bi; p->te += bj; p->score += sc;
