@@ -48,6 +48,7 @@ KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_n
                    "align_wide": "hlmi::align_kernel<256, true>", "align_wide_short": "hlmi::align_kernel<128, true>",
                    "align_score_wide": "hlmi::align_kernel<256, false>", "align_score_wide_short": "hlmi::align_kernel<128, false>",
                    "align_long": "hlmi::align_long_kernel<true, true>", "align_score_long": "hlmi::align_long_kernel<true, false>",
+                   "align_long32": "hlmi::align_long32_kernel<false, true>", "align_score_long32": "hlmi::align_long32_kernel<false, false>",
                    "align_classify": "hlmi::classify_kernel<1>", "assemble_write": "hlmi::assemble_kernel<true>",
                    "assemble_count": "hlmi::assemble_kernel<false>", "seed_fill": "hlmi::seed_kernel<true>",
                    "seed_count": "hlmi::seed_kernel<false>", "anchor_sort": "rocprim::radix_sort_onesweep",
