@@ -190,10 +190,12 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     // wrote them), beside ~45 GB of batch buffers, and a sub-run is only refused at 1.5 x its budget: with the reads, the
     // query sketch and the seed plan of a million long reads resident (84 GB on the full C4) the usual 64 GB do not fit
     // and the pool thrashes - the budget follows what is free when the pass starts
-    double SUBRUN_OUT_BYTES = 64e9;
+    double SUBRUN_OUT_BYTES = 52e9;
     if (const size_t avail = dev_available_bytes()) {
         const double plan = 12.0 * (m.qmz_off.empty() ? 0.0 : (double)m.qmz_off.back());        // count + run of every query minimizer
-        SUBRUN_OUT_BYTES = std::min(64e9, std::max(8e9, ((double)avail - plan - 50e9) / (1.3 * 1.5)));
+        // (round 4: whole-overlap CIGARs of divergent reads - a complete C5 pass peaked at 275 of the 288 GB with 64e9 and a
+        //  divisor of 1.3 x 1.5)
+        SUBRUN_OUT_BYTES = std::min(52e9, std::max(8e9, ((double)avail - plan - 60e9) / (1.5 * 1.5)));
     }
     stat_set("subrun_out_budget_gb", SUBRUN_OUT_BYTES / 1e9);
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
