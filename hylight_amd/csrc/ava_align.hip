@@ -2526,12 +2526,17 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         ext_all_long = (long long)o.match * (EXT_MAX - rows_down) > o.zdrop;
     }
     const uint32_t long_chunks_cap = (uint32_t)(long_rows_cap(o) + 31) / 32, long_runs_cap = (uint32_t)(2 * long_rows_cap(o) + 64);
-    constexpr unsigned LONG_BLOCKS_MAX = 256 * 8;     // 8 workgroups of 4 waves per CU: the walks of the tasks wait on memory
+    // 8 workgroups of 4 waves per CU: the walks of the tasks wait on memory.  (Fewer - to leave wave slots to the kernels on the
+    // compute stream - was measured on a C5 chunk: 1.46 s with 2 048 workgroups, 1.45 with 1 024, 1.40 with 512, 1.43 with the long
+    // kernels in line on the compute stream: the card is busy either way, what runs beside a kernel runs that much slower.)
+    constexpr unsigned LONG_BLOCKS_MAX = 256 * 8;
     // The LONG tasks of a batch are few (C3: ~10 000 per batch) and serial in their rows: alone on the card their launch lasts as
     // long as its longest task.  They run on the side stream beside the batch's other DP kernels; every launch keeps its own
     // list / scratch / control words until the streams are joined (join_long) in front of whatever reads the task results.
     struct LongLaunch { DBuf<uint32_t> list, planes, runs, ctl; };
     std::vector<std::unique_ptr<LongLaunch>> long_launches;
+    struct LongReady { AlignArgs al; LongArgs la; unsigned nb; bool half, tb; const char *timer; };
+    std::vector<LongReady> long_ready;                   // prepared, not yet launched
     hipEvent_t long_done = nullptr;
     bool long_pending = false;
     struct SideGuard {                                   // an exception on the way out must not free buffers the side stream still uses
@@ -2672,29 +2677,37 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             la.chunks_cap = long_chunks_cap; la.runs_cap = long_runs_cap; la.zdrop = o.zdrop;
             L.ctl.alloc(4);
             L.ctl.zero();
-            sync();                                                  // list, keys and control words are in place: over to the side stream
             la.next = L.ctl.p; la.too_long = L.ctl.p + 1; la.rows_run = (unsigned long long *)(L.ctl.p + 2);
             AlignArgs al = aa;
             al.list = L.list.p; al.n_list = nl;
-            {
-                hipStream_t ls = hook("HLMI_LONG_MAIN_STREAM") ? stream() : side_stream();      // (tuning: no second stream)
-                KTimer kt(timer, ls);
+            long_ready.push_back(LongReady{al, la, nb, half, tb, timer});
+            return nl;
+        };
+        // every prepared LONG launch goes to the side stream, after ALL their lists are built: a selection pass queued behind a
+        // running long kernel waits for the whole of it (its first round of tasks fills every SIMD; measured: a 40 us scan took
+        // 31 ms), and with it everything the compute stream was to run beside the long kernel
+        auto launch_long_ready = [&]() {
+            if (long_ready.empty()) return;
+            sync();                                                  // lists, keys and control words are in place
+            hipStream_t ls = hook("HLMI_LONG_MAIN_STREAM") ? stream() : side_stream();      // (tuning: no second stream)
+            for (const LongReady &r : long_ready) {
+                KTimer kt(r.timer, ls);
                 const bool two = aa.go2 > 0;
-                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nb), dim3(WG), 0, ls, al, la); };
-                if (half) {        // (the 32-diagonal band knows the first piece of the gap cost alone: section 5 of DESIGN.md)
-                    if (tb) go(align_long32_kernel<false, true>); else go(align_long32_kernel<false, false>);
+                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(r.nb), dim3(WG), 0, ls, r.al, r.la); };
+                if (r.half) {      // (the 32-diagonal band knows the first piece of the gap cost alone: section 5 of DESIGN.md)
+                    if (r.tb) go(align_long32_kernel<false, true>); else go(align_long32_kernel<false, false>);
                 } else {
-                    if (tb) { if (two) go(align_long_kernel<true, true>); else go(align_long_kernel<false, true>); }
+                    if (r.tb) { if (two) go(align_long_kernel<true, true>); else go(align_long_kernel<false, true>); }
                     else { if (two) go(align_long_kernel<true, false>); else go(align_long_kernel<false, false>); }
                 }
             }
             HIP_CHECK(hipGetLastError());
+            long_ready.clear();
             long_pending = true;
-            return nl;
         };
         auto run_long = [&](const uint8_t *cls_arr, bool tb) -> size_t {
             if (aa.ungapped) return run_ungapped(cls_arr, tb);       // (no LONG class there: every DP task is CLS_UNGAPPED)
-            // both lists first, then the launches: list building behind a running long kernel is slowed down tenfold
+            // (prepared only: launch_long_ready() starts them)
             const size_t n32 = run_long_class(cls_arr, tb, CLS_LONG32);
             return n32 + run_long_class(cls_arr, tb, CLS_LONG);
         };
@@ -2717,7 +2730,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         };
         auto run_bare = [&](bool with_long) {             // (the lists of the four classes are rebuilt here: after the kernels that use them)
             if (!bare) return;
-            if (with_long) run_bare_long();
+            if (with_long) { run_bare_long(); launch_long_ready(); }
             select_classes4_async(cls_bare.p, NT, list1.p, list2.p, list3.p, list4.p, list_n.p);
             const std::vector<uint32_t> hb = list_n.download(4);
             n_bare_tasks += (size_t)hb[0] + hb[1] + hb[2] + hb[3];
@@ -2790,6 +2803,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
         if (long_seen || aa.ungapped) {
             run_bare_long();
             n_long_tb += run_long(cls.p, true);
+            launch_long_ready();
         }
         // pass 2a: near-diagonal blocks, four per wave in the 16-diagonal band
         if (n1 && packed) {
@@ -2892,6 +2906,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                     run_wide(hl[1], hl[3]);
                     const bool more_long = astats.download(N_ALIGN_STATS)[ST_LONG] > long_seen || aa.ungapped;
                     const size_t nl = more_long ? run_long(cls.p, true) : 0;
+                    launch_long_ready();
                     n_long_tb += nl;
                     n_wide_late = (size_t)hl[1] + hl[3] + nl;
                 }
