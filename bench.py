@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 
 # the hybrid pipeline (script/HyLight.py:200,207) over C4's short reads, 8 slices each
 SLICES = {"C3": 8, "C5": 64, "C4": 64, "C4s": 8}
 
-KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "align_narrow": "hlmi::align_narrow_pk_kernel<128, true>",
+KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "chain_small": "hlmi::chain_small_kernel", "align_narrow": "hlmi::align_narrow_pk_kernel<128, true>",
                    "align_narrow_small": "hlmi::align_narrow_pk_kernel<64, true>", "align_narrow_long": "hlmi::align_narrow_pk_kernel<256, true>",
                    "align_score_narrow": "hlmi::align_narrow_pk_kernel<128, false>", "align_score_narrow_long": "hlmi::align_narrow_pk_kernel<256, false>",
                    "align_wide": "hlmi::align_kernel<256, true>", "align_wide_short": "hlmi::align_kernel<128, true>",
@@ -398,7 +398,9 @@ def main():
     algo = {
         # every anchor read once, the alignment pieces (32 B) and their fixed points (8 B) written once; the DP's
         # own arrays are scratch, not counted
-        "chain": AB + 32 * P + 8 * stats.get("fixed_points", 0.0),
+        # (groups of at most 32 anchors go through chain_small_kernel: the bytes are split by the anchors of the two kinds)
+        "chain": (AB + 32 * P + 8 * stats.get("fixed_points", 0.0)) * (1.0 - (stats.get("anchors_small_groups", 0.0) / A if A else 0.0)),
+        "chain_small": (AB + 32 * P + 8 * stats.get("fixed_points", 0.0)) * (stats.get("anchors_small_groups", 0.0) / A if A else 0.0),
         "align_classify": stats.get("align_bases_classify", 0.0) + (32 + 24 + 1) * NT,
         "anchor_sort": 2 * AB,                         # one read + one write per anchor
         "seed_fill": 16 * M + 8 * A + AB,              # query minimizers, index occurrences (y), anchors out

@@ -355,13 +355,27 @@ __global__ void gather_u64_at_kernel(const uint64_t *src, const uint64_t *idx, u
 }
 // sort key that puts the big groups first: the hardware hands workgroups out in order, so the long groups start
 // early and the tail of a launch is made of small ones
-__global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, size_t n_anchors, uint32_t *key, uint32_t *order) {
+// groups of more than SMALL_N anchors go through chain_kernel (a wave per group), the others through chain_small_kernel (a lane
+// per group): tally[0] += groups above SMALL_N, tally[1] += anchors of the others (one atomic per wave)
+constexpr int SMALL_N = 32;
+__global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, size_t n_anchors, uint32_t *key, uint32_t *order,
+                                      unsigned long long *tally) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (g >= n_groups) return;
-    const size_t e = g + 1 < n_groups ? gstart[g + 1] : n_anchors;
-    const uint32_t sz = (uint32_t)(e - gstart[g]);
-    key[g] = 0xffffu - (sz < 0xffffu ? sz : 0xffffu);
-    order[g] = (uint32_t)g;
+    uint32_t sz = 0;
+    if (g < n_groups) {
+        const size_t e = g + 1 < n_groups ? gstart[g + 1] : n_anchors;
+        sz = (uint32_t)(e - gstart[g]);
+        key[g] = 0xffffu - (sz < 0xffffu ? sz : 0xffffu);
+        order[g] = (uint32_t)g;
+    }
+    const unsigned long long big = __ballot(sz > (uint32_t)SMALL_N);
+    uint32_t small_anchors = sz > (uint32_t)SMALL_N ? 0u : sz;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) small_anchors += __shfl_xor(small_anchors, o, 64);
+    if ((threadIdx.x & 63) == 0) {
+        if (big) atomicAdd(&tally[0], (unsigned long long)__popcll(big));
+        if (small_anchors) atomicAdd(&tally[1], (unsigned long long)small_anchors);
+    }
 }
 
 // HLMI_GROUP_HIST=1: groups and anchors per power-of-two size class (tuning aid, statistics group_hist_*)
@@ -1101,6 +1115,150 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) __attribute__((amdgpu_waves_per_e
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+// chains of the small groups: one LANE per group
+// ---------------------------------------------------------------------------------------------
+// chain_kernel spends a wave on a group: right for the groups of long reads (hundreds of anchors), 6 000 wave instructions for
+// the 14 anchors a short read leaves on a contig (C4s: 66 M groups a step, 360 ms).  A group of at most SMALL_N anchors is
+// chained by one lane instead, with the loops of the specification as they stand in oracle/ava_oracle.c (chain_group: every
+// predecessor of the group, closest first; best children; chains from their starts, cut at the peak; align_chain: fixed
+// points) over arrays in LDS ([anchor][lane]: conflict-free for the common index).  Groups arrive sorted by size, so the 64
+// groups of a wave run about equally long.  Pieces: the logic runs twice - first counting, then, after ONE slot request per
+// wave, writing.
+__global__ __launch_bounds__(64) void chain_small_kernel(ChainArgs a, size_t first, size_t count) {
+    __shared__ int s_t[SMALL_N][64], s_q[SMALL_N][64], s_f[SMALL_N][64];
+    __shared__ uint8_t s_sp[SMALL_N][64], s_p[SMALL_N][64], s_bc[SMALL_N][64], s_path[SMALL_N][64];
+    const int lane = threadIdx.x;
+    const size_t u = (size_t)blockIdx.x * 64 + (size_t)lane;
+    int n = 0;
+    size_t b = 0;
+    uint32_t qg = 0, tg = 0, strand = 0;
+    if (u < count) {
+        const size_t g = a.gorder[first + u];
+        b = a.gstart[g];
+        const size_t e = g + 1 < a.n_groups ? (size_t)a.gstart[g + 1] : a.n_anchors;
+        n = (int)(e - b);
+        if (n > SMALL_N) { a.counters[2] = 1; n = 0; }         // (the host splits the list by size: cannot happen)
+        if (n < a.min_cnt) n = 0;
+    }
+    if (n) {
+        const uint64_t key0 = group_word(a, b);
+        qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1));
+        tg = (uint32_t)(key0 >> 1) & ((1u << a.tb) - 1);
+        strand = (uint32_t)key0 & 1u;
+        const size_t g_first = strand ? b + (size_t)n - 1 : b;   // chaining order (chain_kernel)
+        const long long g_step = strand ? -1 : 1;
+        for (int i = 0; i < n; ++i) {
+            int t, q, sp;
+            anchor_fields(a, (size_t)((long long)g_first + g_step * i), t, q, sp);
+            s_t[i][lane] = t; s_q[i][lane] = q; s_sp[i][lane] = (uint8_t)sp;
+        }
+    }
+    // ---- DP + best children (oracle/ava_oracle.c:chain_group) ----
+    for (int i = 0; i < n; ++i) {
+        const int ti = s_t[i][lane], qi = s_q[i][lane], si = s_sp[i][lane];
+        int best = si, bp = -1;
+        for (int j = i - 1; j >= 0; --j) {
+            const int dr = ti - s_t[j][lane], dq = qi - s_q[j][lane];
+            if (dq > a.max_gap) break;                          // query positions only grow going back
+            if (dr <= 0 || dr > a.max_gap || dq == 0) continue;
+            const int dd = dr > dq ? dr - dq : dq - dr;
+            if (dd > a.bw) continue;
+            const int dg = dr < dq ? dr : dq;
+            const int sc = dg < si ? dg : si;
+            const int pen = dd ? (dd * a.k) / 100 + (ilog2_u32((uint32_t)dd) >> 1) : 0;
+            const int cand = s_f[j][lane] + sc - pen;
+            if (cand > best) { best = cand; bp = j; }
+        }
+        s_f[i][lane] = best;
+        s_p[i][lane] = (uint8_t)(bp + 1);
+        s_bc[i][lane] = 0;
+    }
+    for (int i = 0; i < n; ++i) {                               // ascending: a later child wins only with a strictly larger f
+        const int p = (int)s_p[i][lane] - 1;
+        if (p < 0) continue;
+        const int c = (int)s_bc[p][lane] - 1;
+        if (c < 0 || s_f[i][lane] > s_f[c][lane]) s_bc[p][lane] = (uint8_t)(i + 1);
+    }
+    // ---- chains -> pieces + fixed points (chain_group's tail, align_chain) ----
+    auto run = [&](bool write, uint32_t slot0, uint32_t &np_all, uint32_t &nf_all) {
+        np_all = nf_all = 0;
+        uint32_t fcur = 2u * (uint32_t)b;                       // the group's range of the fixed-point array (chain_kernel)
+        for (int s = 0; s < n; ++s) {
+            const int ps = (int)s_p[s][lane] - 1;
+            if (ps >= 0 && (int)s_bc[ps][lane] == s + 1) continue;          // continues its parent's chain
+            int m = 0, best_len = 1, cur = s, best_f = s_f[s][lane];
+            s_path[m++][lane] = (uint8_t)s;
+            while (s_bc[cur][lane]) {
+                cur = (int)s_bc[cur][lane] - 1;
+                s_path[m++][lane] = (uint8_t)cur;
+                if (s_f[cur][lane] > best_f) { best_f = s_f[cur][lane]; best_len = m; }
+            }
+            const int score = best_f - (ps >= 0 ? s_f[ps][lane] : 0);
+            if (score < a.min_score || best_len < a.min_cnt) continue;
+            bool open = false;
+            int cq = 0, ct = 0;
+            uint32_t np = 0, nf = 0, piece_fp0 = 0;
+            auto close_piece = [&]() {
+                if (write) a.pieces[slot0 + np_all + np] = Piece{qg, tg, strand, (uint32_t)s, np, fcur + piece_fp0, nf - piece_fp0, 0};
+                ++np;
+            };
+            for (int x = 0; x < best_len; ++x) {
+                const int an = s_path[x][lane];
+                const int qe = s_q[an][lane] + 1, te = s_t[an][lane] + 1;
+                if (!open) {                                    // a piece starts at the start of this member
+                    const int sp = s_sp[an][lane];
+                    int q0 = qe - sp, t0 = te - sp;
+                    if (q0 < 0 || t0 < 0) { const int sh = q0 < t0 ? -q0 : -t0; q0 += sh; t0 += sh; }
+                    if (q0 < 0) q0 = 0;
+                    if (t0 < 0) t0 = 0;
+                    if (!block_ok(q0, t0, qe, te, a.shift_max)) continue;
+                    piece_fp0 = nf;
+                    if (write) { a.fps[fcur + nf] = FixPt{(uint32_t)q0, (uint32_t)t0}; a.fps[fcur + nf + 1] = FixPt{(uint32_t)qe, (uint32_t)te}; }
+                    nf += 2;
+                    cq = qe; ct = te; open = true;
+                    continue;
+                }
+                if (!((qe - cq >= BLOCK_MIN && te - ct >= BLOCK_MIN) || x == best_len - 1)) continue;
+                if (qe <= cq || te <= ct) continue;
+                if (block_ok(cq, ct, qe, te, a.shift_max)) {
+                    if (write) a.fps[fcur + nf] = FixPt{(uint32_t)qe, (uint32_t)te};
+                    ++nf;
+                    cq = qe; ct = te;
+                } else {                                        // split: close here, reopen at this member
+                    close_piece();
+                    open = false;
+                    --x;
+                }
+            }
+            if (open) close_piece();
+            fcur += nf;
+            np_all += np; nf_all += nf;
+        }
+    };
+    uint32_t np_mine = 0, nf_mine = 0;
+    run(false, 0, np_mine, nf_mine);
+    uint32_t incl = np_mine;                                    // inclusive prefix sum over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    uint32_t nf_wave = nf_mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nf_wave += (uint32_t)__shfl_xor((int)nf_wave, o, 64);
+    if (!total) return;                                         // (uniform)
+    uint32_t slot = 0;
+    if (lane == 0) {
+        slot = atomicAdd(&a.counters[0], total);
+        atomicAdd(&a.counters[3], nf_wave);
+    }
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+    if ((unsigned long long)slot + total > a.cap_pieces) { if (lane == 0) a.counters[2] = 1; return; }
+    if (np_mine) run(true, slot + incl - np_mine, np_mine, nf_mine);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
 void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint32_t *d_rank_t, uint32_t n_chunks,
@@ -1307,9 +1465,16 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     counters.zero();
     ChainArgs ca{};
     DBuf<uint32_t> gkey(G ? G : 1), gorder(G ? G : 1);
+    size_t G_big = 0;                            // groups of more than SMALL_N anchors: the head of the size-ordered list
     if (G) {
-        hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p);
+        DBuf<unsigned long long> tally(2);
+        tally.zero();
+        hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p, tally.p);
         sort_pairs_u32_u32(gkey.p, gorder.p, G, 0, 16);
+        const std::vector<unsigned long long> ht = tally.download(2);
+        G_big = (size_t)ht[0];
+        stat_add("chain_groups_small", (double)(G - G_big));
+        stat_add("anchors_small_groups", (double)ht[1]);
         if (INSTR && hook("HLMI_GROUP_HIST")) {
             DBuf<unsigned long long> hist(64);
             hist.zero();
@@ -1339,25 +1504,30 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     // packed DP state: scores (< longest query + one span) must stay below 2^22, positions * 4 inside 31 bits
     const bool packed = o.bandwidth + 2 <= PEN_TAB && max_qlen + 256 < (1ull << 22) && pb <= 28 && o.max_gap < (1 << 24) &&
                         !hook("HLMI_CHAIN_UNPACKED");
-    ca.n_list = G;
+    ca.n_list = G_big;
+    if (G > G_big) {                              // the small groups: a lane each
+        KTimer kt("chain_small");
+        hipLaunchKernelGGL(chain_small_kernel, dim3((unsigned)cdiv(G - G_big, (size_t)64)), dim3(64), 0, stream(), ca, G_big, G - G_big);
+        HIP_CHECK(hipGetLastError());
+    }
     const dim3 block(64 * CHAIN_WAVES);
     auto grid_for = [](size_t n_list) { return dim3((unsigned)std::max<size_t>(1, cdiv(n_list, (size_t)CHAIN_GROUPS * CHAIN_WAVES))); };
-    if (packed && G && !hook("HLMI_CHAIN_NO_DP16")) {
+    if (packed && G_big && !hook("HLMI_CHAIN_NO_DP16")) {
         // every wave first runs the 16-predecessor DP over its four groups, which also proves per group whether the
         // 64-predecessor DP of the specification would have given the same scores and predecessors (dp16_groups); the
         // chain bookkeeping of a proven group reads those, only the groups without the proof run the full DP
         DBuf<uint32_t> fp(A);
         ca.fp = fp.p;
         if (INSTR && hook("HLMI_CHAIN_DP16_CHECK")) {     // self-check: every group through the full DP, compared with the proven ones
-            DBuf<uint8_t> verdict(G), ok_of_group(G);
+            DBuf<uint8_t> verdict(G), ok_of_group(G);      // (indexed by list position / group: the first G_big entries are used)
             DBuf<unsigned long long> n_bad(8);
             n_bad.zero();
             ok_of_group.zero();
-            hipLaunchKernelGGL(chain_dp16_kernel, dim3((unsigned)cdiv(G, (size_t)D16_WAVES * 4)), dim3(64 * D16_WAVES), 0, stream(), ca, fp.p,
+            hipLaunchKernelGGL(chain_dp16_kernel, dim3((unsigned)cdiv(G_big, (size_t)D16_WAVES * 4)), dim3(64 * D16_WAVES), 0, stream(), ca, fp.p,
                                verdict.p);
-            hipLaunchKernelGGL(mark_proven_kernel, grid1(G), dim3(WG), 0, stream(), gorder.p, verdict.p, G, ok_of_group.p);
+            hipLaunchKernelGGL(mark_proven_kernel, grid1(G_big), dim3(WG), 0, stream(), gorder.p, verdict.p, G_big, ok_of_group.p);
             ca.check_ok = ok_of_group.p; ca.check_bad = n_bad.p;
-            hipLaunchKernelGGL((chain_kernel<3, 0>), grid_for(G), block, 0, stream(), ca);
+            hipLaunchKernelGGL((chain_kernel<3, 0>), grid_for(G_big), block, 0, stream(), ca);
             HIP_CHECK(hipGetLastError());
             const std::vector<unsigned long long> hb = n_bad.download(8);
             stat_add("chain_dp16_mismatches", (double)hb[0]);
@@ -1368,7 +1538,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
             if (INSTR && hook("HLMI_CHAIN_PROF")) { prof.zero(); ca.prof = prof.p; }
             {
                 KTimer kt("chain");
-                hipLaunchKernelGGL((chain_kernel<3, 2>), grid_for(G), block, 0, stream(), ca);
+                hipLaunchKernelGGL((chain_kernel<3, 2>), grid_for(G_big), block, 0, stream(), ca);
             }
             HIP_CHECK(hipGetLastError());
             sync();                                   // fp goes out of scope
@@ -1379,9 +1549,9 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
                 stat_add("chain_prof_fixed_cyc", (double)hp[2]); stat_add("chain_prof_groups", (double)hp[3]);
             }
         }
-    } else {
+    } else if (G_big) {
         KTimer kt("chain");
-        const dim3 grid = grid_for(G);
+        const dim3 grid = grid_for(G_big);
         if (packed) hipLaunchKernelGGL(chain_kernel<3>, grid, block, 0, stream(), ca);
         else if (o.bandwidth + 2 > PEN_TAB) hipLaunchKernelGGL(chain_kernel<0>, grid, block, 0, stream(), ca);
         else if ((o.bandwidth * o.k) / 100 + 16 <= 255) hipLaunchKernelGGL(chain_kernel<1>, grid, block, 0, stream(), ca);
