@@ -460,7 +460,7 @@ def main():
                 e2e=dict(open_parse_upload_s=round(t_open, 3), pass_s=round(pass_s, 3), pass_overlaps=int(pass_rows),
                          sketch_exchange_s=[round(x, 4) for x in t_prepare]),
                 exchange=dict(world=(dist.get_world_size() if world > 1 else 1), backend=(backend if world > 1 else None), per_rank=per_rank),
-                stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_format_sort_write_s", "t_total_s") if k in stats})
+                stage_seconds={k: stats[k] for k in ("t_ava_s", "t_filter_s", "t_rows_to_text_s", "t_rows_download_s", "t_final_sort_s", "t_format_sort_write_s", "t_total_s") if k in stats})
     # second half of the BASELINE metric: overlap-graph build seconds (PAF on disk -> GFA on disk), not part of `value`
     if not args.no_graph and not short_calls:
         try:

@@ -1,6 +1,7 @@
 // paf_io.cpp - host text I/O (see paf_io.h).  Nothing here is on the timed device path; it is
 // the text boundary the reference pipes between its processes.
 #include "paf_io.h"
+#include <atomic>
 
 #include <functional>
 
@@ -19,6 +20,7 @@
 #include <algorithm>
 #include <thread>
 #include <cerrno>
+#include <cstring>
 #include <cstdlib>
 #include <numeric>
 
@@ -55,42 +57,83 @@ void write_lines(const char *path, const std::vector<std::string_view> &lines) {
     struct stat st;
     const bool direct = stat(path, &st) == 0 && !S_ISREG(st.st_mode);
     std::string tmp = path;
-    FILE *f = nullptr;
+    int fd = -1;
     if (direct) {
-        f = fopen(path, "wb");
+        fd = open(path, O_WRONLY);
     } else {
         tmp += ".XXXXXX";
-        const int fd = mkstemp(&tmp[0]);
-        if (fd >= 0) {
-            fchmod(fd, 0666 & ~[] { const mode_t m = umask(0); umask(m); return m; }());
-            f = fdopen(fd, "wb");
-            if (!f) { const int e = errno; close(fd); remove(tmp.c_str()); errno = e; }
+        fd = mkstemp(&tmp[0]);
+        if (fd >= 0) fchmod(fd, 0666 & ~[] { const mode_t m = umask(0); umask(m); return m; }());
+    }
+    if (fd < 0) fail(HLMI_EIO, "cannot write %s: %s", tmp.c_str(), strerror(errno));
+    // Regular file: the size is known, so the blocks are reserved (a full disk is reported here, as an error), the file is
+    // mapped and the lines are copied straight into the page cache by a few threads - a third of the time of write() from a
+    // staging buffer for the millions of rows of a short-read call.  Anything that cannot be mapped (and every special file)
+    // takes the plain loop: 8 MB buffers, write().
+    const size_t n = lines.size();
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::min(host_threads(), 4), n / 65536));
+    std::vector<size_t> first(nt + 1), off(nt + 1, 0);
+    for (int t = 0; t <= nt; ++t) first[t] = n * (size_t)t / (size_t)nt;
+    auto each_span = [&](auto &&fn) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(fn, t);
+        fn(0);
+        for (auto &th : pool) th.join();
+    };
+    each_span([&](int t) { size_t b = 0; for (size_t i = first[t]; i < first[t + 1]; ++i) b += lines[i].size() + 1; off[t + 1] = b; });
+    for (int t = 0; t < nt; ++t) off[t + 1] += off[t];
+    const size_t total = off[nt];
+    std::atomic<int> err{0};                     // errno of the first failing call
+    bool done = total == 0;
+    if (!direct && total) {
+        const int fe = posix_fallocate(fd, 0, (off_t)total);
+        if (fe == ENOSPC || fe == EFBIG || fe == EDQUOT || fe == EIO) err = fe;
+        else if (fe == 0) {
+            void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) {
+                each_span([&](int t) {
+                    char *p = (char *)m + off[t];
+                    for (size_t i = first[t]; i < first[t + 1]; ++i) {
+                        memcpy(p, lines[i].data(), lines[i].size());
+                        p += lines[i].size();
+                        *p++ = '\n';
+                    }
+                });
+                if (munmap(m, total) != 0) err = errno ? errno : EIO;
+                done = true;
+            } else if (ftruncate(fd, 0) != 0) err = errno ? errno : EIO;      // (back to an empty file for the plain loop)
         }
     }
-    if (!f) fail(HLMI_EIO, "cannot write %s: %s", tmp.c_str(), strerror(errno));
-    std::string buf;                             // one buffer, few large writes
-    buf.reserve(8u << 20);
-    int err = 0;                                 // errno of the first failing call
-    auto flush = [&]() {
-        if (!err && !buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) err = errno ? errno : EIO;
-        buf.clear();
-    };
-    for (auto &l : lines) {
-        buf.append(l);
-        buf.push_back('\n');
-        if (buf.size() > (7u << 20)) flush();
+    if (!done && !err.load()) {
+        std::string buf;
+        buf.reserve(8u << 20);
+        auto flush = [&]() {
+            const char *p = buf.data();
+            size_t left = buf.size();
+            while (left && !err.load()) {
+                const ssize_t w = write(fd, p, left);
+                if (w < 0) { if (errno == EINTR) continue; err = errno ? errno : EIO; break; }
+                p += w; left -= (size_t)w;
+            }
+            buf.clear();
+        };
+        for (auto &l : lines) {
+            buf.append(l);
+            buf.push_back('\n');
+            if (buf.size() > (7u << 20)) flush();
+        }
+        flush();
     }
-    flush();
-    if (!err && fflush(f) != 0) err = errno ? errno : EIO;
-    if (fclose(f) != 0 && !err) err = errno ? errno : EIO;
-    if (err) {
+    int e = err.load();
+    if (close(fd) != 0 && !e) e = errno ? errno : EIO;
+    if (e) {
         if (!direct) remove(tmp.c_str());
-        fail(HLMI_EIO, "write error on %s: %s", tmp.c_str(), strerror(err));
+        fail(HLMI_EIO, "write error on %s: %s", tmp.c_str(), strerror(e));
     }
     if (!direct && rename(tmp.c_str(), path) != 0) {
-        const int e = errno;
+        const int e2 = errno;
         remove(tmp.c_str());
-        fail(HLMI_EIO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(e));
+        fail(HLMI_EIO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(e2));
     }
 }
 
@@ -276,8 +319,51 @@ void read_seqs_subset(const char *path, const std::function<bool(std::string_vie
 // ------------------------------------------------------------------------------------------
 // final rows
 // ------------------------------------------------------------------------------------------
+// "%.4f" of v into dst (at least 64 bytes), the bytes printf writes.  A finite v in [0, 2^40) - every score of a row - is
+// converted exactly in integers: v = m x 2^e, so v x 10^4 = (m x 10^4) >> -e, rounded to nearest, ties to even (the
+// rounding glibc's printf applies to the exact binary value in the default rounding mode); three conversions per row were
+// most of the stage's text time with printf and still a third of it with std::to_chars.  Anything else goes through
+// std::to_chars / printf.
+size_t format_fixed4(double v, char *dst) {
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    if (!(bits >> 63) && be != 0x7ff && v < 1099511627776.0) {
+        uint64_t m = bits & ((1ull << 52) - 1);
+        int e = be - 1075;                                   // v = m x 2^e
+        if (be) m |= 1ull << 52; else e = -1074;
+        uint64_t q;
+        if (e >= 0) q = (m << e) * 10000ull;                 // (an integer below 2^40)
+        else {
+            const unsigned __int128 N = (unsigned __int128)m * 10000u;      // < 2^67
+            const int sh = -e;
+            if (sh > 68) q = 0;                              // below a half: rounds to zero
+            else {
+                q = (uint64_t)(N >> sh);
+                const unsigned __int128 rem = N & (((unsigned __int128)1 << sh) - 1), half = (unsigned __int128)1 << (sh - 1);
+                if (rem > half || (rem == half && (q & 1))) ++q;
+            }
+        }
+        const uint64_t ip = q / 10000u;
+        uint32_t fp = (uint32_t)(q % 10000u);
+        auto res = std::to_chars(dst, dst + 24, ip);
+        char *p = res.ptr;
+        *p++ = '.';
+        p[3] = (char)('0' + fp % 10); fp /= 10;
+        p[2] = (char)('0' + fp % 10); fp /= 10;
+        p[1] = (char)('0' + fp % 10); fp /= 10;
+        p[0] = (char)('0' + fp);
+        return (size_t)(p + 4 - dst);
+    }
+    if (std::isfinite(v)) {
+        auto res = std::to_chars(dst, dst + 48, v, std::chars_format::fixed, 4);
+        if (res.ec == std::errc()) return (size_t)(res.ptr - dst);
+    }
+    return (size_t)snprintf(dst, 64, "%.4f", v);
+}
+
 bool format_scored_row(const PafRec &r, const std::string &qname, const std::string &tname,
-                       uint32_t x_digit_sum, double iden, std::string &out) {
+                       uint32_t x_digit_sum, double iden, std::string &out, uint32_t *sort_key) {
     // filter_overlap_slr2.py:113,138-146 - plain IEEE doubles in the reference's evaluation order
     double mc = (double)r.nmatch, ln = (double)r.blen;
     double mlen = (double)((uint64_t)r.qlen + r.tlen) / 2.0;
@@ -286,16 +372,8 @@ bool format_scored_row(const PafRec &r, const std::string &qname, const std::str
     double score = a + b;
     double mis = (double)x_digit_sum / mc;
     double score2 = 1.0 - mis;
-    // "%.4f": std::to_chars(fixed, 4) writes the same correctly rounded digits as printf for finite values and is
-    // several times quicker (three of them per row were most of the stage's text time); anything else goes through
-    // printf itself.  float("0.9876") is the correctly rounded 9876 / 10^4, which is what the division below gives.
-    auto f4 = [](double v, char *dst) -> size_t {
-        if (std::isfinite(v)) {
-            auto res = std::to_chars(dst, dst + 48, v, std::chars_format::fixed, 4);
-            if (res.ec == std::errc()) return (size_t)(res.ptr - dst);
-        }
-        return (size_t)snprintf(dst, 64, "%.4f", v);
-    };
+    // "%.4f" (format_fixed4).  float("0.9876") is the correctly rounded 9876 / 10^4, which is what the division below gives.
+    auto f4 = [](double v, char *dst) -> size_t { return format_fixed4(v, dst); };
     char s1[64], s2[64], s3[64];
     const size_t n1 = f4(score, s1), n2 = f4(score2, s2), n3 = f4(t2, s3);
     {
@@ -335,6 +413,17 @@ bool format_scored_row(const PafRec &r, const std::string &qname, const std::str
     out.push_back('\t'); out.append(s2, n2);
     out.push_back('\t'); out.append(s3, n3);
     out.push_back('\t');
+    if (sort_key) {                              // column 12 as sort_scored_lines reads it: value x 10^4 when it is plain digits
+        uint64_t v = 0;
+        size_t frac = 0;
+        bool plain = n1 > 0, dot = false;
+        for (size_t i = 0; plain && i < n1; ++i) {
+            if (s1[i] == '.' && !dot) dot = true;
+            else if (s1[i] >= '0' && s1[i] <= '9' && v < (1ull << 40)) { v = v * 10 + (uint64_t)(s1[i] - '0'); frac += dot ? 1 : 0; }
+            else plain = false;
+        }
+        *sort_key = plain && dot && frac == 4 && v < SCORE_KEY_LIMIT ? (uint32_t)v : 0xffffffffu;
+    }
     return true;
 }
 
@@ -389,16 +478,16 @@ void sort_scored_lines(std::vector<std::string> &lines) {
     for (std::string_view x : v) out.emplace_back(x);
     lines.swap(out);
 }
-void sort_scored_lines(std::vector<std::string_view> &lines) {
+void sort_scored_lines(std::vector<std::string_view> &lines, const std::vector<uint32_t> *keys) {
     const size_t n = lines.size();
     std::vector<uint32_t> idx(n);
     // The rows this library writes carry "%.4f" scores: non-negative, few integer digits, at most 4 decimals.  Such a
     // key is an integer (value x 10^4): a counting sort on it, then the runs of equal scores by the text rule (the
     // 8-byte head of a line settles nearly every tie without touching the strings; memcmp order = big-endian integer
     // order).  Parsing and the tie runs go over the host threads.  Anything else in the column takes the general
-    // comparator.
+    // comparator.  `keys` (the stage: format_scored_row hands them out) spares the parse of column 12.
     struct Rec { uint32_t score, idx; uint64_t head; };
-    constexpr uint32_t SCORE_LIMIT = 1u << 22;                // 419.4304
+    constexpr uint32_t SCORE_LIMIT = SCORE_KEY_LIMIT;         // 419.4304
     std::vector<Rec> rec(n);
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), n / 4096));
     std::vector<uint8_t> bad(nt, 0);
@@ -408,13 +497,20 @@ void sort_scored_lines(std::vector<std::string_view> &lines) {
         fn(0);
         for (auto &th : pool) th.join();
     };
+    const bool have_keys = keys && keys->size() == n;
     each_slice([&](int t) {
         for (size_t i = n * (size_t)t / nt; i < n * (size_t)(t + 1) / nt; ++i) {
-            const NumKey k = gnu_num(field_tail(lines[i], 12));
-            uint64_t v = 0;
-            for (char c : k.ip) v = v * 10 + (uint64_t)(c - '0');
-            for (size_t d = 0; d < 4; ++d) v = v * 10 + (d < k.fp.size() ? (uint64_t)(k.fp[d] - '0') : 0u);
-            if (k.neg || k.ip.size() > 4 || k.fp.size() > 4 || v >= SCORE_LIMIT) { bad[t] = 1; return; }
+            uint64_t v;
+            if (have_keys) {
+                v = (*keys)[i];
+            } else {
+                const NumKey k = gnu_num(field_tail(lines[i], 12));
+                v = 0;
+                for (char c : k.ip) v = v * 10 + (uint64_t)(c - '0');
+                for (size_t d = 0; d < 4; ++d) v = v * 10 + (d < k.fp.size() ? (uint64_t)(k.fp[d] - '0') : 0u);
+                if (k.neg || k.ip.size() > 4 || k.fp.size() > 4) v = SCORE_LIMIT;
+            }
+            if (v >= SCORE_LIMIT) { bad[t] = 1; return; }
             uint64_t h = 0;
             for (size_t d = 0; d < 8; ++d) h = h << 8 | (d < lines[i].size() ? (uint64_t)(unsigned char)lines[i][d] : 0u);
             rec[i] = Rec{(uint32_t)v, (uint32_t)i, h};
@@ -433,18 +529,39 @@ void sort_scored_lines(std::vector<std::string_view> &lines) {
             std::vector<uint32_t> at(start.begin(), start.end() - 1);
             for (const Rec &r : rec) byscore[at[hi - r.score]++] = r;
         }
-        // tie runs: slices of whole score values
+        auto less = [&](const Rec &a, const Rec &b) {
+            if (a.head != b.head) return a.head > b.head;
+            return lines[a.idx] > lines[b.idx];
+        };
+        // Tie runs.  Scores of one read set crowd into a few hundred values (C4s: 3.5 M rows), so the runs are handed out by
+        // ROWS, not by score values: thread t takes the runs that start in its n / nt rows; a run longer than that is sorted
+        // afterwards by all threads together (pieces, then merges).
+        const size_t big = std::max<size_t>(n / (size_t)nt, 1u << 16);
+        std::vector<std::pair<uint32_t, uint32_t>> big_runs;
+        for (uint32_t v = 0; v <= hi; ++v)
+            if ((size_t)(start[v + 1] - start[v]) > big && nt > 1) big_runs.emplace_back(start[v], start[v + 1]);
         each_slice([&](int t) {
-            const uint32_t v0 = (uint32_t)((uint64_t)(hi + 1) * t / nt), v1 = (uint32_t)((uint64_t)(hi + 1) * (t + 1) / nt);
-            for (uint32_t v = v0; v < v1; ++v) {
+            const uint32_t r0 = (uint32_t)(n * (size_t)t / nt), r1 = (uint32_t)(n * (size_t)(t + 1) / nt);
+            // first score value whose run starts at or after r0
+            uint32_t v = (uint32_t)(std::lower_bound(start.begin(), start.end() - 1, r0) - start.begin());
+            for (; v <= hi && start[v] < r1; ++v) {
                 const uint32_t lo = start[v], up = start[v + 1];
-                if (up - lo > 1)
-                    std::sort(byscore.begin() + lo, byscore.begin() + up, [&](const Rec &a, const Rec &b) {
-                        if (a.head != b.head) return a.head > b.head;
-                        return lines[a.idx] > lines[b.idx];
-                    });
+                if (up - lo > 1 && !((size_t)(up - lo) > big && nt > 1)) std::sort(byscore.begin() + lo, byscore.begin() + up, less);
             }
         });
+        for (auto &run : big_runs) {
+            const size_t lo = run.first, len = run.second - run.first;
+            auto cut = [&](int k) { return lo + len * (size_t)k / (size_t)nt; };
+            each_slice([&](int t) { std::sort(byscore.begin() + cut(t), byscore.begin() + cut(t + 1), less); });
+            for (int w = 1; w < nt; w *= 2) {                 // merge neighbours: pieces [k, k + w) and [k + w, k + 2w)
+                std::vector<std::thread> pool;
+                for (int k = 0; k + w < nt; k += 2 * w)
+                    pool.emplace_back([&, k, w] {
+                        std::inplace_merge(byscore.begin() + cut(k), byscore.begin() + cut(k + w), byscore.begin() + cut(std::min(k + 2 * w, nt)), less);
+                    });
+                for (auto &th : pool) th.join();
+            }
+        }
         for (size_t i = 0; i < n; ++i) idx[i] = byscore[i].idx;
     } else {
         std::iota(idx.begin(), idx.end(), 0u);

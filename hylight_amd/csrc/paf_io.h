@@ -51,15 +51,20 @@ void read_seqs_subset(const char *path, const std::function<bool(std::string_vie
 
 // Final 14-column row of filter_overlap_slr2.py:142-151 (with the trailing TAB); returns
 // false when the row is dropped by the identity test `float(score2) < iden` (slr2:146).
+// "%.4f" of v, the bytes printf writes, into dst (>= 64 bytes); returns the length (tests/capi/fixed4_check.cpp)
+size_t format_fixed4(double v, char *dst);
+// sort_key (optional): column 12 as an integer (value x 10^4) for sort_scored_lines, 0xffffffff when it is not plain digits.
+constexpr uint32_t SCORE_KEY_LIMIT = 1u << 22;                // 419.4304
 bool format_scored_row(const PafRec &r, const std::string &qname, const std::string &tname,
-                       uint32_t x_digit_sum, double iden, std::string &out);
+                       uint32_t x_digit_sum, double iden, std::string &out, uint32_t *sort_key = nullptr);
 
 // `sort -k12 -nr` (utils.py:54,69): numeric descending on column 12, ties by reversed
 // whole-line byte order.  Lines carry no newline.
 void sort_scored_lines(std::vector<std::string> &lines);
 // the same on views into text the caller keeps alive (the stage formats its rows into a few large buffers: one
 // allocation per thread instead of one per line)
-void sort_scored_lines(std::vector<std::string_view> &lines);
+// (keys: the sort_key of every line, from format_scored_row - spares the parse of column 12)
+void sort_scored_lines(std::vector<std::string_view> &lines, const std::vector<uint32_t> *keys = nullptr);
 
 void write_lines(const char *path, const std::vector<std::string> &lines);
 void write_lines(const char *path, const std::vector<std::string_view> &lines);

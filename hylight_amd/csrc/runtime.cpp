@@ -2,6 +2,7 @@
 #include <mutex>
 
 #include "common.h"
+#include <sched.h>
 
 #include <iterator>
 
@@ -12,7 +13,7 @@ thread_local std::string g_last_error;
 hipStream_t g_stream = nullptr;
 hipStream_t g_side = nullptr;
 bool g_ready = false;
-int g_threads = 8;
+int g_threads = 0;                       // 0: not chosen yet (host_threads)
 std::map<std::string, double> g_stats;
 std::mutex g_mu;
 }  // namespace
@@ -20,7 +21,17 @@ std::mutex g_mu;
 void set_last_error(const std::string &m) { g_last_error = m; }
 const std::string &last_error() { return g_last_error; }
 
-int host_threads() { return g_threads; }
+// host threads of the text passes: what hlmi_init was given, else the CPUs this process may run on, 16 at most (a rank per
+// GPU on a 256-thread host: 8 x 16 leaves half the machine to the caller)
+int host_threads() {
+    if (g_threads <= 0) {
+        cpu_set_t set;
+        int n = 8;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+        g_threads = std::max(1, std::min(n, 16));
+    }
+    return g_threads;
+}
 
 void *pinned_scratch() {
     static void *p = nullptr;

@@ -35,6 +35,9 @@ struct Job::Impl {
     // anchors / output bytes per target base seen by the last pass over this job: the next pass sizes its first sub-run
     // from them instead of probing with 128 Mbases (and being refused on deep read sets)
     double est_anchors_per_base = 0, est_out_per_base = 0;
+    // text buffers of the last pass, kept for the next one (capacity only): a short-read call formats ~400 MB of rows per
+    // pass, and fresh memory costs a page fault per 4 KB under a lock all formatting threads share
+    std::vector<std::unique_ptr<std::string>> text_cache;
 };
 
 static double now_s() {
@@ -214,9 +217,10 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     }
     // the rows' text: every formatting thread appends to a buffer of its own, `lines` are views into those buffers
     std::vector<std::string_view> lines;
+    std::vector<uint32_t> line_keys;             // column 12 of every line as an integer (format_scored_row)
     std::vector<std::unique_ptr<std::string>> text;
     std::vector<uint32_t> tids;
-    double t_ava = 0, t_flt = 0, t_fmt = 0;
+    double t_ava = 0, t_flt = 0, t_fmt = 0, t_dl = 0;
     size_t n_v4 = 0, n_ev = 0, n_pairs = 0, n_subruns = 0;
     uint64_t done_bases = 0;
     double done_anchors = 0, done_out_bytes = 0;
@@ -309,18 +313,22 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
             n_v4 += fo.n_after_v4; n_ev += fo.n_events; n_pairs += fo.n_pairs;
             const double tf = now_s();
             std::vector<PafRec> kept = download_rows(rows.recs.p + r0, fo.rows);
+            t_dl += now_s() - tf;
             {   // rows -> text on the host threads (three %.4f conversions per row dominate), order kept
                 const size_t nk = kept.size();
-                std::vector<uint32_t> at(nk), len(nk, 0);          // span of row i in its thread's buffer (len 0: dropped)
+                std::vector<uint32_t> at(nk), len(nk, 0), key(nk); // span of row i in its thread's buffer (len 0: dropped), sort key
                 const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), nk / 2048));
                 const size_t first_buf = text.size();
-                for (int t = 0; t < nt; ++t) text.emplace_back(new std::string());
+                for (int t = 0; t < nt; ++t) {
+                    if (!m.text_cache.empty()) { text.emplace_back(std::move(m.text_cache.back())); m.text_cache.pop_back(); text.back()->clear(); }
+                    else text.emplace_back(new std::string());
+                }
                 auto work = [&](int t) {
                     std::string tmp, &buf = *text[first_buf + (size_t)t];
                     buf.reserve((nk / nt + 1) * 160);
                     for (size_t i = nk * (size_t)t / nt; i < nk * (size_t)(t + 1) / nt; ++i)
                         if (format_scored_row(kept[i], m.name_of_rank[kept[i].qid], m.name_of_rank[kept[i].tid],
-                                              fo.x_digit_sum[i], iden, tmp)) {
+                                              fo.x_digit_sum[i], iden, tmp, &key[i])) {
                             at[i] = (uint32_t)buf.size(); len[i] = (uint32_t)tmp.size();
                             buf.append(tmp);
                         }
@@ -329,10 +337,12 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
                 for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
                 work(0);
                 for (auto &th : pool) th.join();
+                lines.reserve(lines.size() + nk);
+                line_keys.reserve(line_keys.size() + nk);
                 for (int t = 0; t < nt; ++t) {                      // the buffers are final: views are safe now
                     const std::string &buf = *text[first_buf + (size_t)t];
                     for (size_t i = nk * (size_t)t / nt; i < nk * (size_t)(t + 1) / nt; ++i)
-                        if (len[i]) lines.emplace_back(buf.data() + at[i], len[i]);
+                        if (len[i]) { lines.emplace_back(buf.data() + at[i], len[i]); line_keys.push_back(key[i]); }
                 }
             }
             t_fmt_sub += now_s() - tf;
@@ -352,11 +362,21 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     stat_set("t_ava_s", t_ava);
     stat_set("t_filter_s", t_flt);
     stat_set("t_rows_to_text_s", t_fmt);
+    stat_set("t_rows_download_s", t_dl);            // (part of t_rows_to_text_s)
     const double t3 = now_s();
-    sort_scored_lines(lines);     // per-chunk sort + merged sort of utils.py:54,69 collapse into one total order
+    sort_scored_lines(lines, &line_keys);     // per-chunk sort + merged sort of utils.py:54,69 collapse into one total order
     stat_set("t_final_sort_s", now_s() - t3);
     write_lines(out_paf, lines);
-    stat_set("rows_out", (double)lines.size());
+    {   // the buffers go back to the job, largest first, 2 GB of capacity at most
+        std::sort(text.begin(), text.end(), [](const auto &a, const auto &b) { return a->capacity() > b->capacity(); });
+        size_t held = 0;
+        for (auto &b : m.text_cache) held += b->capacity();
+        for (auto &b : text)
+            if (held + b->capacity() <= (2ull << 30) && m.text_cache.size() < 64) { held += b->capacity(); m.text_cache.emplace_back(std::move(b)); }
+        lines.clear();
+        text.clear();
+    }
+    stat_set("rows_out", (double)line_keys.size());
     stat_set("t_format_sort_write_s", now_s() - t3);
     ktimer_flush();
     stat_set("t_total_s", now_s() - t0);

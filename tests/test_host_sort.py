@@ -40,3 +40,47 @@ def test_merge_matches_gnu_sort(tmp_path, seed, scores):
     want = subprocess.run(["sort", "-k12", "-nr", str(tmp_path / "all.paf")], env=dict(os.environ, LC_ALL="C"),
                           capture_output=True, text=True, check=True).stdout
     assert open(tmp_path / "out.paf").read() == want
+
+
+def test_merge_with_huge_tie_runs_matches_gnu_sort(tmp_path):
+    """Three score values over 300 000 lines: every tie run is longer than a thread's share of the rows, so the runs are
+    sorted piecewise by all host threads and merged (paf_io.cpp:sort_scored_lines), and the output goes through the
+    mapped-file writer (write_lines).  Same bytes as GNU sort."""
+    rng = random.Random(7)
+    lines = [_line(rng, i, ["0.9990", "1.0000", "0.9876"]) + str(rng.randrange(10 ** 6)) for i in range(300000)]
+    (tmp_path / "in.paf").write_text("\n".join(lines) + "\n")
+    api.merge_scored_paf([tmp_path / "in.paf"], tmp_path / "out.paf")
+    want = subprocess.run(["sort", "-k12", "-nr", str(tmp_path / "in.paf")], env=dict(os.environ, LC_ALL="C"),
+                          capture_output=True, check=True).stdout
+    assert open(tmp_path / "out.paf", "rb").read() == want
+
+
+def test_write_errors_and_special_files(tmp_path):
+    """A target that is not a regular file is written directly (no temporary + rename); a full device is an error that
+    names the file, not a truncated output."""
+    (tmp_path / "in.paf").write_text("a\t1\t0\t1\t+\tb\t1\t0\t1\t1\t1\t0.5000\t1.0000\t1.0000\t\n")
+    fifo = tmp_path / "fifo"
+    os.mkfifo(fifo)
+    reader = subprocess.Popen(["cat", str(fifo)], stdout=subprocess.PIPE)
+    api.merge_scored_paf([tmp_path / "in.paf"], fifo)
+    assert reader.communicate(timeout=30)[0] == open(tmp_path / "in.paf", "rb").read()
+    with pytest.raises(Exception, match="/dev/full"):
+        api.merge_scored_paf([tmp_path / "in.paf"], "/dev/full")
+    out = tmp_path / "out.paf"
+    api.merge_scored_paf([tmp_path / "in.paf"], out)
+    assert out.read_bytes() == open(tmp_path / "in.paf", "rb").read()
+    assert sorted(os.listdir(tmp_path)) == ["fifo", "in.paf", "out.paf"]          # no temporary left behind
+
+
+def test_fixed4_formatter_writes_what_printf_writes(tmp_path):
+    """The integer "%.4f" of the final rows' three score columns (paf_io.cpp:format_fixed4) against printf on ~24 M values:
+    the dyadic grid (every exact tie of the fourth decimal), ratios of small integers as the rows have them, random bit
+    patterns of every exponent, signs and specials (tests/capi/fixed4_check.cpp)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api.load()                                                  # (builds the library when it is missing)
+    exe = tmp_path / "fixed4_check"
+    libdir = os.path.join(root, "hylight_amd")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "capi", "fixed4_check.cpp"), "-o", str(exe),
+                    "-L", libdir, "-lhylight_mi", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr
