@@ -356,8 +356,10 @@ __global__ void gather_u64_at_kernel(const uint64_t *src, const uint64_t *idx, u
 // sort key that puts the big groups first: the hardware hands workgroups out in order, so the long groups start
 // early and the tail of a launch is made of small ones
 // groups of more than SMALL_N anchors go through chain_kernel (a wave per group), the others through chain_small_kernel (a lane
-// per group): tally[0] += groups above SMALL_N, tally[1] += anchors of the others (one atomic per wave)
+// per group): groups above SMALL_N and anchors of the others, one atomic pair per wave into one of TALLY_SLOTS cache lines (a short-
+// read call has a million waves of small groups a step: on one address their atomics took longer than the kernel's real work)
 constexpr int SMALL_N = 32;
+constexpr int TALLY_SLOTS = 64, TALLY_STRIDE = 16;       // 16 x 8 B = one 128-byte line per slot
 __global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, size_t n_anchors, uint32_t *key, uint32_t *order,
                                       unsigned long long *tally) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -373,8 +375,9 @@ __global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, s
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) small_anchors += __shfl_xor(small_anchors, o, 64);
     if ((threadIdx.x & 63) == 0) {
-        if (big) atomicAdd(&tally[0], (unsigned long long)__popcll(big));
-        if (small_anchors) atomicAdd(&tally[1], (unsigned long long)small_anchors);
+        unsigned long long *slot = tally + (size_t)(blockIdx.x % TALLY_SLOTS) * TALLY_STRIDE;
+        if (big) atomicAdd(&slot[0], (unsigned long long)__popcll(big));
+        if (small_anchors) atomicAdd(&slot[1], (unsigned long long)small_anchors);
     }
 }
 
@@ -1467,14 +1470,15 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     DBuf<uint32_t> gkey(G ? G : 1), gorder(G ? G : 1);
     size_t G_big = 0;                            // groups of more than SMALL_N anchors: the head of the size-ordered list
     if (G) {
-        DBuf<unsigned long long> tally(2);
+        DBuf<unsigned long long> tally((size_t)TALLY_SLOTS * TALLY_STRIDE);
         tally.zero();
         hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p, tally.p);
         sort_pairs_u32_u32(gkey.p, gorder.p, G, 0, 16);
-        const std::vector<unsigned long long> ht = tally.download(2);
-        G_big = (size_t)ht[0];
+        const std::vector<unsigned long long> ht = tally.download((size_t)TALLY_SLOTS * TALLY_STRIDE);
+        unsigned long long a_small = 0;
+        for (int k = 0; k < TALLY_SLOTS; ++k) { G_big += (size_t)ht[(size_t)k * TALLY_STRIDE]; a_small += ht[(size_t)k * TALLY_STRIDE + 1]; }
         stat_add("chain_groups_small", (double)(G - G_big));
-        stat_add("anchors_small_groups", (double)ht[1]);
+        stat_add("anchors_small_groups", (double)a_small);
         if (INSTR && hook("HLMI_GROUP_HIST")) {
             DBuf<unsigned long long> hist(64);
             hist.zero();
