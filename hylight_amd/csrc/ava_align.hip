@@ -2683,13 +2683,16 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             long_ready.push_back(LongReady{al, la, nb, half, tb, timer});
             return nl;
         };
-        // every prepared LONG launch goes to the side stream, after ALL their lists are built: a selection pass queued behind a
-        // running long kernel waits for the whole of it (its first round of tasks fills every SIMD; measured: a 40 us scan took
-        // 31 ms), and with it everything the compute stream was to run beside the long kernel
+        // every prepared LONG launch starts after ALL their lists are built: on the second stream (HLMI_LONG_SIDE_STREAM) a selection
+        // pass queued behind a running long kernel waits for the whole of it (its first round of tasks fills every SIMD; measured:
+        // a 40 us scan took 31 ms), and with it everything the compute stream was to run beside the long kernel
         auto launch_long_ready = [&]() {
             if (long_ready.empty()) return;
             sync();                                                  // lists, keys and control words are in place
-            hipStream_t ls = hook("HLMI_LONG_MAIN_STREAM") ? stream() : side_stream();      // (tuning: no second stream)
+            // in line on the compute stream.  (HLMI_LONG_SIDE_STREAM: on the second stream, beside the DP kernels that follow -
+            // measured equal, C3 slice 957 vs 961 ms, C5 chunk 3.55 vs 3.56 s: the card is busy either way, and kernels that
+            // share it stretch each other's timers, which is why the default is the one stream)
+            hipStream_t ls = hook("HLMI_LONG_SIDE_STREAM") ? side_stream() : stream();
             for (const LongReady &r : long_ready) {
                 KTimer kt(r.timer, ls);
                 const bool two = aa.go2 > 0;

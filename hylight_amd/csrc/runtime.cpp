@@ -153,7 +153,7 @@ const char *const HOOK_NAMES[] = {
     "HLMI_CHAIN_UNPACKED",
     "HLMI_GROUP_HIST",
     "HLMI_HOST_TIMERS",
-    "HLMI_LONG_MAIN_STREAM",
+    "HLMI_LONG_SIDE_STREAM",
     "HLMI_NARROW_LONG_UNPACKED",
     "HLMI_NARROW_UNPACKED",
     "HLMI_NO_EXT_CERT",
