@@ -260,7 +260,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     if (base_addr == ~(uintptr_t)0) base_addr = 0;
     out.ops_base = (const uint32_t *)base_addr;
     delete ht_part; ht_part = new HostTimer("concat_copy");
-    size_t r0 = 0, e0 = 0;
+    size_t r0 = 0;
     for (auto &p : parts) {
         HIP_CHECK(hipMemcpyAsync(recs.p + r0, p.recs.p, p.n_rows * sizeof(PafRec), hipMemcpyDeviceToDevice, stream()));
         HIP_CHECK(hipMemcpyAsync(hi64.p + r0, p.ord_hi.p, p.n_rows * 8, hipMemcpyDeviceToDevice, stream()));
@@ -268,7 +268,6 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         const uint64_t shift = p.n_ops ? (uint64_t)(((uintptr_t)p.ops.p - base_addr) / 4) : 0;     // the part's ops stay in place
         if (shift) hipLaunchKernelGGL(shift_cigar_kernel, grid1(p.n_rows), dim3(WG), 0, stream(), recs.p + r0, p.n_rows, shift);
         r0 += p.n_rows;
-        e0 += p.n_ops;
         out.ops_part_len.push_back(p.n_ops);
         out.ops_parts.push_back(std::move(p.ops));
     }
