@@ -32,7 +32,8 @@ extern "C" {
 
 /* ---- library state -------------------------------------------------------------------- */
 /* Select the HIP device used by this process (one process per GPU).  device < 0 keeps the
- * current device.  host_threads bounds host-side helper threads (text formatting, sorting). */
+ * current device.  host_threads bounds host-side helper threads (text formatting, sorting,
+ * the output writer); <= 0: the CPUs this process may run on, 16 at most. */
 int         hlmi_init(int device, int host_threads);
 void        hlmi_shutdown(void);
 const char *hlmi_last_error(void);
