@@ -1477,6 +1477,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         const std::vector<unsigned long long> ht = tally.download((size_t)TALLY_SLOTS * TALLY_STRIDE);
         unsigned long long a_small = 0;
         for (int k = 0; k < TALLY_SLOTS; ++k) { G_big += (size_t)ht[(size_t)k * TALLY_STRIDE]; a_small += ht[(size_t)k * TALLY_STRIDE + 1]; }
+        if (hook("HLMI_CHAIN_NO_SMALL")) { G_big = G; a_small = 0; }      // test hook: every group through chain_kernel
         stat_add("chain_groups_small", (double)(G - G_big));
         stat_add("anchors_small_groups", (double)a_small);
         if (INSTR && hook("HLMI_GROUP_HIST")) {

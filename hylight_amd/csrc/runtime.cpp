@@ -149,6 +149,7 @@ const char *const HOOK_NAMES[] = {
     "HLMI_ASM_STAGE_CAP",
     "HLMI_CHAIN_DP16_CHECK",
     "HLMI_CHAIN_NO_DP16",
+    "HLMI_CHAIN_NO_SMALL",
     "HLMI_CHAIN_PROF",
     "HLMI_CHAIN_UNPACKED",
     "HLMI_GROUP_HIST",

@@ -48,6 +48,24 @@ def test_short_reads_vs_contigs_matches_oracle(tmp_path):
     assert got == want
 
 
+def test_small_groups_chain_the_same_in_both_kernels(tmp_path, monkeypatch):
+    """Short reads on contigs leave groups of a dozen anchors: they go through chain_small_kernel (a lane per group).  With
+    HLMI_CHAIN_NO_SMALL every group takes chain_kernel (a wave per group) instead: same rows, and the statistic shows which
+    kernel did the work."""
+    reads, contigs = _short_reads_and_contigs(93)
+    q, t = tmp_path / "short.fa", tmp_path / "con.fa"
+    S.write_fasta(reads, q)
+    S.write_fasta(contigs, t)
+    api.ava(t, q, tmp_path / "a.paf", api.ava_opts_short())
+    st = api.last_stats()
+    assert st["chain_groups_small"] > 0.9 * st["chain_groups"] and st["anchors_small_groups"] > 0
+    monkeypatch.setenv("HLMI_CHAIN_NO_SMALL", "1")
+    api.ava(t, q, tmp_path / "b.paf", api.ava_opts_short())
+    assert api.last_stats()["chain_groups_small"] == 0
+    a = open(tmp_path / "a.paf").read()
+    assert a == open(tmp_path / "b.paf").read() and a.count("\n") > 0.6 * len(reads)
+
+
 def test_short_noisy_reads_vs_contigs_matches_oracle(tmp_path):
     """2 % / 1 % / 1 % read errors: the end bonus now decides between clipped and full-length alignments, extensions
     rarely match exactly (third certificate with the bonus row in play) and go through the 64-diagonal DP."""
