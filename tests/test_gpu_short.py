@@ -58,7 +58,7 @@ def test_small_groups_chain_the_same_in_both_kernels(tmp_path, monkeypatch):
     S.write_fasta(contigs, t)
     api.ava(t, q, tmp_path / "a.paf", api.ava_opts_short())
     st = api.last_stats()
-    assert st["chain_groups_small"] > 0.9 * st["chain_groups"] and st["anchors_small_groups"] > 0
+    assert st["chain_groups_small"] > 0.5 * st["chain_groups"] and st["anchors_small_groups"] > 0
     monkeypatch.setenv("HLMI_CHAIN_NO_SMALL", "1")
     api.ava(t, q, tmp_path / "b.paf", api.ava_opts_short())
     assert api.last_stats()["chain_groups_small"] == 0
