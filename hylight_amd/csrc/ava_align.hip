@@ -142,6 +142,29 @@ __global__ __launch_bounds__(WG) void task_ref_kernel(const Piece *pieces, const
     }
 }
 
+// the same with a lane per piece (pieces of a handful of fixed points: short reads)
+__global__ __launch_bounds__(WG) void task_ref_lane_kernel(const Piece *pieces, const uint32_t *task_off, size_t n, const uint32_t *qlen,
+                                                            const uint32_t *tlen, const uint64_t *qoff, const uint64_t *toff,
+                                                            const FixPt *fps, int stub_oh, int ext_max, TaskRef *task_ref, PieceGeom *pg) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Piece p = pieces[i];
+    const uint32_t n_tasks = p.n_fp + 1;
+    TaskRef *out = task_ref + task_off[i];
+    for (uint32_t k = 0; k < n_tasks; ++k) {
+        const uint32_t kind = k == 0 ? 1u : (k == p.n_fp ? 2u : 0u);
+        out[k] = TaskRef{(uint32_t)i | kind << 30, p.fp_off + (k == 0 ? 0u : k - 1)};
+    }
+    const uint32_t ql = qlen[p.q], tl = tlen[p.t];
+    uint32_t cand = 0;
+    if (stub_oh >= 0) {
+        const FixPt a = fps[p.fp_off], b = fps[p.fp_off + p.n_fp - 1];
+        const uint32_t dq = (uint32_t)(ext_max + stub_oh), dt = (uint32_t)(ext_max + BAND_W + stub_oh);
+        cand = ((a.q > dq && a.t > dt) || (ql - b.q > dq && tl - b.t > dt)) ? 1u : 0u;
+    }
+    pg[i] = PieceGeom{qoff[p.q], toff[p.t], ql, tl, p.strand, cand};
+}
+
 struct AlignArgs {
     Task *tasks;            // records of the tasks that need a DP (written by the classifier, read by the DP kernels)
     TaskGeom geom;
@@ -2441,6 +2464,29 @@ __global__ __launch_bounds__(WG) void piece_long_flag_kernel(const Piece *pieces
         if (lane == 0) flag[i] = any ? 1 : 0;
     }
 }
+// the same with a lane per piece: pieces of a handful of fixed points (short reads on contigs: 62 M pieces of ~6 a step) would
+// each occupy a wave above
+__global__ __launch_bounds__(WG) void piece_long_flag_lane_kernel(const Piece *pieces, size_t n, const FixPt *fps, const uint32_t *qlen,
+                                                                   const uint32_t *tlen, int ext_max, uint8_t *flag) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Piece p = pieces[i];
+    const FixPt *fp = fps + p.fp_off;
+    FixPt f0 = fp[0];
+    const FixPt b = fp[p.n_fp - 1];
+    const int ql = (int)qlen[p.q], tl = (int)tlen[p.t];
+    auto rows = [&](int aq, int at) {
+        const int m = aq < ext_max ? aq : ext_max, nn = at < m + BAND_W ? at : m + BAND_W;
+        return m < nn + (BAND_W / 2 - 1) ? m : nn + (BAND_W / 2 - 1);
+    };
+    bool lng = rows((int)f0.q, (int)f0.t) > EXT_MAX || rows(ql - (int)b.q, tl - (int)b.t) > EXT_MAX;
+    for (uint32_t k = 1; k < p.n_fp && !lng; ++k) {
+        const FixPt f1 = fp[k];
+        lng = (int)(f1.q - f0.q) > BLOCK_MAX || (int)(f1.t - f0.t) > BLOCK_MAX;
+        f0 = f1;
+    }
+    flag[i] = lng ? 1 : 0;
+}
 __global__ void gather_pieces_kernel(const Piece *src, const uint32_t *idx, size_t n, Piece *dst, uint32_t *n_fp) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2478,6 +2524,10 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     if (P >= (1u << 30)) fail(HLMI_EINVAL, "more than 2^30 alignment pieces in one batch");
     DBuf<TaskRef> task_ref(NT);
     DBuf<PieceGeom> pgeom(P);
+    if (NT <= 17 * P)                  // pieces of a handful of tasks: a lane each
+        hipLaunchKernelGGL(task_ref_lane_kernel, grid1(P), dim3(WG), 0, stream(), ch.pieces.p, toff.p, P, d_qlen, d_tlen, in.Q->off.p, in.T->off.p,
+                           ch.fps.p, o.stub_oh, ext_rows(o), task_ref.p, pgeom.p);
+    else
     hipLaunchKernelGGL(task_ref_kernel, dim3((unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
                        ch.pieces.p, toff.p, P, d_qlen, d_tlen, in.Q->off.p, in.T->off.p, ch.fps.p, o.stub_oh, ext_rows(o), task_ref.p, pgeom.p);
     HIP_CHECK(hipGetLastError());
@@ -3012,6 +3062,10 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
     if (defer && o.bandwidth != 0) {
         const size_t P0 = ch_in.n_pieces;
         DBuf<uint8_t> flag(P0), nflag(P0);
+        if (ch_in.n_fp <= 16 * P0)         // few fixed points per piece: a lane each
+            hipLaunchKernelGGL(piece_long_flag_lane_kernel, grid1(P0), dim3(WG), 0, stream(), ch_in.pieces.p, P0, ch_in.fps.p, d_qlen, d_tlen,
+                               ext_rows(o), flag.p);
+        else
         hipLaunchKernelGGL(piece_long_flag_kernel, dim3((unsigned)std::min<size_t>(cdiv(P0, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
                            ch_in.pieces.p, P0, ch_in.fps.p, d_qlen, d_tlen, ext_rows(o), flag.p);
         DBuf<uint32_t> lidx(P0);
