@@ -2373,6 +2373,85 @@ __global__ __launch_bounds__(WG) void assemble_kernel(AsmArgs a, uint32_t *n_ops
     }
 }
 
+// The same with a LANE per piece: the pieces of short reads have half a dozen tasks of one or two runs each, and a wave per piece
+// (62 M waves a step on the short-read calls) spends its time on scans over six lanes.  The lane walks its piece's tasks in
+// order with the row's definition as it stands above: kept tasks' runs concatenated, a task's first run merged into the run
+// before it when the codes agree.  The counting pass reads the codes of the first / last run from TaskOut::pad like the wave
+// form; the writing pass reads the runs.
+template <bool WRITE>
+__global__ __launch_bounds__(WG) void assemble_lane_kernel(AsmArgs a, uint32_t *n_ops, uint8_t *valid, const uint64_t *ops_off,
+                                                            uint32_t *ops, PafRec *recs, uint64_t *ord_hi, uint64_t *ord_lo) {
+    const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (idx >= a.n_pieces) return;
+    const size_t i = !WRITE && a.plist ? (size_t)a.plist[idx] : idx;
+    if (WRITE && !valid[i]) return;
+    const Piece p = a.pieces[i];
+    const FixPt *fp = a.fps + p.fp_off;
+    const TaskOut *to = a.tout + a.task_off[i];
+    const uint32_t n_tasks = p.n_fp + 1;
+    const bool bare = a.bare && a.pg[i].stub_cand != 0;
+    uint32_t *w = WRITE ? ops + ops_off[i] : nullptr;
+    long long score = 0;
+    unsigned long long nmatch = 0, blen = 0;
+    uint32_t slots = 0;                       // ops written (WRITE) / counted so far, the pending one excluded
+    uint32_t pend = 0;                        // WRITE: the op still taking merges (len << 4 | code), 0: none
+    uint32_t carry_code = 99;                 // last code of the last non-empty kept task so far
+    int li = 0, lj = 0, ri = 0, rj = 0;
+    for (uint32_t t = 0; t < n_tasks; ++t) {
+        const TaskOut r = to[t];
+        bool keep = true;
+        if (t == 0 || t == n_tasks - 1)       // an extension counts when it gains something (bonus: decision only)
+            keep = !(r.score + ((r.pad & 0x80000000u) ? a.end_bonus : 0) <= 0 || (r.n_runs == 0 && !bare));
+        if (!keep) continue;
+        if (t == 0) { li = r.bi; lj = r.bj; }
+        else if (t == n_tasks - 1) { ri = r.bi; rj = r.bj; }
+        score += r.score;
+        const uint32_t nr = bare ? 0u : r.n_runs;
+        if (!nr) continue;
+        const uint32_t first = r.pad & 15u, last = (r.pad >> 4) & 15u;     // codes of the first / last run (TaskOut::pad)
+        const bool mrg = first == carry_code;  // (both passes decide by these codes: the writer fills exactly the counted slots)
+        carry_code = last;
+        if (!WRITE) {
+            slots += nr - (mrg ? 1u : 0u);
+            continue;
+        }
+        for (uint32_t x = 0; x < nr; ++x) {
+            const uint32_t run = a.runs[r.runs_off + x];
+            blen += run >> 4;
+            if ((run & 15u) == OP_EQ) nmatch += run >> 4;
+            if (x == 0 && mrg) pend += (run >> 4) << 4;
+            else {
+                if (pend) w[slots++] = pend;
+                pend = run;
+            }
+        }
+    }
+    if (!WRITE) {
+        const bool ok = (slots > 0 || bare) && score >= a.min_dp_score;
+        valid[i] = ok ? 1 : 0;
+        n_ops[i] = ok ? slots : 0;
+        if (a.late) a.late[i] = a.pg[i].stub_cand && !((slots > 0 || bare) && score >= a.stub_score) ? 1 : 0;
+        return;
+    }
+    if (pend) w[slots++] = pend;
+    const int qs = (int)fp[0].q - li, ts = (int)fp[0].t - lj;
+    const int qe = (int)fp[p.n_fp - 1].q + ri, te = (int)fp[p.n_fp - 1].t + rj;
+    const uint32_t ql = a.qlen[p.q];
+    PafRec r{};
+    r.qid = a.rank_q[p.q]; r.tid = a.rank_t[p.t];
+    r.qlen = ql; r.tlen = a.tlen[p.t];
+    r.qs = p.strand ? ql - (uint32_t)qe : (uint32_t)qs;
+    r.qe = p.strand ? ql - (uint32_t)qs : (uint32_t)qe;
+    r.ts = (uint32_t)ts; r.te = (uint32_t)te;
+    r.nmatch = (uint32_t)nmatch; r.blen = (uint32_t)blen;
+    r.flags = p.strand ? PF_REV : 0;
+    r.chunk = a.chunk_of_t[p.t];
+    r.cig_off = ops_off[i]; r.cig_n = slots; r.tie = 0;
+    recs[i] = r;
+    ord_hi[i] = (uint64_t)r.chunk << 32 | p.q;
+    ord_lo[i] = (uint64_t)p.t << 43 | (uint64_t)p.strand << 42 | (uint64_t)(p.chain & 0x3fffffu) << 20 | (p.piece & 0xfffffu);
+}
+
 // the two end extensions of every listed piece, as task ids (stub rule: pieces whose extensions were held back and are
 // needed after all)
 __global__ void late_tasks_kernel(const uint32_t *plist, size_t n, const Piece *pieces, const uint32_t *task_off, uint32_t *tasks,
@@ -2555,6 +2634,7 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     DBuf<uint32_t> late_idx(o.stub_oh >= 0 ? P : 0);
     size_t n_late = 0;
     const unsigned nba = (unsigned)std::min<size_t>(cdiv(P, (size_t)WAVES), 256 * 32);
+    const bool small_pieces = NT <= 17 * P && !hook("HLMI_ASM_WAVE");      // half a dozen tasks per piece: the lane forms of the piece kernels
     // packed form of the near-diagonal DP (two tasks per lane, 16-bit scores): block scores must stay within +-4096 of the bias
     const int worst = std::max(std::max(o.match, o.mismatch), std::max(o.ambi, o.gap_open + o.gap_ext));
     const bool packed = worst > 0 && (long long)worst * (BLOCK_MAX + NARROW_W + 2) <= 4000 && o.match >= 0 && o.mismatch >= 0 &&
@@ -2930,6 +3010,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             join_long();
             {
                 KTimer kt("assemble_count");
+                if (small_pieces) hipLaunchKernelGGL(assemble_lane_kernel<false>, grid1(as.n_pieces), dim3(WG), 0, stream(), as, nops.p, valid.p,
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr);
+                else
                 hipLaunchKernelGGL(assemble_kernel<false>, dim3(nba), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
                                    nullptr, nullptr, nullptr);
             }
@@ -2968,6 +3051,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                 join_long();
                 {
                     KTimer kt("assemble_count");
+                    if (small_pieces) hipLaunchKernelGGL(assemble_lane_kernel<false>, grid1(as.n_pieces), dim3(WG), 0, stream(), as, nops.p, valid.p,
+                                                         nullptr, nullptr, nullptr, nullptr, nullptr);
+                    else
                     hipLaunchKernelGGL(assemble_kernel<false>, dim3(nbl), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
                                        nullptr, nullptr, nullptr);
                 }
@@ -3017,6 +3103,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     // assemble
     if (o.stub_oh < 0) {
         KTimer kt("assemble_count");
+        if (small_pieces) hipLaunchKernelGGL(assemble_lane_kernel<false>, grid1(as.n_pieces), dim3(WG), 0, stream(), as, nops.p, valid.p,
+                                             nullptr, nullptr, nullptr, nullptr, nullptr);
+        else
         hipLaunchKernelGGL(assemble_kernel<false>, dim3(nba), dim3(WG), 0, stream(), as, nops.p, valid.p, nullptr, nullptr,
                            nullptr, nullptr, nullptr);
     }
@@ -3032,6 +3121,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     DBuf<uint64_t> hi(P), lo(P);
     {
         KTimer kt("assemble_write");
+        if (small_pieces) hipLaunchKernelGGL(assemble_lane_kernel<true>, grid1(as.n_pieces), dim3(WG), 0, stream(), as, nullptr, valid.p, ooff.p,
+                                             out.ops.p, recs.p, hi.p, lo.p);
+        else
         hipLaunchKernelGGL(assemble_kernel<true>, dim3(nba), dim3(WG), 0, stream(), as, nullptr, valid.p, ooff.p, out.ops.p,
                            recs.p, hi.p, lo.p);
     }

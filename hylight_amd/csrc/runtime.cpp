@@ -147,6 +147,7 @@ const char *const HOOK_NAMES[] = {
     "HLMI_ANCHOR_PAIRS",
     "HLMI_ANCHOR_SPLIT",
     "HLMI_ASM_STAGE_CAP",
+    "HLMI_ASM_WAVE",
     "HLMI_CHAIN_DP16_CHECK",
     "HLMI_CHAIN_NO_DP16",
     "HLMI_CHAIN_NO_SMALL",

@@ -66,6 +66,20 @@ def test_small_groups_chain_the_same_in_both_kernels(tmp_path, monkeypatch):
     assert a == open(tmp_path / "b.paf").read() and a.count("\n") > 0.6 * len(reads)
 
 
+def test_small_pieces_assemble_the_same_in_both_kernels(tmp_path, monkeypatch):
+    """The pieces of short reads have half a dozen alignment tasks: the piece kernels (task references, LONG flags, row
+    assembly) run a lane per piece there.  HLMI_ASM_WAVE keeps the wave-per-piece row assembly: same rows."""
+    reads, contigs = _short_reads_and_contigs(95)
+    q, t = tmp_path / "short.fa", tmp_path / "con.fa"
+    S.write_fasta(reads, q)
+    S.write_fasta(contigs, t)
+    api.ava(t, q, tmp_path / "a.paf", api.ava_opts_short())
+    monkeypatch.setenv("HLMI_ASM_WAVE", "1")
+    api.ava(t, q, tmp_path / "b.paf", api.ava_opts_short())
+    a = open(tmp_path / "a.paf").read()
+    assert a == open(tmp_path / "b.paf").read() and a.count("\n") > 0.6 * len(reads)
+
+
 def test_short_noisy_reads_vs_contigs_matches_oracle(tmp_path):
     """2 % / 1 % / 1 % read errors: the end bonus now decides between clipped and full-length alignments, extensions
     rarely match exactly (third certificate with the bonus row in play) and go through the 64-diagonal DP."""
