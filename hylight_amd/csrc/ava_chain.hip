@@ -37,6 +37,7 @@ constexpr bool INSTR = true;
 #else
 constexpr bool INSTR = false;
 #endif
+constexpr int SEED_GROUP_MIN_PER_QUERY = 2048;       // anchors per query from which a batch is grouped by seed_group_kernel (a workgroup per query)
 constexpr int QL_BITS = 16, T_BITS_MAX = 21, TPOS_BITS_MAX = 29;     // target positions: 29 bits (contigs as targets, HyLight.py:149,180); chain scores are
                                                                       // bounded by the QUERY length (22 bits in the packed DP, else 26: 6 tie-break bits in 32)
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
@@ -360,13 +361,13 @@ __global__ void gather_u64_at_kernel(const uint64_t *src, const uint64_t *idx, u
 // read call has a million waves of small groups a step: on one address their atomics took longer than the kernel's real work)
 constexpr int SMALL_N = 32;
 constexpr int TALLY_SLOTS = 64, TALLY_STRIDE = 16;       // 16 x 8 B = one 128-byte line per slot
-__global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, size_t n_anchors, uint32_t *key, uint32_t *order,
-                                      unsigned long long *tally) {
+__global__ void group_size_key_kernel(const uint32_t *gstart, const uint32_t *gsize, size_t n_groups, size_t n_anchors, uint32_t *key,
+                                      uint32_t *order, unsigned long long *tally) {
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     uint32_t sz = 0;
     if (g < n_groups) {
         const size_t e = g + 1 < n_groups ? gstart[g + 1] : n_anchors;
-        sz = (uint32_t)(e - gstart[g]);
+        sz = gsize ? gsize[g] : (uint32_t)(e - gstart[g]);
         key[g] = 0xffffu - (sz < 0xffffu ? sz : 0xffffu);
         order[g] = (uint32_t)g;
     }
@@ -382,14 +383,14 @@ __global__ void group_size_key_kernel(const uint32_t *gstart, size_t n_groups, s
 }
 
 // HLMI_GROUP_HIST=1: groups and anchors per power-of-two size class (tuning aid, statistics group_hist_*)
-__global__ void group_hist_kernel(const uint32_t *gstart, size_t n_groups, size_t n_anchors, unsigned long long *hist) {
+__global__ void group_hist_kernel(const uint32_t *gstart, const uint32_t *gsize, size_t n_groups, size_t n_anchors, unsigned long long *hist) {
     __shared__ unsigned long long h[64];
     if (threadIdx.x < 64) h[threadIdx.x] = 0;
     __syncthreads();
     size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (g < n_groups) {
         const size_t e = g + 1 < n_groups ? gstart[g + 1] : n_anchors;
-        const uint32_t sz = (uint32_t)(e - gstart[g]);
+        const uint32_t sz = gsize ? gsize[g] : (uint32_t)(e - gstart[g]);
         const int c = 31 - __clz((int)sz);
         atomicAdd(&h[c], 1ull);
         atomicAdd(&h[32 + c], (unsigned long long)sz);
@@ -416,6 +417,8 @@ struct ChainArgs {
     const void *skey;                 // (target << 1 | strand) of every anchor when the key word does not hold them
     int sk;                           //   its width in bytes (2 / 4), 0: the bits sit in `key` above the target position
     const uint32_t *gstart;
+    const uint32_t *gsize, *gq, *gts; // group records of seed_group.hip (nullptr: groups are the runs of the sorted batch, their
+                                      // query / target / strand sit in the anchors)
     const uint32_t *gorder;           // groups, largest first (the order the workgroups take them in)
     size_t n_list;                    // groups in gorder (this launch's share of the n_groups groups)
     size_t n_groups, n_anchors;
@@ -441,12 +444,17 @@ struct ChainArgs {
     unsigned long long *check_bad;    //   the full DP then compares its scores / predecessors with fp and counts differences
 };
 
-// query in the batch || target || strand of the group whose first anchor is b
-__device__ __forceinline__ uint64_t group_word(const ChainArgs &a, size_t b) {
+// query in the batch || target || strand of group g, whose first anchor is b
+__device__ __forceinline__ uint64_t group_word(const ChainArgs &a, size_t g, size_t b) {
+    if (a.gsize) return (uint64_t)a.gq[g] << (a.tb + 1) | a.gts[g];
     const uint64_t top = a.key[b] >> (a.vb + a.pb);
     if (!a.sk) return top;
     const uint32_t ts = a.sk == 2 ? (uint32_t)((const uint16_t *)a.skey)[b] : ((const uint32_t *)a.skey)[b];
     return top << (a.tb + 1) | ts;
+}
+__device__ __forceinline__ size_t group_end(const ChainArgs &a, size_t g, size_t b) {
+    if (a.gsize) return b + a.gsize[g];
+    return g + 1 < a.n_groups ? (size_t)a.gstart[g + 1] : a.n_anchors;
 }
 // target position, query position, span of anchor idx
 __device__ __forceinline__ void anchor_fields(const ChainArgs &a, size_t idx, int &t, int &q, int &sp) {
@@ -711,10 +719,10 @@ __device__ int dp16_groups(const ChainArgs &a, const int *pen_tab, size_t gi0, u
     int n = 0;
     if (gi < a.n_list) {
         g = a.gorder[gi];
-        const size_t b = a.gstart[g], e = g + 1 < a.n_groups ? (size_t)a.gstart[g + 1] : a.n_anchors;
+        const size_t b = a.gstart[g], e = group_end(a, g, b);
         n = (int)(e - b);
         if (n < a.min_cnt) n = 0;                                  // nobody chains it
-        const uint32_t strand = (uint32_t)group_word(a, b) & 1u;
+        const uint32_t strand = (uint32_t)group_word(a, g, b) & 1u;
         g_first = strand ? b + (size_t)(e - b) - 1 : b;
         g_step = strand ? -1 : 1;
     }
@@ -840,7 +848,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) __attribute__((amdgpu_waves_per_e
         }
         const size_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gorder[gi]);
         const size_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g]);
-        const size_t e = g + 1 < a.n_groups ? (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.gstart[g + 1]) : a.n_anchors;
+        const size_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)group_end(a, g, b));
         const int n = (int)(e - b);
         if (n < a.min_cnt) continue;
         // ---- DP ---------------------------------------------------------------------------------------------------
@@ -851,7 +859,7 @@ __global__ __launch_bounds__(64 * CHAIN_WAVES) __attribute__((amdgpu_waves_per_e
         // depend on f (gap geometry, gap cost look-up) is computed one step ahead.  Predecessors arrive in ascending
         // order, so "candidate >= best" gives ties to the closest one; M_best starts at span + 1 so that the first
         // predecessor needs candidate > span.
-        const uint64_t key0 = group_word(a, b);
+        const uint64_t key0 = group_word(a, g, b);
         const uint32_t qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1));
         const uint32_t tg = (uint32_t)(key0 >> 1) & ((1u << a.tb) - 1);
         const uint32_t strand = (uint32_t)key0 & 1u;
@@ -1133,18 +1141,18 @@ __global__ __launch_bounds__(64) void chain_small_kernel(ChainArgs a, size_t fir
     const int lane = threadIdx.x;
     const size_t u = (size_t)blockIdx.x * 64 + (size_t)lane;
     int n = 0;
-    size_t b = 0;
+    size_t b = 0, g = 0;
     uint32_t qg = 0, tg = 0, strand = 0;
     if (u < count) {
-        const size_t g = a.gorder[first + u];
+        g = a.gorder[first + u];
         b = a.gstart[g];
-        const size_t e = g + 1 < a.n_groups ? (size_t)a.gstart[g + 1] : a.n_anchors;
+        const size_t e = group_end(a, g, b);
         n = (int)(e - b);
         if (n > SMALL_N) { a.counters[2] = 1; n = 0; }         // (the host splits the list by size: cannot happen)
         if (n < a.min_cnt) n = 0;
     }
     if (n) {
-        const uint64_t key0 = group_word(a, b);
+        const uint64_t key0 = group_word(a, g, b);
         qg = a.q_lo + (uint32_t)(key0 >> (a.tb + 1));
         tg = (uint32_t)(key0 >> 1) & ((1u << a.tb) - 1);
         strand = (uint32_t)key0 & 1u;
@@ -1442,25 +1450,55 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     // (the word's query position is read back through 32 bits: 24 position bits above the 8 of the span)
     const bool fits = qbits + tb + 1 + pb + qpb + 8 <= 64 && qpb <= 24 && !pairs && !hook("HLMI_ANCHOR_SPLIT");
     const bool split = !fits && !pairs && qbits + pb + qpb + 8 <= 64 && qpb <= 24;
-    const int vb = fits || split ? qpb + 8 : 0;
+    int vb = fits || split ? qpb + 8 : 0;
     const char *force = hook("HLMI_ANCHOR_SPLIT");         // "4": the wide key also where two bytes would do
-    const int sk = split ? (tb + 1 <= 16 && !(force && force[0] == '4') ? 2 : 4) : 0;
+    int sk = split ? (tb + 1 <= 16 && !(force && force[0] == '4') ? 2 : 4) : 0;
     SeedArgs sa = make_seed_args(in, ix, plan, d_qlen, q_lo, q_hi);
     sa.pb = pb; sa.tb = tb; sa.vb = vb; sa.sk = sk;
     if (!sa.n_mz || !ix.n) return;
     const uint32_t *cnt = plan.cnt.p + in.qmz_off[q_lo];
-    DBuf<uint64_t> aoff(sa.n_mz);
-    exclusive_scan_u32_to_u64(cnt, aoff.p, sa.n_mz);
     size_t A = 0;                               // the plan knows the anchors of every query: no round trip to the device
     for (size_t q = q_lo; q < q_hi; ++q) A += plan.per_query[q];
     st.anchors += A;
-    stat_add("anchor_bytes", (double)A * (sk ? 8.0 + sk : vb ? 8.0 : 16.0));
     if (!A) return;
     if (A >= (1ull << 31) - 1024) fail(HLMI_EINVAL, "anchor batch too large");      // fixed points sit at 2 x anchor offsets
     HostTimer *ht_s = new HostTimer("seed_sort_phase");
-    DBuf<uint64_t> akey(A), aval(vb ? 1 : A);
-    DBuf<uint16_t> sk16(sk == 2 ? A : 0);
-    DBuf<uint32_t> sk32(sk == 4 ? A : 0);
+    // Long queries under the pair-once rule: grouped straight out of the index by seed_group_kernel - no anchor batch in
+    // generation order, no device-wide sort, no head selection (HLMI_SEED_SORT: the sort path everywhere; HLMI_SEED_GROUP: the
+    // grouping kernel also for batches of few anchors per query - test hooks for the two forms)
+    uint64_t max_per_query = 0;
+    size_t n_q_live = 0;
+    for (size_t q = q_lo; q < q_hi; ++q) { max_per_query = std::max<uint64_t>(max_per_query, plan.per_query[q]); n_q_live += plan.per_query[q] ? 1 : 0; }
+    GroupedAnchors ga;
+    bool grouped = ix.pair_once && !pairs && !hook("HLMI_ANCHOR_SPLIT") && !hook("HLMI_SEED_SORT") && qpb <= 24 && pb + qpb + 8 <= 64 &&
+                   seed_group_supported(q_hi - q_lo, A, max_per_query, qpb) &&
+                   (hook("HLMI_SEED_GROUP") || A >= (uint64_t)SEED_GROUP_MIN_PER_QUERY * n_q_live);
+    if (grouped) {
+        grouped = seed_group(in, ix, plan, d_qlen, q_lo, q_hi, qpb + 8, tb, o.min_cnt, A, ga);
+        if (!grouped) stat_add("seed_group_gave_up", 1);
+    }
+    if (grouped) stat_add("anchors_grouped_in_lds", (double)A);
+    DBuf<uint64_t> akey, aval;
+    DBuf<uint16_t> sk16;
+    DBuf<uint32_t> sk32;
+    DBuf<uint32_t> gstart;
+    const void *skey = nullptr;
+    const uint32_t *gsize_p = nullptr;
+    size_t G = 0;
+    stat_add("anchor_bytes", (double)A * (grouped ? 8.0 : sk ? 8.0 + sk : vb ? 8.0 : 16.0));
+    if (grouped) {
+        vb = qpb + 8; sk = 0;
+        akey = std::move(ga.key);
+        gstart = std::move(ga.gstart);
+        gsize_p = ga.gsize.p;
+        G = ga.G;
+        st.groups += ga.G_all;
+    } else {
+    DBuf<uint64_t> aoff(sa.n_mz);
+    exclusive_scan_u32_to_u64(cnt, aoff.p, sa.n_mz);
+    akey.alloc(A); aval.alloc(vb ? 1 : A);
+    sk16.alloc(sk == 2 ? A : 0);
+    sk32.alloc(sk == 4 ? A : 0);
     sa.oskey = sk == 2 ? (void *)sk16.p : (void *)sk32.p;
     {
         KTimer kt("seed_fill");
@@ -1478,11 +1516,12 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         else if (vb) sort_keys_u64(akey, A, vb + pb, vb + pb + 1 + tb);
         else sort_pairs_u64_u64(akey.p, aval.p, A, pb, pb + 1 + tb);
     }
-    const void *skey = sk == 2 ? (const void *)sk16.p : (const void *)sk32.p;
-    DBuf<uint32_t> gstart(A);
-    const size_t G = sk ? select_run_heads_split(skey, sk, akey.p, A, vb + pb, gstart.p)
-                        : select_run_heads_u64(akey.p, A, vb + pb, gstart.p);
+    skey = sk == 2 ? (const void *)sk16.p : (const void *)sk32.p;
+    gstart.alloc(A);
+    G = sk ? select_run_heads_split(skey, sk, akey.p, A, vb + pb, gstart.p)
+           : select_run_heads_u64(akey.p, A, vb + pb, gstart.p);
     st.groups += G;
+    }
     delete ht_s;
 
     HostTimer ht_c("chain_phase");
@@ -1495,7 +1534,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (G) {
         DBuf<unsigned long long> tally((size_t)TALLY_SLOTS * TALLY_STRIDE);
         tally.zero();
-        hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, gkey.p, gorder.p, tally.p);
+        hipLaunchKernelGGL(group_size_key_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, gsize_p, G, A, gkey.p, gorder.p, tally.p);
         sort_pairs_u32_u32(gkey.p, gorder.p, G, 0, 16);
         const std::vector<unsigned long long> ht = tally.download((size_t)TALLY_SLOTS * TALLY_STRIDE);
         unsigned long long a_small = 0;
@@ -1506,7 +1545,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         if (INSTR && hook("HLMI_GROUP_HIST")) {
             DBuf<unsigned long long> hist(64);
             hist.zero();
-            hipLaunchKernelGGL(group_hist_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, G, A, hist.p);
+            hipLaunchKernelGGL(group_hist_kernel, grid1(G), dim3(WG), 0, stream(), gstart.p, gsize_p, G, A, hist.p);
             const std::vector<unsigned long long> h = hist.download(64);
             for (int c = 0; c < 32; ++c) if (h[c]) {
                 char nm[48];
@@ -1516,6 +1555,7 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
         }
     }
     ca.key = akey.p; ca.val = aval.p; ca.skey = skey; ca.sk = sk; ca.gstart = gstart.p; ca.gorder = gorder.p; ca.n_groups = G; ca.n_anchors = A;
+    if (grouped) { ca.gsize = ga.gsize.p; ca.gq = ga.gq.p; ca.gts = ga.gts.p; }
     DBuf<int> root(A);
     DBuf<unsigned long long> peak(A);             // written by the kernel at every chain start before it is voted on
     DBuf<uint32_t> sbase(A), starts(A);

@@ -46,6 +46,19 @@ struct SeedPlan {
     std::vector<uint64_t> per_query;    // per query read
 };
 void plan_seeds(const AvaInput &in, const DevIndex &ix, SeedPlan &plan);
+// Anchors of a query batch grouped by (query, target, strand) without a device-wide sort (seed_group.hip): one 64-bit word per
+// anchor (tpos << vb | qpos << 8 | span), every group contiguous and in generation order, one record per group of at least
+// min_cnt anchors.
+struct GroupedAnchors {
+    DBuf<uint64_t> key;
+    DBuf<uint32_t> gstart, gsize, gq, gts;   // first anchor, anchors, query inside the batch, target << 1 | strand
+    size_t G = 0, G_all = 0;                 // records; groups of any size (statistics)
+};
+// can the batch take that path (widths, anchors per query)?
+bool seed_group_supported(size_t n_queries, uint64_t anchors, uint64_t max_per_query, int qpb);
+// false: the kernel met a group its counters do not hold - the caller sorts the batch instead
+bool seed_group(const AvaInput &in, const DevIndex &ix, const SeedPlan &plan, const uint32_t *d_qlen, size_t q_lo, size_t q_hi,
+                int vb, int tb, int min_cnt, size_t A, GroupedAnchors &out);
 // seeds + chains queries [q_lo,q_hi)
 void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const SeedPlan &plan,
                     const uint32_t *d_qlen, const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out,
