@@ -52,7 +52,7 @@ KERNEL_OF_TIMER = {"chain": "hlmi::chain_kernel", "chain_small": "hlmi::chain_sm
                    "align_classify": "hlmi::classify_kernel<1>", "assemble_write": "hlmi::assemble_kernel<true>",
                    "assemble_count": "hlmi::assemble_kernel<false>", "seed_fill": "hlmi::seed_kernel<true>",
                    "seed_count": "hlmi::seed_kernel<false>", "anchor_sort": "rocprim::radix_sort_onesweep",
-                   "seed_group": "hlmi::seed_group_kernel", "seed_group_prep": "hlmi::nz_fill_kernel",
+                   "seed_group_count": "hlmi::seed_count_kernel", "seed_group_place": "hlmi::seed_place_kernel", "seed_group_scan": "hlmi::seed_scan_kernel", "seed_group_prep": "hlmi::nz_fill_kernel",
                    "filter_v4": "hlmi::window_filter_kernel", "filter_pileup_heavy": "hlmi::snp_pileup_kernel",
                    "filter_pileup_light": "hlmi::snp_pileup_light_kernel"}
 
@@ -406,9 +406,11 @@ def main():
         "anchor_sort": 2 * AB,                         # one read + one write per anchor
         "seed_fill": 16 * M + 8 * A + AB,              # query minimizers, index occurrences (y), anchors out
         "seed_count": 16 * M + 4 * A,                  # query minimizers, rank/frequency word of every occurrence
-        # anchors grouped by (query, target, strand) without a sort (seed_group.hip): window records of the minimizers, every
-        # index entry once, every anchor out once (the kernel reads the entries twice: its second walk is traffic, not algorithm)
-        "seed_group": 16 * M + 8 * stats.get("anchors_grouped_in_lds", 0.0) + 8 * stats.get("anchors_grouped_in_lds", 0.0),
+        # anchors grouped by (query, target, strand) without a sort (seed_group.hip): records of the minimizers + every 4-byte
+        # index entry once per kernel, every anchor out once (a long query's pieces read its entries again: traffic, not algorithm)
+        "seed_group_count": 16 * M + 4 * stats.get("anchors_grouped_in_lds", 0.0),
+        "seed_group_place": 16 * M + 4 * stats.get("anchors_grouped_in_lds", 0.0) + 8 * stats.get("anchors_grouped_in_lds", 0.0),
+        "seed_group_scan": 12 * 1024 * 2 * stats.get("seed_group_pieces", 0.0),      # the pieces' tables, read and written back
         "seed_group_prep": (16 + 8 + 16) * M,          # minimizers + counts and runs in, window records out
         # task results (24 B) and their runs in, merged CIGAR ops + 64-byte rows out
         "assemble_write": 24 * NT + 4 * E + 4 * E + 64 * rows_in,
@@ -438,7 +440,7 @@ def main():
                 kernel_ms_per_step={k: round(v, 3) for k, v in sorted(kms.items(), key=lambda kv: -kv[1])})
 
     counts = {k: stats.get(k) for k in ("queries", "targets", "chunks_run", "bases_q", "bases_t", "minimizers_q", "index_entries",
-                                        "anchors", "anchor_bytes", "anchors_grouped_in_lds", "seed_group_gave_up", "seed_group_split_passes", "chain_groups", "pieces", "fixed_points", "align_tasks",
+                                        "anchors", "anchor_bytes", "anchors_grouped_in_lds", "seed_group_gave_up", "seed_group_pieces", "seed_group_query_table_full", "seed_group_piece_table_full", "chain_groups", "pieces", "fixed_points", "align_tasks",
                                         "align_tasks_dp", "align_tasks_fast", "align_dp_bases", "cigar_ops", "ava_rows",
                                         "rows_after_v4", "snp_events", "pairs", "rows_out")}
     pass_steps = shares

@@ -146,6 +146,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         if (!in.n_ranks) fail(HLMI_EINVAL, "AvaInput::n_ranks not set");
         build_index(tsk, in.d_chunk_of_t, in.d_rank_t, in.n_chunks, in.n_ranks, o, ix);
         tsk.mz.release();
+        if (hook("HLMI_SEED_GROUP")) seed_group_prepare(in, ix);
     }
 
     // ---- query batches ----------------------------------------------------------------------------------

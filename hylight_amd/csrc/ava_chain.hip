@@ -37,7 +37,6 @@ constexpr bool INSTR = true;
 #else
 constexpr bool INSTR = false;
 #endif
-constexpr int SEED_GROUP_MIN_PER_QUERY = 2048;       // anchors per query from which a batch is grouped by seed_group_kernel (a workgroup per query)
 constexpr int QL_BITS = 16, T_BITS_MAX = 21, TPOS_BITS_MAX = 29;     // target positions: 29 bits (contigs as targets, HyLight.py:149,180); chain scores are
                                                                       // bounded by the QUERY length (22 bits in the packed DP, else 26: 6 tie-break bits in 32)
 inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
@@ -1463,18 +1462,15 @@ void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts 
     if (!A) return;
     if (A >= (1ull << 31) - 1024) fail(HLMI_EINVAL, "anchor batch too large");      // fixed points sit at 2 x anchor offsets
     HostTimer *ht_s = new HostTimer("seed_sort_phase");
-    // Long queries under the pair-once rule: grouped straight out of the index by seed_group_kernel - no anchor batch in
-    // generation order, no device-wide sort, no head selection (HLMI_SEED_SORT: the sort path everywhere; HLMI_SEED_GROUP: the
-    // grouping kernel also for batches of few anchors per query - test hooks for the two forms)
-    uint64_t max_per_query = 0;
-    size_t n_q_live = 0;
-    for (size_t q = q_lo; q < q_hi; ++q) { max_per_query = std::max<uint64_t>(max_per_query, plan.per_query[q]); n_q_live += plan.per_query[q] ? 1 : 0; }
+    // HLMI_SEED_GROUP: the batch's anchors grouped straight out of the index by seed_group.hip (pieces of queries, partner tables in
+    // LDS, merge by target) - no anchor batch in generation order, no device-wide sort, no head selection.  Measured on C3
+    // (profiles/r05c_*): 108 ms per step for the 68 % of the anchors whose pieces fit their tables, i.e. about the 169 ms of
+    // fill + sort + heads for all of them - so the sort path stays the default and the kernels stay behind the switch.
     GroupedAnchors ga;
-    bool grouped = ix.pair_once && !pairs && !hook("HLMI_ANCHOR_SPLIT") && !hook("HLMI_SEED_SORT") && qpb <= 24 && pb + qpb + 8 <= 64 &&
-                   seed_group_supported(q_hi - q_lo, A, max_per_query, qpb) &&
-                   (hook("HLMI_SEED_GROUP") || A >= (uint64_t)SEED_GROUP_MIN_PER_QUERY * n_q_live);
+    bool grouped = hook("HLMI_SEED_GROUP") && ix.pair_once && !pairs && !hook("HLMI_ANCHOR_SPLIT") && qpb <= 24 && pb + qpb + 8 <= 64 &&
+                   seed_group_supported(ix, A, pb, qpb);
     if (grouped) {
-        grouped = seed_group(in, ix, plan, d_qlen, q_lo, q_hi, qpb + 8, tb, o.min_cnt, A, ga);
+        grouped = seed_group(in, ix, plan, d_qlen, q_lo, q_hi, qpb + 8, o.min_cnt, A, ga);
         if (!grouped) stat_add("seed_group_gave_up", 1);
     }
     if (grouped) stat_add("anchors_grouped_in_lds", (double)A);

@@ -18,6 +18,11 @@ struct DevIndex {
     DBuf<uint32_t> bucket;   // first entry of every value of the top bucket_bits key bits (2^bits + 1 offsets)
     int bucket_shift = 0, bucket_bits = 0;
     int pair_once = 1;       // seeding rule carried with the index (hlmi_ava_opts::pair_once)
+    // seed_group.hip: the entries once more as 32-bit words dense target << y32_sh | position << 1 | strand (dense = place of
+    // the target in the order (name rank, target), the order of a hash's entries); y32_sh = 0: not built
+    DBuf<uint32_t> y32, t_of_dense;
+    int y32_sh = 0;
+    std::vector<uint32_t> rank_of_dense;   // host: name ranks of the targets in dense order (ascending)
 };
 void build_index(const DevSketch &tsk, const uint32_t *d_chunk_of_t, const uint32_t *d_rank_t, uint32_t n_chunks,
                  uint64_t n_names, const hlmi_ava_opts &o, DevIndex &ix);      // n_names: bound of the name ranks
@@ -54,11 +59,12 @@ struct GroupedAnchors {
     DBuf<uint32_t> gstart, gsize, gq, gts;   // first anchor, anchors, query inside the batch, target << 1 | strand
     size_t G = 0, G_all = 0;                 // records; groups of any size (statistics)
 };
-// can the batch take that path (widths, anchors per query)?
-bool seed_group_supported(size_t n_queries, uint64_t anchors, uint64_t max_per_query, int qpb);
+void seed_group_prepare(const AvaInput &in, DevIndex &ix);       // once per index
+// can the batch take that path (widths)?
+bool seed_group_supported(const DevIndex &ix, uint64_t anchors, int pb, int qpb);
 // false: the kernel met a group its counters do not hold - the caller sorts the batch instead
 bool seed_group(const AvaInput &in, const DevIndex &ix, const SeedPlan &plan, const uint32_t *d_qlen, size_t q_lo, size_t q_hi,
-                int vb, int tb, int min_cnt, size_t A, GroupedAnchors &out);
+                int vb, int min_cnt, size_t A, GroupedAnchors &out);
 // seeds + chains queries [q_lo,q_hi)
 void seed_and_chain(const AvaInput &in, const DevIndex &ix, const hlmi_ava_opts &o, const SeedPlan &plan,
                     const uint32_t *d_qlen, const uint32_t *d_tlen, size_t q_lo, size_t q_hi, ChainOut &out,

@@ -34,6 +34,19 @@ __device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
+// min over the 64 lanes (unsigned, identity ~0), returned to every lane
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
+    int x = (int)v;
+    auto mn = [](int a, int b) { return (int)((uint32_t)a < (uint32_t)b ? (uint32_t)a : (uint32_t)b); };
+    x = mn(x, dpp_i32<0x111>(-1, x));
+    x = mn(x, dpp_i32<0x112>(-1, x));
+    x = mn(x, dpp_i32<0x114>(-1, x));
+    x = mn(x, dpp_i32<0x118>(-1, x));
+    x = mn(x, dpp_i32<0x142, 0xa>(-1, x));
+    x = mn(x, dpp_i32<0x143, 0xc>(-1, x));
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
 // max over the 64 lanes (signed), returned to every lane.  `old` = INT_MIN is the identity of signed max, which
 // is what lets the compiler fold every step into one v_max_i32_dpp (any other filler costs three instructions).
 __device__ __forceinline__ int wave_max_i32_dpp(int x) {

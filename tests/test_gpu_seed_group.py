@@ -1,8 +1,9 @@
-"""GPU: anchors grouped by seed_group_kernel (a workgroup per query, (target, strand) table in LDS, stable placement) give
-the rows of the sort path (seed fill + radix sort + head selection) and of the oracle, bit for bit.
+"""GPU: anchors grouped by seed_count_kernel / seed_place_kernel (a workgroup per query piece, table of its partners in LDS,
+merge by target from LDS-staged runs) give the rows of the sort path (seed fill + radix sort + head selection) and of the
+oracle, bit for bit.
 
-Batches of long queries take the grouping kernel by themselves (>= 2048 anchors per query on average); HLMI_SEED_GROUP forces
-it on small fixtures, HLMI_SEED_SORT forces the sort path.  Reference call: filter_overlap_slr2.py:51 (minimap2 -x ava-pb)."""
+HLMI_SEED_GROUP selects the grouping kernels (measured equal to the sort path on C3: off by default).  Reference call:
+filter_overlap_slr2.py:51 (minimap2 -x ava-pb)."""
 import numpy as np
 import pytest
 
@@ -21,8 +22,7 @@ def _sim(seed, n, **kw):
 
 
 def _run(tmp_path, fa_t, fa_q, name, monkeypatch, env):
-    for k in ("HLMI_SEED_GROUP", "HLMI_SEED_SORT"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("HLMI_SEED_GROUP", raising=False)
     if env:
         monkeypatch.setenv(env, "1")
     api.ava(fa_t, fa_q, tmp_path / name)
@@ -43,7 +43,7 @@ def test_grouped_equals_sorted_equals_oracle(tmp_path, monkeypatch, seed, n, kw)
     want = open(tmp_path / "o.paf").read()
     assert len(want.splitlines()) > 50
     got_g, st_g = _run(tmp_path, fa, fa, "g.paf", monkeypatch, "HLMI_SEED_GROUP")
-    got_s, st_s = _run(tmp_path, fa, fa, "s.paf", monkeypatch, "HLMI_SEED_SORT")
+    got_s, st_s = _run(tmp_path, fa, fa, "s.paf", monkeypatch, None)
     assert got_g == want
     assert got_s == want
     assert st_g["anchors_grouped_in_lds"] == st_g["anchors"] > 0
@@ -52,28 +52,31 @@ def test_grouped_equals_sorted_equals_oracle(tmp_path, monkeypatch, seed, n, kw)
     assert st_g["pieces"] == st_s["pieces"] and st_g["fixed_points"] == st_s["fixed_points"]
 
 
-def test_deep_batch_takes_the_grouping_kernel_by_itself(tmp_path, monkeypatch):
-    """25 x depth of 8 kb reads: ~20 000 anchors per query, the batch is grouped without the hook; the sort path agrees."""
-    reads = _sim(41, 70, n_strains=2, genome_len=22000, mean_len=8000, min_len=6000, max_len=12000)
+def test_deep_batch_with_several_pieces_per_query(tmp_path, monkeypatch):
+    """60 x depth of 12-20 kb reads: ~200 000 anchors per query = several pieces each (ranges of the query's minimizers of
+    ~96 k anchors: seed_scan_kernel puts their tables together); the sort path and the oracle agree."""
+    reads = _sim(41, 110, n_strains=2, genome_len=30000, mean_len=16000, min_len=12000, max_len=20000)
     fa = tmp_path / "r.fa"
     S.write_fasta(reads, fa)
-    got_d, st_d = _run(tmp_path, fa, fa, "d.paf", monkeypatch, None)
-    got_s, st_s = _run(tmp_path, fa, fa, "s.paf", monkeypatch, "HLMI_SEED_SORT")
+    got_d, st_d = _run(tmp_path, fa, fa, "d.paf", monkeypatch, "HLMI_SEED_GROUP")
+    got_s, st_s = _run(tmp_path, fa, fa, "s.paf", monkeypatch, None)
     OA.ava(fa, fa, tmp_path / "o.paf")
-    assert st_d["anchors_grouped_in_lds"] == st_d["anchors"] > 2048 * 60
+    assert st_d["anchors_grouped_in_lds"] == st_d["anchors"] > 0
+    assert st_d["seed_group_pieces"] >= 110 + 20                 # queries of more than 96 k anchors have two pieces and more
+    assert st_s.get("anchors_grouped_in_lds", 0) == 0
     assert got_d == got_s == open(tmp_path / "o.paf").read()
-    assert len(got_d.splitlines()) > 500
+    assert len(got_d.splitlines()) > 2000
 
 
 def test_more_partners_than_the_table_holds(tmp_path, monkeypatch):
-    """One long query against 1 500 short targets cut from it on both strands: more distinct (target, strand) keys than the
-    LDS table takes (1 024) - the kernel halves the targets of the sub-pass until they fit; rows as the sort path and the
-    oracle give them."""
+    """One long query against 3 000 short targets cut from it on both strands: more partners than the LDS table of a piece
+    takes (640 targets; the query's ~250 000 anchors make three pieces) - the kernel says so and the batch goes through the
+    sort path; rows as the oracle gives them."""
     rng = np.random.default_rng(7)
     g = S._BASES[rng.integers(0, 4, size=36000)]
     targets = []
-    for i in range(1500):
-        L = int(rng.integers(500, 900))
+    for i in range(3000):
+        L = int(rng.integers(250, 400))
         s = int(rng.integers(0, len(g) - L))
         seq = g[s:s + L].copy()
         if i & 1:
@@ -84,12 +87,12 @@ def test_more_partners_than_the_table_holds(tmp_path, monkeypatch):
     S.write_fasta(targets, fa_t)
     S.write_fasta(query, fa_q)
     got_g, st_g = _run(tmp_path, fa_t, fa_q, "g.paf", monkeypatch, "HLMI_SEED_GROUP")
-    got_s, st_s = _run(tmp_path, fa_t, fa_q, "s.paf", monkeypatch, "HLMI_SEED_SORT")
+    got_s, st_s = _run(tmp_path, fa_t, fa_q, "s.paf", monkeypatch, None)
     OA.ava(fa_t, fa_q, tmp_path / "o.paf")
     want = open(tmp_path / "o.paf").read()
-    assert len(want.splitlines()) > 1200
-    assert st_g["chain_groups"] > 1024
-    assert st_g["seed_group_split_passes"] >= 1
+    assert len(want.splitlines()) > 2400
+    assert st_g["chain_groups"] > 2048
+    assert st_g["seed_group_gave_up"] == 1 and st_g.get("anchors_grouped_in_lds", 0) == 0
     assert got_g == want
     assert got_s == want
 
