@@ -63,6 +63,28 @@ def _latest_profile(suffix, workload):
     return files[-1] if files else None
 
 
+def _lib_sha():
+    """sha256 (first 16 hex digits) of the library this run loaded."""
+    import hashlib
+    so = os.path.join(ROOT, "hylight_amd", "libhylight_mi.so")
+    return hashlib.sha256(open(so, "rb").read()).hexdigest()[:16] if os.path.exists(so) else None
+
+
+def profile_provenance(workload):
+    """Where `roofline.traffic` / `roofline.valu` come from: they are NOT measured by this run (PMC counters need their own
+    rocprofv3 passes: tools/profile_round.sh) but read from the newest committed passes of the same workload - file names,
+    and the hash of the library those passes profiled (written beside them by tools/profile_round.sh) next to the hash of the
+    library running now: a mismatch says the ratio is of an older build."""
+    out = {}
+    for suffix in ("pmc_traffic", "sq_counters"):
+        f = _latest_profile(suffix, workload)
+        if f:
+            sha_file = f.replace(f"_{suffix}.json", "_lib_sha.txt")
+            out[suffix] = dict(file=os.path.basename(f), profiled_lib_sha=(open(sha_file).read().strip() if os.path.exists(sha_file) else None))
+    out["this_lib_sha"] = _lib_sha()
+    return out
+
+
 def pmc_traffic(timer, workload):
     """HBM bytes per launch of the kernel behind `timer`, from the committed rocprofv3 --pmc passes of the SAME
     workload and step definition (profiles/*_<workload>_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE as
@@ -94,6 +116,45 @@ def pmc_valu(timer, workload):
     return dict(valu_issue_frac=round(busy, 4), valu_issue_vs_saturation=round(busy / 0.893, 4),
                 valu_insts_per_launch=insts / max(k.get("launches", 1), 1), frac_wait_any=k.get("frac_wait_any"),
                 source=os.path.basename(f))
+
+
+def graph_large(work):
+    """The metric's second half at a size that says something (the C3 step output is ~3 000 rows): the seeded layout PAF of
+    tests/test_gpu_graph_scale.py - 20 000 reads, 1.44 M rows, 2.9 M overlap records - through hlmi_miniasm with HyLight's
+    flags (script/HyLight.py:140: -d 10000 -n 1 -e 1 -c 1; PAF on disk -> GFA on disk), and through the reference itself
+    (oracle/_ref/miniasm = tools/miniasm compiled by oracle/Makefile, main.c:117-194) on this box's host."""
+    from hylight_amd import api
+    from hylight_amd import simulate as S
+    out = {}
+    try:
+        _, rows = S.layout_paf(1)
+        paf = os.path.join(work, "layout.paf")
+        with open(paf, "w") as f:
+            f.write("\n".join(rows) + "\n")
+        gfa = os.path.join(work, "layout.gfa")
+        api.miniasm(paf, None, gfa, bub_dist=10000, n_rounds_arg=1, max_ext=1, min_dp=1)          # (first call: pools, page cache)
+        ts = []
+        for _ in range(3):
+            t = time.time()
+            api.miniasm(paf, None, gfa, bub_dist=10000, n_rounds_arg=1, max_ext=1, min_dp=1)
+            ts.append(time.time() - t)
+        st = api.last_stats()
+        out.update(graph_build_large_s=round(min(ts), 4), graph_large_rows=len(rows), graph_large_overlaps=st.get("graph_overlaps"),
+                   graph_large_arcs=st.get("graph_arcs"), graph_large_unitigs=sum(1 for l in open(gfa) if l.startswith("S\t")))
+        ref = os.path.join(ROOT, "oracle", "_ref", "miniasm")
+        if os.path.exists(ref):
+            rt = []
+            for _ in range(2):
+                t = time.time()
+                r = subprocess.run([ref, "-d", "10000", "-n", "1", "-e", "1", "-c", "1", paf], capture_output=True)
+                rt.append(time.time() - t)
+            same = r.returncode == 0 and r.stdout == open(gfa, "rb").read()
+            out["cpu_baseline_graph"] = dict(value=round(min(rt), 4), unit="s", cores=1, kind="reference",
+                                             sample="the same 1.44 M-row PAF through oracle/_ref/miniasm (tools/miniasm, -d 10000 -n 1 -e 1 -c 1)",
+                                             gfa_identical=bool(same))
+    except Exception as e:
+        out["graph_large_error"] = str(e)[:200]
+    return out
 
 
 # ---- CPU baseline ------------------------------------------------------------------------------------------
@@ -206,6 +267,15 @@ def cpu_baseline(target_fa, query_fa, nsplit, stage, long_mode=True, budget_s=15
             api.split_reads2(query_fa, target_fa, nsplit, tmp, cf + ".gpu.w.paf", long=long_mode, rank=c, world=len(ranges), **stage)
             same_w = open(cf + ".gpu.w.paf").read().split("\n")[:-1] == kept
             checks = dict(chunk=c, candidate_rows=len(rows), gpu_rows_identical=same, final_rows=len(kept), gpu_worker_identical=same_w)
+            # the stage's own constants keep next to nothing at pooled depth: the same rows once more through the filter chain
+            # with -thre wide open and -len 1000, where the kept set is large and depends on every step before the rate test
+            # (tests/test_gpu_workloads_oracle.py sweeps -thre across the pair-count distribution)
+            wide = F.worker(rows, long_mode, 1000 if long_mode else stage["len_over"], stage["mc"], stage["iden"], threshold=1.0)
+            api.filter_chunk(cf + ".paf", cf + ".gpu.wide.paf", 1000 if long_mode else stage["len_over"], stage["mc"], stage["iden"], thre=1.0,
+                             long_mode=long_mode)
+            same_wide = open(cf + ".gpu.wide.paf").read().split("\n")[:-1] == wide
+            checks.update(rows_kept_thre_1=len(wide), gpu_filter_identical_thre_1=same_wide)
+            same_w = same_w and same_wide
             if not (same and same_w):
                 sys.stderr.write(f"PARITY FAILURE at the benched workload: chunk {c}: {checks}\n")
         done.append(c)
@@ -355,6 +425,7 @@ def main():
     rows = 0
     stats = None
     step_rows, step_s = [], []
+    share_load = {}             # slice of the pass -> (anchors, seconds): the 8 shares an 8-rank job hands out, seen one after the other
     for i in range(args.steps):
         ts = time.time()
         r = step(args.warmup + i)
@@ -362,6 +433,7 @@ def main():
         step_rows.append(r)
         rows += r
         stats = dict(step_stats)
+        share_load[(args.warmup + i) % shares if shares > 1 else 0] = (stats.get("anchors", 0.0), step_s[-1])
     fence()
     dt = time.time() - t0
     if world > 1:
@@ -374,7 +446,9 @@ def main():
         rows = int(tot[0])
     # the one exchange step of the path, per rank: seconds of sketch + all-gather per pass start, bytes received, rounds
     mine = dict(rank=rank, sketch_exchange_s=[round(x, 4) for x in t_prepare], bytes_received=int(getattr(runner, "exchange_bytes", 0)),
-                rounds=int(getattr(runner, "exchange_rounds", 0)))
+                rounds=int(getattr(runner, "exchange_rounds", 0)),
+                # load balance without an 8-GPU node: anchors and seconds of every share of the pass this rank walked through
+                shares_seen={str(k): dict(anchors=int(a), step_s=round(t, 4)) for k, (a, t) in sorted(share_load.items())})
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
@@ -433,6 +507,7 @@ def main():
     roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                 traffic=pmc_traffic(dom, args.workload), algorithmic_bytes_per_launch=bytes_per_launch,
                 avg_launch_ms=avg_ms, launches_per_step=launches, valu=pmc_valu(dom, args.workload),
+                profile_source=profile_provenance(args.workload),
                 # whole stage: SURVEY.md 8d's bytes_ava + bytes_filter evaluated on the counts of the last step, over
                 # that step's wall time
                 stage=dict(bytes_ava=b_ava, bytes_filter=b_flt, step_s=last_s,
@@ -483,6 +558,8 @@ def main():
         except Exception as e:                                    # the stage number stays valid without it
             line["graph_build_s"] = None
             line["graph_error"] = str(e)[:200]
+    if not args.no_graph and not short_calls and rank == 0:
+        line.update(graph_large(work))
     if os.environ.get("HL_BENCH_STATS"):
         sys.stderr.write("STATS " + json.dumps({k: round(v, 4) for k, v in sorted(stats.items())}) + "\n")
     if not args.no_cpu_baseline and world == 1:

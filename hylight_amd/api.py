@@ -247,6 +247,9 @@ def vq_transitive_edges(n_vertices, src, dst, ovlen=None, remove_trans=1):
     return list(flags[:n]), cnt.value
 
 
+DEVICE = "cuda"          # where the buffers that cross the C ABI live (stage.py allocates them with torch)
+
+
 class Job:
     """Staged stage run for the multi-GPU path (sketch shard -> all-gather -> run)."""
 

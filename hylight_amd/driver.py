@@ -35,10 +35,6 @@ from .stage import StagePool
 __version__ = "1.0.1-mi355x"
 EXIT_NO_FINAL = 3        # everything this implementation covers ran, but final_contigs.fa (the stage-b merge) was not written
 
-# test hook (tests/test_multirank_gloo.py): (job_factory, device) replacing api.Job on "cuda" - the CPU tests of the
-# N > 1 control flow run the driver over gloo with an oracle-backed job
-TEST_BACKEND = None
-
 
 def fq_or_fa(path):
     """toolkits.fq_or_fa (script/toolkits.py:7-18): first character decides."""
@@ -168,6 +164,16 @@ def build_parser():
     return p
 
 
+def _init_rank(args, world, local):
+    """This rank's GPU, the library on it, the process group of the run (RCCL)."""
+    import torch
+    n_dev = torch.cuda.device_count()                         # (counting devices does not initialise the GPU)
+    dev = args.device if world == 1 else local % max(n_dev, 1)
+    torch.cuda.set_device(dev)
+    api.init(dev, args.threads)
+    launch.init_process_group(dev)
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
@@ -177,17 +183,8 @@ def main(argv=None):
     rank, world, local = launch.rank_env()
     if launch.launched() and args.gpus not in (1, world):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if TEST_BACKEND is None:
-        import torch
-        n_dev = torch.cuda.device_count()                     # (counting devices does not initialise the GPU)
-        dev = args.device if world == 1 else local % max(n_dev, 1)
-        torch.cuda.set_device(dev)
-        api.init(dev, args.threads)
-        launch.init_process_group(dev)
-        pool = StagePool(rank, world)
-    else:
-        launch.init_process_group(backend="gloo")
-        pool = StagePool(rank, world, job_factory=TEST_BACKEND[0], device=TEST_BACKEND[1])
+    _init_rank(args, world, local)
+    pool = StagePool(rank, world)
     try:
         if rank != 0:
             pool.serve()

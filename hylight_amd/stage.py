@@ -22,15 +22,14 @@ SLAB = 32 << 20          # minimizers per rank and round (16 B each: 512 MiB per
 
 
 class StageRunner:
-    def __init__(self, reads_fa, ref_fa, nsplit, long_mode=True, rank=0, world=1, group=None, job=None,
-                 device="cuda", slab=SLAB, force_exchange=False):
-        """`job` / `device` exist for the CPU (gloo) tests of the exchange logic: the product always uses
-        api.Job on "cuda".  `force_exchange` takes the all-gather path with one rank as well (the RCCL calls of the N > 1
-        flow on a single card: tests/test_gpu_multirank.py)."""
-        self.rank, self.world, self.group, self.device = rank, world, group, device
+    def __init__(self, reads_fa, ref_fa, nsplit, long_mode=True, rank=0, world=1, group=None, slab=SLAB,
+                 force_exchange=False):
+        """`force_exchange` takes the all-gather path with one rank as well (the RCCL calls of the N > 1 flow on a single
+        card: tests/test_gpu_multirank.py).  The job is always api.Job, its buffers live on api.DEVICE."""
+        self.rank, self.world, self.group, self.device = rank, world, group, api.DEVICE
         self.force_exchange = force_exchange
         self.slab = max(1, int(slab))
-        self.job = job if job is not None else api.Job(reads_fa, ref_fa, nsplit, long_mode)
+        self.job = api.Job(reads_fa, ref_fa, nsplit, long_mode)
         self._keep = None
         self.exchange_rounds = 0
         self.exchange_bytes = 0          # bytes this rank received in the last exchange (minimizers + per-read counts)
@@ -140,11 +139,8 @@ class StagePool:
     in every stage call they are told about (the call's arguments are broadcast): each rank opens the same files, sketches
     its slice of the reads, runs its chunks (chunk i -> rank i % N), rank 0 merges.  With one rank this is a plain call."""
 
-    def __init__(self, rank=0, world=1, group=None, job_factory=None, device="cuda"):
-        """`job_factory(reads_fa, ref_fa, nsplit, long_mode)` / `device` exist for the CPU (gloo) tests, as in
-        StageRunner: the product always runs api.Job on "cuda"."""
+    def __init__(self, rank=0, world=1, group=None):
         self.rank, self.world, self.group = rank, world, group
-        self.job_factory, self.device = job_factory, device
         self.calls = 0
         self.broken = False          # a stage call failed on this rank: the other ranks are inside collectives, not in serve()
 
@@ -155,9 +151,7 @@ class StagePool:
         return obj[0]
 
     def _run(self, fa, ref, nsplit, out_file, len_over, mc, iden, long):
-        job = self.job_factory(fa, ref, nsplit, long) if self.job_factory else None
-        r = StageRunner(fa, ref, nsplit, long_mode=long, rank=self.rank, world=self.world, group=self.group, job=job,
-                        device=self.device)
+        r = StageRunner(fa, ref, nsplit, long_mode=long, rank=self.rank, world=self.world, group=self.group)
         try:
             n = r.run(out_file, len_over, mc, iden)
         except BaseException:

@@ -400,16 +400,23 @@ def pair_counts_np(sorted_lines, long_mode, mc):
     return {pair_key(names[int(k) >> 32], names[int(k) & 0xffffffff]): int(v) for k, v in zip(pu, pc)}
 
 
-def worker(raw_lines, long_mode, min_ovlp_len, mc, iden, fast=True):
+def worker(raw_lines, long_mode, min_ovlp_len, mc, iden, fast=True, threshold=0.0025, min_o=4):
     """One chunk: filter_overlap_slr2.main after the overlapper (slr2:51-152).  fast=False: the pile-up by the
-    definitional per-event functions (snp_pileup, supported_pair_counts) instead of their numpy restatement."""
+    definitional per-event functions (snp_pileup, supported_pair_counts) instead of their numpy restatement.
+    threshold / min_o: the script's -thre and -oh (slr2:24,26; the stage never overrides their defaults)."""
+    return worker_sweep(raw_lines, long_mode, min_ovlp_len, mc, iden, [threshold], fast, min_o)[threshold]
+
+
+def worker_sweep(raw_lines, long_mode, min_ovlp_len, mc, iden, thresholds, fast=True, min_o=4):
+    """worker() for several values of -thre at once: window filter, intermediate sort and pile-up are the same for all of
+    them (the pair counts of slr2:370-405 enter pass 2 only through `count / matchcount > thre`, slr2:90-96)."""
     kept = window_filter(raw_lines, variant=4, min_len=30, min_o=3)
     srt = sort_intermediate(kept)
     mutation = pair_counts_np(srt, long_mode, mc) if fast else None
     if mutation is None:
         snp, partners, intervals = snp_pileup(srt, long_mode)
         mutation = supported_pair_counts(snp, partners, intervals, mc)
-    return pass2(srt, mutation, long_mode, min_ovlp_len, iden)
+    return {t: pass2(srt, mutation, long_mode, min_ovlp_len, iden, threshold=t, min_o=min_o) for t in thresholds}
 
 
 def chunk_ranges(n_lines, nsplit):

@@ -40,10 +40,15 @@ def test_c5_is_dp_bound_and_rows_are_valid(c5):
     # the gaps of more than 256 bases between chained anchors (divergent strains) are LONG blocks now, not cuts of the chain:
     # every overlap is one row, with its CIGAR (round 3: fragments, most of them stub candidates with score-only tasks)
     assert st["align_tasks_long"] > 1e6 and st["align_tasks_long"] > 0.02 * st["ava_rows"]
-    # With whole-overlap rows in the pile-up every sequencing error of a read (1 % substitutions in C5's recipe) is an X against
-    # all its partners, i.e. a SUPPORTED key (slr2:370-405), and the pair rate test of pass 2 (> 0.0025, slr2:90-96) drops the
-    # pairs: the reference's filter is made for corrected reads, C5's final output is (nearly) empty - the work is in the
-    # candidate rows.  (Rounds 1-3 kept ~500 rows here: fragments whose partners' fragments never met in the pile-up.)
+    # C5's final output is (nearly) empty - the work is in the candidate rows, and candidate rows/s is what this workload
+    # measures.  Why: an error of read R at position p is an X against ALL of R's partners there, so on R's own key v = con
+    # and c = con - v = 0: not supported (slr2:383-396 wants c >= mc).  The keys that ARE supported sit on the partners' side:
+    # a position of read T collects the X of every read piled up on it that errs there, and at this pooled depth (hundreds of
+    # reads per position, 1 % errors) at least mc of them do at nearly every position while con - v stays large.  So every
+    # alignment crosses supported keys, its pair count / matchcount exceeds -thre 0.0025 (slr2:90-96) and the pair is dropped:
+    # the reference's filter is made for corrected reads.  (Rounds 1-3 kept ~500 rows here: fragments whose partners'
+    # fragments never met in the pile-up.)  The filter chain at this depth is compared with the oracle under a sweep of -thre
+    # in tests/test_gpu_workloads_oracle.py::test_c5_depth_sample_matches_the_oracle.
     assert st["rows_after_v4"] > 1e5 and st["snp_events"] > 1e8
     check_rows(out, cfg["stage"]["len_over"], cfg["stage"]["iden"], 0)
     assert rows == sum(1 for _ in open(out))

@@ -66,10 +66,26 @@ def test_one_whole_chunk_of_c3_matches_the_oracle(tmp_path):
     want, got = _lines(cf + ".oracle.paf"), _lines(cf + ".gpu.paf")
     assert len(want) > 100_000
     assert got == want, "whole C3 chunk, raw overlapper rows: " + _first_difference(got, want)
+    # The stage's own constants keep a handful of rows at this depth (a position of a read collects the X of every read piled
+    # up on it that errs there - at ~1000 x pooled depth at least mc of them do nearly everywhere, with con - v still large:
+    # supported keys of slr2:370-405 all along every alignment, and -thre 0.0025 drops nearly every pair): the comparison
+    # above says little about the pair counts.  So the same chunk's rows go through the filter chain with -thre swept across the
+    # distribution of count / matchcount and -len 1000: the survivors - tens of thousands - depend on every pair's count.
+    thresholds = [0.0025, 0.004, 0.008, 0.02, 1.0]
+    sweep = F.worker_sweep(want, True, 1000, stage["mc"], stage["iden"], thresholds)
     w = F.sort_scored(F.worker(want, True, stage["len_over"], stage["mc"], stage["iden"]))
     g = _lines(tmp_path / "w.paf")
     print(f"C3 chunk {c}: {len(want)} candidate rows, {len(w)} final rows")
     assert g == w, "whole C3 chunk, worker output: " + _first_difference(g, w)
+    sizes = {}
+    for t in thresholds:
+        api.filter_chunk(cf + ".oracle.paf", cf + f".f{t}.paf", 1000, stage["mc"], stage["iden"], thre=t)
+        gt, wt = _lines(cf + f".f{t}.paf"), sweep[t]
+        sizes[t] = len(wt)
+        assert gt == wt, f"whole C3 chunk, filter chain at -thre {t}: " + _first_difference(gt, wt)
+    print("C3 chunk, rows kept per -thre:", sizes)
+    assert sizes[1.0] > 100_000 and sizes[0.02] >= 10_000 and sizes[0.008] >= 10_000
+    assert sizes[0.0025] < sizes[0.004] < sizes[0.008] < sizes[0.02] <= sizes[1.0]      # the sweep crosses the distribution
 
 
 def _sampled_targets(fa, out, n, per_rec=2):
@@ -102,8 +118,21 @@ def test_c5_depth_sample_matches_the_oracle(tmp_path):
         assert got == want, f"C5 sample (stub_oh {stub}): " + _first_difference(got, want)
     stage = cfg["stage"]
     rows = _lines(tf + ".oracle3.paf")
-    print(f"C5 sample: {len(rows)} candidate rows of 48 targets, "
-          f"{len(F.worker(rows, True, stage['len_over'], stage['mc'], stage['iden']))} final rows")
+    # C5's reads carry 1 % substitutions.  On the erring read's own key v = con (all partners disagree), so c = con - v = 0 and
+    # the key is NOT supported; but a position of a partner collects the X of every read that errs there, at this depth at least
+    # mc of them nearly everywhere (slr2:383-396), so -thre 0.0025 drops every pair - the reference's filter is made for
+    # corrected reads.
+    # The filter chain is therefore compared with -thre swept across the distribution of count / matchcount.
+    thresholds = [0.0025, 0.02, 0.04, 1.0]
+    sweep = F.worker_sweep(rows, True, stage["len_over"], stage["mc"], stage["iden"], thresholds)
+    sizes = {}
+    for t in thresholds:
+        api.filter_chunk(tf + ".oracle3.paf", tf + f".f{t}.paf", stage["len_over"], stage["mc"], stage["iden"], thre=t)
+        gt = _lines(tf + f".f{t}.paf")
+        sizes[t] = len(sweep[t])
+        assert gt == sweep[t], f"C5 sample, filter chain at -thre {t}: " + _first_difference(gt, sweep[t])
+    print(f"C5 sample: {len(rows)} candidate rows of 48 targets, rows kept per -thre: {sizes}")
+    assert sizes[1.0] >= 1_000 and sizes[0.0025] <= sizes[0.02] <= sizes[0.04] <= sizes[1.0]
 
 
 def test_c4_short_calls_sample_matches_the_oracle(tmp_path):

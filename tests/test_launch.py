@@ -51,8 +51,10 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
 def _driver_rank(rank, world, port, argv, done_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     from hylight_amd import driver
-    from test_multirank_gloo import OracleJob
-    driver.TEST_BACKEND = (lambda fa, ref, nsplit, long_mode: OracleJob(fa, nsplit), "cpu")
+    from hylight_amd import launch as L
+    from test_multirank_gloo import patch_product_with_oracle_job
+    patch_product_with_oracle_job()
+    driver._init_rank = lambda args, world, local: L.init_process_group(backend="gloo")      # no GPU here: gloo ranks on the CPU
     rc = driver.main(argv)
     with open(os.path.join(done_dir, f"rc{rank}"), "w") as f:
         f.write(str(rc))

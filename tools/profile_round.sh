@@ -18,5 +18,6 @@ python tools/summarize_pmc.py "$out/${tag}_fetch/p_counter_collection.csv" "$out
 run ${tag}_sq1 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run ${tag}_sq2 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 python tools/summarize_sq.py "$out/${tag}_${wl}_sq_counters.json" "$out/${tag}_sq1/p_counter_collection.csv" "$out/${tag}_sq2/p_counter_collection.csv" > "$out/${tag}_${wl}_sq_counters.txt"
+sha256sum hylight_amd/libhylight_mi.so | cut -c1-16 > "$out/${tag}_${wl}_lib_sha.txt"
 find "$out" -name "*.csv" -size +1M -delete
 ls "$out" | grep "^${tag}_" | head -30
