@@ -32,8 +32,11 @@ class VqOverlap(C.Structure):
                 ("pad", C.c_char * 3)]
 
 
+ABI_VERSION = 5          # include/hylight_mi.h: HLMI_ABI_VERSION
+
 # every symbol include/hylight_mi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
+    "hlmi_abi_version": (C.c_int, []),
     "hlmi_init": (C.c_int, [C.c_int, C.c_int]),
     "hlmi_shutdown": (None, []),
     "hlmi_last_error": (C.c_char_p, []),
@@ -104,6 +107,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.hlmi_abi_version() != ABI_VERSION:          # (AvaOpts above mirrors the header's hlmi_ava_opts of that version)
+            raise ImportError(f"{LIB_PATH}: ABI version {lib.hlmi_abi_version()}, this binding is written for {ABI_VERSION}")
         _lib = lib
     return _lib
 

@@ -2653,7 +2653,8 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     if (o.zdrop > 0) {
         const int D = std::max(std::max(o.mismatch, o.ambi), o.gap_open + o.gap_ext);
         const int rows_down = D > 0 ? (o.zdrop + D - 1) / D : EXT_MAX;
-        ext_all_long = (long long)o.match * (EXT_MAX - rows_down) > o.zdrop;
+        // (the best cell is ranked with the end bonus: a row that reaches the query end counts end_bonus more)
+        ext_all_long = (long long)o.match * (EXT_MAX - rows_down) + std::max(o.end_bonus, 0) > o.zdrop;
     }
     const uint32_t long_chunks_cap = (uint32_t)(long_rows_cap(o) + 31) / 32, long_runs_cap = (uint32_t)(2 * long_rows_cap(o) + 64);
     // 8 workgroups of 4 waves per CU: the walks of the tasks wait on memory.  (Fewer - to leave wave slots to the kernels on the
@@ -2668,15 +2669,18 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
     struct LongReady { AlignArgs al; LongArgs la; unsigned nb; bool half, tb; const char *timer; };
     std::vector<LongReady> long_ready;                   // prepared, not yet launched
     hipEvent_t long_done = nullptr;
-    bool long_pending = false;
+    bool long_pending = false, long_on_side = false;     // launches not yet joined / some of them on the second stream
     struct SideGuard {                                   // an exception on the way out must not free buffers the side stream still uses
-        ~SideGuard() { (void)hipStreamSynchronize(side_stream()); }
+        ~SideGuard() { if (hipStream_t s = side_stream_if_created()) (void)hipStreamSynchronize(s); }      // (never creates it, never throws)
     } side_guard;
     auto join_long = [&]() {
         if (!long_pending) return;
-        if (!long_done) HIP_CHECK(hipEventCreateWithFlags(&long_done, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(long_done, side_stream()));
-        HIP_CHECK(hipStreamWaitEvent(stream(), long_done, 0));
+        if (long_on_side) {                              // (in line on the compute stream - the default - there is nothing to join)
+            if (!long_done) HIP_CHECK(hipEventCreateWithFlags(&long_done, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(long_done, side_stream()));
+            HIP_CHECK(hipStreamWaitEvent(stream(), long_done, 0));
+            long_on_side = false;
+        }
         long_pending = false;
     };
     DBuf<uint8_t> long_flag;
@@ -2822,7 +2826,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             // in line on the compute stream.  (HLMI_LONG_SIDE_STREAM: on the second stream, beside the DP kernels that follow -
             // measured equal, C3 slice 957 vs 961 ms, C5 chunk 3.55 vs 3.56 s: the card is busy either way, and kernels that
             // share it stretch each other's timers, which is why the default is the one stream)
-            hipStream_t ls = hook("HLMI_LONG_SIDE_STREAM") ? side_stream() : stream();
+            const bool on_side = hook("HLMI_LONG_SIDE_STREAM") != nullptr;
+            hipStream_t ls = on_side ? side_stream() : stream();
+            long_on_side = long_on_side || on_side;
             for (const LongReady &r : long_ready) {
                 KTimer kt(r.timer, ls);
                 const bool two = aa.go2 > 0;
@@ -2851,7 +2857,9 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
                 const std::vector<uint32_t> c = L->ctl.download(4);
                 if (c[1]) fail(HLMI_EINVAL, "an alignment task exceeds the scratch area of align_long_kernel");
                 long_rows_run += (double)((unsigned long long)c[3] << 32 | c[2]);
-                L->ctl.release();                                  // (read once)
+                // (read once; the launch is over - joined and waited for -: its planes (GBs at max_gap 10 000), runs and list go
+                //  back to the pool now, not when align_span returns: a retry of the span allocates them again)
+                L->ctl.release(); L->planes.release(); L->runs.release(); L->list.release();
             }
         };
         // the tasks of stub candidates (cls_bare): score-only kernels over their own four lists

@@ -57,6 +57,7 @@ extern "C" {
 int hlmi_init(int device, int host_threads) {
     return guarded([&] { init_device(device, host_threads); });
 }
+int hlmi_abi_version(void) { return HLMI_ABI_VERSION; }
 void hlmi_shutdown(void) { shutdown_device(); }
 const char *hlmi_last_error(void) { return last_error().c_str(); }
 const char *hlmi_version(void) { return "hylight-mi355x 0.1 (gfx950)"; }

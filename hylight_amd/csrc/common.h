@@ -107,6 +107,7 @@ struct DBuf {
 };
 
 hipStream_t side_stream();       // second stream (runtime.cpp): LONG alignment tasks beside the batch's other DP kernels
+hipStream_t side_stream_if_created();      // the same without creating it (nullptr: never used) - for destructors
 inline void sync() { HIP_CHECK(hipStreamSynchronize(stream())); }
 
 // Scoped HIP-event timer on the library stream: per-kernel device time for bench.py's roofline line

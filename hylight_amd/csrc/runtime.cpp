@@ -76,6 +76,7 @@ void require_device() {
 hipStream_t stream() { return g_stream; }
 // second stream: the few LONG alignment tasks of a batch (serial rows, a tail of minutes of wave time on a handful of CUs) run
 // here beside the batch's other DP kernels; the caller joins it with an event before anything reads their results
+hipStream_t side_stream_if_created() { return g_side; }
 hipStream_t side_stream() {
     if (!g_side) {
         // highest priority: its few waves are the tail of the batch - they should never wait for an issue slot behind the

@@ -34,6 +34,11 @@ extern "C" {
 /* Select the HIP device used by this process (one process per GPU).  device < 0 keeps the
  * current device.  host_threads bounds host-side helper threads (text formatting, sorting,
  * the output writer); <= 0: the CPUs this process may run on, 16 at most. */
+/* ABI version: bumped whenever a public struct grows or an entry point changes (5: hlmi_ava_opts ends in zdrop).  A caller
+ * compares hlmi_abi_version() with the HLMI_ABI_VERSION of the header it was built against BEFORE passing structs: a caller of
+ * an older header would hand over a shorter hlmi_ava_opts than the library reads. */
+#define HLMI_ABI_VERSION 5
+int         hlmi_abi_version(void);
 int         hlmi_init(int device, int host_threads);
 void        hlmi_shutdown(void);
 const char *hlmi_last_error(void);

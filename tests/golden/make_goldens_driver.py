@@ -94,6 +94,13 @@ def main_c1():
             raise SystemExit(f"the reference run did not produce {rel}")
         gz(src, os.path.join(HERE, name))
         print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+    meta["provenance"] = {
+        "driver_and_filters": "the reference's own code, run unmodified (script/HyLight.py, utils.split_reads2, filter_overlap_slr2.py, tools/miniasm)",
+        "overlapper": "NOT minimap2 (absent from the reference tree, SURVEY.md D1): a stand-in on $PATH that answers with this repo's "
+                      "oracle/ava_oracle.c for the same chunk and read file - the PAF rows entering the reference's filters are this project's "
+                      "specification of the overlapper, and these goldens are regenerated when that specification changes",
+        "oracle_sha256": hashlib.sha256(open(os.path.join(ROOT, "oracle", "ava_oracle.c"), "rb").read()).hexdigest(),
+        "oracle_commit": subprocess.run(["git", "log", "-1", "--format=%h", "--", "oracle/ava_oracle.c"], cwd=ROOT, capture_output=True, text=True).stdout.strip()}
     meta["s1_fa_sha256"] = hashlib.sha256(open(os.path.join(out, "1.split_fastx/s1.fa"), "rb").read()).hexdigest()
     meta["paf_rows"] = sum(1 for _ in open(os.path.join(out, "2.overlap/s1_s1.paf")))
     with open(os.path.join(HERE, "fxG_meta.json"), "w") as f:

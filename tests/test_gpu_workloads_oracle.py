@@ -117,7 +117,7 @@ def test_c5_depth_sample_matches_the_oracle(tmp_path):
         assert len(want) > 5_000
         assert got == want, f"C5 sample (stub_oh {stub}): " + _first_difference(got, want)
     stage = cfg["stage"]
-    rows = _lines(tf + ".oracle3.paf")
+    rows = _lines(tf + ".oracle-1.paf")        # (every row with its CIGAR: the stub rule's bare rows end in cg:Z:*)
     # C5's reads carry 1 % substitutions.  On the erring read's own key v = con (all partners disagree), so c = con - v = 0 and
     # the key is NOT supported; but a position of a partner collects the X of every read that errs there, at this depth at least
     # mc of them nearly everywhere (slr2:383-396), so -thre 0.0025 drops every pair - the reference's filter is made for
@@ -127,7 +127,7 @@ def test_c5_depth_sample_matches_the_oracle(tmp_path):
     sweep = F.worker_sweep(rows, True, stage["len_over"], stage["mc"], stage["iden"], thresholds)
     sizes = {}
     for t in thresholds:
-        api.filter_chunk(tf + ".oracle3.paf", tf + f".f{t}.paf", stage["len_over"], stage["mc"], stage["iden"], thre=t)
+        api.filter_chunk(tf + ".oracle-1.paf", tf + f".f{t}.paf", stage["len_over"], stage["mc"], stage["iden"], thre=t)
         gt = _lines(tf + f".f{t}.paf")
         sizes[t] = len(sweep[t])
         assert gt == sweep[t], f"C5 sample, filter chain at -thre {t}: " + _first_difference(gt, sweep[t])
