@@ -240,7 +240,10 @@ __global__ __launch_bounds__(WG) void seed_kernel(SeedArgs a, uint32_t *cnt, con
                 }
             } else if (a.pair_once) {                            // only partners that rank above the query
                 lo = first_ge(b_lo, key, rq + 2);
-                hi = first_ge(lo, key + 1, 0u);
+                // (at read-set depth a bucket is one key's run: when the bucket's last entry carries the key, the run ends with
+                //  the bucket - one word instead of a second search over the same hundred entries)
+                if (a.rb && b_hi > b_lo && (a.ick[b_hi - 1] >> a.rb) == key) hi = b_hi > lo ? b_hi : lo;
+                else hi = first_ge(lo, key + 1, 0u);
                 c = (uint32_t)(hi - lo);
             } else {                                             // every partner but the read itself
                 lo = first_ge(b_lo, key, 1u);

@@ -13,6 +13,7 @@
 #include "ava.h"
 #include "filter_stage.h"
 #include "paf_io.h"
+#include "row_text.h"
 
 namespace hlmi {
 
@@ -38,6 +39,7 @@ struct Job::Impl {
     // text buffers of the last pass, kept for the next one (capacity only): a short-read call formats ~400 MB of rows per
     // pass, and fresh memory costs a page fault per 4 KB under a lock all formatting threads share
     std::vector<std::unique_ptr<std::string>> text_cache;
+    DevNames d_names;                 // the reads' names in HBM (uploaded when the first pass formats its rows on the device)
 };
 
 static double now_s() {
@@ -312,6 +314,47 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
             filter_stage_device(rows.recs.p + r0, (size_t)(r1 - r0), rows.ops_base, crs, cfg, fo);
             n_v4 += fo.n_after_v4; n_ev += fo.n_events; n_pairs += fo.n_pairs;
             const double tf = now_s();
+            // Rows -> text.  Many rows (the short-read calls keep millions per pass): on the device (row_text.hip), the host only
+            // takes the few rows the device's "%.4f" does not cover.  Few rows: on the host threads as before (HLMI_TEXT_GPU /
+            // HLMI_TEXT_HOST: test hooks for the two forms).
+            const bool text_on_gpu = !hook("HLMI_TEXT_HOST") && (fo.rows.size() >= 65536 || hook("HLMI_TEXT_GPU"));
+            if (text_on_gpu) {
+                if (!m.d_names.n) m.d_names.upload(m.name_of_rank);
+                RowText rt;
+                format_rows_device(rows.recs.p + r0, fo.rows, fo.x_digit_sum, m.d_names, iden, rt);
+                t_dl += now_s() - tf;
+                std::unique_ptr<std::string> extra(new std::string());        // rows formatted by the host
+                std::vector<std::pair<size_t, std::pair<size_t, size_t>>> extra_at;     // row -> (offset, length) in *extra
+                for (size_t i = 0; i < fo.rows.size(); ++i)
+                    if (rt.len[i] == ROW_TEXT_TO_HOST) {
+                        const std::vector<PafRec> one = download_rows(rows.recs.p + r0, std::vector<uint32_t>(1, fo.rows[i]));
+                        std::string tmp;
+                        uint32_t k = 0;
+                        if (format_scored_row(one[0], m.name_of_rank[one[0].qid], m.name_of_rank[one[0].tid], fo.x_digit_sum[i], iden, tmp, &k)) {
+                            extra_at.push_back({i, {extra->size(), tmp.size()}});
+                            extra->append(tmp);
+                            rt.key[i] = k;
+                        }
+                    }
+                stat_add("rows_text_on_gpu", (double)fo.rows.size());
+                stat_add("rows_text_left_to_host", (double)extra_at.size());
+                text.emplace_back(new std::string(std::move(rt.text)));
+                const std::string &buf = *text.back();
+                text.emplace_back(std::move(extra));
+                const std::string &ebuf = *text.back();
+                size_t e = 0;
+                lines.reserve(lines.size() + fo.rows.size());
+                line_keys.reserve(line_keys.size() + fo.rows.size());
+                for (size_t i = 0; i < fo.rows.size(); ++i) {               // stream order kept (the final sort is total anyway)
+                    if (rt.len[i] == ROW_TEXT_TO_HOST) {
+                        if (e < extra_at.size() && extra_at[e].first == i) {
+                            lines.emplace_back(ebuf.data() + extra_at[e].second.first, extra_at[e].second.second);
+                            line_keys.push_back(rt.key[i]);
+                            ++e;
+                        }
+                    } else if (rt.len[i]) { lines.emplace_back(buf.data() + rt.at[i], rt.len[i]); line_keys.push_back(rt.key[i]); }
+                }
+            } else {
             std::vector<PafRec> kept = download_rows(rows.recs.p + r0, fo.rows);
             t_dl += now_s() - tf;
             {   // rows -> text on the host threads (three %.4f conversions per row dominate), order kept
@@ -344,6 +387,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
                     for (size_t i = nk * (size_t)t / nt; i < nk * (size_t)(t + 1) / nt; ++i)
                         if (len[i]) { lines.emplace_back(buf.data() + at[i], len[i]); line_keys.push_back(key[i]); }
                 }
+            }
             }
             t_fmt_sub += now_s() - tf;
             c0 = c1;
