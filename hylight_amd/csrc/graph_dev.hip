@@ -36,17 +36,23 @@ inline dim3 grid1(size_t n) { return dim3(cdiv(n ? n : 1, WG)); }
 // ---------------------------------------------------------------------------------------------
 struct PafRow {                 // one parsed line (paf.h:21-25)
     uint32_t ql, qs, qe, tl, ts, te, ml, bl;
-    uint32_t qn_off, qn_len, tn_off, tn_len;
+    uint64_t qn_off, tn_off;     // (byte offsets into the file: a merged PAF may exceed 4 GiB)
+    uint32_t qn_len, tn_len;
     uint32_t rev;
 };
 
-__global__ void line_start_kernel(const uint8_t *txt, size_t n, uint8_t *flag) {
+// flags of the window txt[base .. base + n): 1 where a line starts
+__global__ void line_start_kernel(const uint8_t *txt, size_t base, size_t n, uint8_t *flag) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i == 0 || txt[i - 1] == '\n') ? 1 : 0;
+    if (i < n) flag[i] = (base + i == 0 || txt[base + i - 1] == '\n') ? 1 : 0;
+}
+__global__ void add_base_kernel(const uint32_t *rel, size_t n, uint64_t base, uint64_t *out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base + rel[i];
 }
 
 // strtol(token, 0, 10) truncated to 32 bits: white space, sign, digits, saturation at LONG_MIN / LONG_MAX
-__device__ uint32_t strtol_u32(const uint8_t *s, uint32_t a, uint32_t b) {
+__device__ uint32_t strtol_u32(const uint8_t *s, uint64_t a, uint64_t b) {
     while (a < b && (s[a] == ' ' || (s[a] >= 9 && s[a] <= 13))) ++a;
     bool neg = false;
     if (a < b && (s[a] == '+' || s[a] == '-')) { neg = s[a] == '-'; ++a; }
@@ -62,25 +68,25 @@ __device__ uint32_t strtol_u32(const uint8_t *s, uint32_t a, uint32_t b) {
     return (uint32_t)(neg ? 0ull - v : v);
 }
 
-__global__ void parse_rows_kernel(const uint8_t *txt, size_t n_bytes, const uint32_t *line_start, size_t n_lines, int min_span,
+__global__ void parse_rows_kernel(const uint8_t *txt, size_t n_bytes, const uint64_t *line_start, size_t n_lines, int min_span,
                                   int min_match, PafRow *rows, uint8_t *ok) {
     size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (L >= n_lines) return;
-    uint32_t a = line_start[L];
-    uint32_t e = L + 1 < n_lines ? line_start[L + 1] - 1 : (uint32_t)(txt[n_bytes - 1] == '\n' ? n_bytes - 1 : n_bytes);
+    uint64_t a = line_start[L];
+    uint64_t e = L + 1 < n_lines ? line_start[L + 1] - 1 : (uint64_t)(txt[n_bytes - 1] == '\n' ? n_bytes - 1 : n_bytes);
     if (e - a > 1 && txt[e - 1] == '\r') --e;           // the line reader drops one trailing CR (kseq.h)
     PafRow r{};
     int t = 0;
-    uint32_t p = a;
-    for (uint32_t i = a; i <= e; ++i) {
+    uint64_t p = a;
+    for (uint64_t i = a; i <= e; ++i) {
         if (i < e && txt[i] != '\t') continue;
         switch (t) {                                     // paf.c:42-55
-            case 0: r.qn_off = p; r.qn_len = i - p; break;
+            case 0: r.qn_off = p; r.qn_len = (uint32_t)(i - p); break;
             case 1: r.ql = strtol_u32(txt, p, i); break;
             case 2: r.qs = strtol_u32(txt, p, i); break;
             case 3: r.qe = strtol_u32(txt, p, i); break;
             case 4: r.rev = p < i && txt[p] == '-'; break;
-            case 5: r.tn_off = p; r.tn_len = i - p; break;
+            case 5: r.tn_off = p; r.tn_len = (uint32_t)(i - p); break;
             case 6: r.tl = strtol_u32(txt, p, i); break;
             case 7: r.ts = strtol_u32(txt, p, i); break;
             case 8: r.te = strtol_u32(txt, p, i); break;
@@ -101,7 +107,7 @@ __global__ void parse_rows_kernel(const uint8_t *txt, size_t n_bytes, const uint
 // a9: names -> ids in order of first appearance
 // ---------------------------------------------------------------------------------------------
 // occurrence 2 i = query name of kept row i, 2 i + 1 = its target name (the order sd_put sees them, hit.c:88-90)
-__device__ __forceinline__ void occ_name(const PafRow *rows, const uint32_t *kept, uint32_t occ, uint32_t &off, uint32_t &len) {
+__device__ __forceinline__ void occ_name(const PafRow *rows, const uint32_t *kept, uint32_t occ, uint64_t &off, uint32_t &len) {
     const PafRow &r = rows[kept[occ >> 1]];
     off = (occ & 1) ? r.tn_off : r.qn_off;
     len = (occ & 1) ? r.tn_len : r.qn_len;
@@ -110,7 +116,8 @@ __global__ void name_hash_kernel(const uint8_t *txt, const PafRow *rows, const u
                                  uint64_t *hash, uint32_t *occ_id) {
     size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (o >= n_occ) return;
-    uint32_t off, len;
+    uint64_t off;
+    uint32_t len;
     occ_name(rows, kept, (uint32_t)o, off, len);
     uint64_t h = seed ^ (0x9e3779b97f4a7c15ull * (len + 1));
     for (uint32_t i = 0; i < len; ++i) {
@@ -130,7 +137,8 @@ __global__ void name_group_kernel(const uint8_t *txt, const PafRow *rows, const 
     if (i >= n_occ) return;
     if (i == 0 || hash[i] != hash[i - 1]) { head[i] = 1; return; }
     head[i] = 0;
-    uint32_t o1, l1, o2, l2;
+    uint64_t o1, o2;
+    uint32_t l1, l2;
     occ_name(rows, kept, occ_sorted[i - 1], o1, l1);
     occ_name(rows, kept, occ_sorted[i], o2, l2);
     bool same = l1 == l2;
@@ -163,7 +171,8 @@ __global__ void name_ref_kernel(const PafRow *rows, const uint32_t *kept, const 
                                 size_t n_occ, uint64_t *ref_off, uint32_t *ref_len) {
     size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (o >= n_occ || !first[o]) return;
-    uint32_t off, len;
+    uint64_t off;
+    uint32_t len;
     occ_name(rows, kept, (uint32_t)o, off, len);
     ref_off[first_rank[o]] = off;
     ref_len[first_rank[o]] = len;
@@ -703,18 +712,42 @@ void graph_device(const char *paf_path, const GraphOpt &o, const std::string &un
     out.paf = read_file(paf_path);
     const size_t nb = out.paf.size();
     if (!nb) return;
-    if (nb >= 0xfffffff0ull) fail(HLMI_EINVAL, "%s: PAF files of 4 GiB and more are not supported by the graph stage", paf_path);
     KTimer kt_all("graph_device");
     DBuf<uint8_t> txt;
     txt.upload((const uint8_t *)out.paf.data(), nb);
     // ---- a9: lines -> rows ----------------------------------------------------------------------------------------
-    DBuf<uint32_t> line_start(nb);
-    size_t n_lines;
+    // Line starts as 64-bit byte offsets (a merged PAF may exceed 4 GiB), found window by window (a launch and a selection
+    // hold fewer than 2^32 items; HLMI_GRAPH_WINDOW_MB: small windows with small files, test hook): the windows' counts
+    // first, then the offsets into one array.
+    size_t pwin = (size_t)1 << 30;
+    if (const char *e = hook("HLMI_GRAPH_WINDOW_MB")) pwin = (size_t)std::max(1, atoi(e)) << 20;
+    DBuf<uint64_t> line_start;
+    size_t n_lines = 0;
     {
-        DBuf<uint8_t> flag(nb);
-        hipLaunchKernelGGL(line_start_kernel, grid1(nb), dim3(WG), 0, stream(), txt.p, nb, flag.p);
-        n_lines = select_flagged_indices(flag.p, line_start.p, nb);
+        DBuf<uint8_t> flag(std::min(pwin, nb));
+        DBuf<uint32_t> rel(std::min(pwin, nb));
+        std::vector<size_t> per_window;
+        for (size_t b = 0; b < nb; b += pwin) {
+            const size_t n = std::min(pwin, nb - b);
+            hipLaunchKernelGGL(line_start_kernel, grid1(n), dim3(WG), 0, stream(), txt.p, b, n, flag.p);
+            per_window.push_back(select_flagged_indices(flag.p, rel.p, n));
+            n_lines += per_window.back();
+        }
+        line_start.alloc(n_lines ? n_lines : 1);
+        size_t at = 0, w = 0;
+        for (size_t b = 0; b < nb; b += pwin, ++w) {
+            const size_t n = std::min(pwin, nb - b);
+            if (per_window.size() > 1) {                             // (one window: its offsets are still in `rel`)
+                hipLaunchKernelGGL(line_start_kernel, grid1(n), dim3(WG), 0, stream(), txt.p, b, n, flag.p);
+                select_flagged_indices(flag.p, rel.p, n);
+            }
+            if (per_window[w]) hipLaunchKernelGGL(add_base_kernel, grid1(per_window[w]), dim3(WG), 0, stream(), rel.p, per_window[w], (uint64_t)b, line_start.p + at);
+            at += per_window[w];
+        }
+        HIP_CHECK(hipGetLastError());
+        stat_set("graph_parse_windows", (double)per_window.size());
     }
+    if (n_lines >= (1ull << 32)) fail(HLMI_EINVAL, "overlap graph: more than 2^32 lines in %s", paf_path);
     DBuf<PafRow> rows(n_lines);
     DBuf<uint32_t> kept(n_lines);
     size_t n_rows;

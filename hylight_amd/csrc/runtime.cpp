@@ -152,7 +152,7 @@ const char *const HOOK_NAMES[] = {
     "HLMI_CHAIN_DP16_CHECK",
     "HLMI_CHAIN_NO_DP16",
     "HLMI_CHAIN_NO_SMALL",
-    "HLMI_SEED_GROUP", "HLMI_TEXT_GPU", "HLMI_TEXT_HOST",
+    "HLMI_SEED_GROUP", "HLMI_TEXT_GPU", "HLMI_TEXT_HOST", "HLMI_GRAPH_WINDOW_MB",
     "HLMI_CHAIN_PROF",
     "HLMI_CHAIN_UNPACKED",
     "HLMI_GROUP_HIST",

@@ -37,6 +37,27 @@ def test_miniasm_fixture_A(golden, tmp_path, tag, fmt):
     assert open(out).read() == golden.text(f"fxA_miniasm_{tag}.{ext}")
 
 
+def test_line_starts_found_in_windows(golden, tmp_path, monkeypatch):
+    """Files of 4 GiB and more are parsed with 64-bit line offsets found window by window (1 GiB each); HLMI_GRAPH_WINDOW_MB
+    forces the same path through a small file: 1 MB windows over a ~20 MB PAF, lines straddling the window borders."""
+    rows = open(_plain(golden, "fxD1_messy.paf", tmp_path)).read().split("\n")[:-1]
+    big = tmp_path / "big.paf"
+    with open(big, "w") as f:
+        while f.tell() < 20 << 20:
+            f.write("\n".join(rows) + "\n")
+    outs = {}
+    for mb in (None, "1", "3"):
+        if mb:
+            monkeypatch.setenv("HLMI_GRAPH_WINDOW_MB", mb)
+        for fmt in ("ug", "paf"):
+            out = tmp_path / f"o{mb}.{fmt}"
+            api.miniasm(big, None, out, bub_dist=10000, max_ext=1, outfmt=fmt, **FLAGS["n1c1"])
+            outs[(mb, fmt)] = open(out, "rb").read()
+        assert api.last_stats()["graph_parse_windows"] == (1 if mb is None else -(-os.path.getsize(big) // (int(mb) << 20)))
+    for fmt in ("ug", "paf"):
+        assert outs[(None, fmt)] == outs[("1", fmt)] == outs[("3", fmt)] and len(outs[(None, fmt)]) > 1000
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 @pytest.mark.parametrize("tag", ["n1c1", "n3c3"])
 def test_miniasm_messy_graphs(golden, tmp_path, seed, tag):
