@@ -90,6 +90,8 @@ struct AvaInput {
     // same for the run's output: after the first query batch the rows + CIGARs of the whole run are projected from that
     // batch's bytes per anchor (divergent read sets carry five times the CIGAR ops per anchor of clean ones)
     uint64_t max_out_bytes = 0;
+    int max_lanes = 0;                 // query batches in flight (runtime.cpp: lanes); 0: the library's default (lane_count()), 1: one
+                                       // after the other - the stage says so when the card has no room for a second batch's buffers
 };
 // HBM a run's output occupies until the caller has filtered it: CIGAR ops once (they stay in their batch buffers), the
 // 64-byte records three times (per batch, concatenated, stream-ordered) plus their order keys

@@ -6,6 +6,12 @@
 #include <numeric>
 
 #include "ava_internal.h"
+
+#include <time.h>
+#include <atomic>
+#include <exception>
+#include <memory>
+#include <thread>
 #include "dev_prims.h"
 
 namespace hlmi {
@@ -112,7 +118,29 @@ __global__ __launch_bounds__(WG) void gather_sketch_kernel(const Mz *qmz, const 
     }
 }
 
+// start[c] = first row of the sorted keys whose chunk field (the upper half) is >= c; start[n_chunks] = n
+__global__ __launch_bounds__(WG) void chunk_row_start_kernel(const uint64_t *hi, size_t n, uint32_t n_chunks, uint64_t *start) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_chunks) return;
+    size_t lo = 0, up = n;
+    if (c == n_chunks) lo = n;
+    for (int it = 0; it < 64 && lo < up; ++it) {
+        const size_t mid = lo + (up - lo) / 2;
+        if ((uint32_t)(hi[mid] >> 32) < c) lo = mid + 1; else up = mid;
+    }
+    start[c] = lo;
+}
+
+// pieces of a set-aside part behind the parts of earlier batches: their fixed points moved by `delta` (mod 2^32)
+__global__ __launch_bounds__(WG) void shift_fp_off_kernel(Piece *pieces, size_t n, uint32_t delta) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) pieces[i].fp_off += delta;
+}
+
 void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
+    timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    const double w_start = (double)ts0.tv_sec + 1e-9 * (double)ts0.tv_nsec;
     out = AvaRows();
     out.chunk_row_start.assign(in.n_chunks + 1, 0);
     const size_t nQ = in.Q->n, nT = in.T->n;
@@ -151,7 +179,6 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
 
     // ---- query batches ----------------------------------------------------------------------------------
     std::vector<AlignOut> parts;
-    DeferredPieces deferred;                 // pieces with LONG alignment tasks: aligned together after the last batch
     SeedStats st;
     SeedPlan plan;
     {
@@ -195,58 +222,160 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
         const int key_spare = 64 - (bits_for(nT > 1 ? nT - 1 : 1) + 1 + bits_for(max_tlen));
         q_cap = std::min<size_t>(q_cap, (size_t)1 << std::max(0, std::min(key_spare, 16)));
     }
-    size_t q = 0;
-    while (q < nQ) {
+    // wall clock of the pass's phases (no extra synchronisation: each phase ends drained)
+    auto wall = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double w_batches = wall();
+    stat_add("wall_s.ava_index_plan", w_batches - w_start);
+    // the batches of the pass: [q, hi) and their anchors
+    struct Batch { size_t q, hi; uint64_t acc; };
+    std::vector<Batch> batches;
+    for (size_t q = 0; q < nQ;) {
         uint64_t acc = 0;
         size_t hi = q;
         while (hi < nQ && hi - q < q_cap && (hi == q || acc < batch_target) && (hi == q || acc + plan.per_query[hi] <= anchor_batch + anchor_batch / 4))
             acc += plan.per_query[hi++];
+        batches.push_back(Batch{q, hi, acc});
+        q = hi;
+    }
+    // every batch leaves its rows, its deferred pieces and its counts in a slot of its own: whatever order the lanes finish them
+    // in, they are put together in batch order
+    const size_t nb = batches.size();
+    std::vector<std::vector<AlignOut>> parts_of(nb);
+    std::vector<DeferredPieces> deferred_of(nb);
+    std::vector<SeedStats> st_of(nb);
+    auto run_batch = [&](size_t b) {
         ChainOut ch;
         {
             HostTimer ht("seed_and_chain");
-            seed_and_chain(in, ix, o, plan, qlen.p, tlen.p, q, hi, ch, st);
+            seed_and_chain(in, ix, o, plan, qlen.p, tlen.p, batches[b].q, batches[b].hi, ch, st_of[b]);
         }
         stat_add("pieces", (double)ch.n_pieces);
         stat_add("fixed_points", (double)ch.n_fp);
         if (ch.n_pieces) {
             HostTimer ht("align_pieces");
-            const bool first = parts.empty();
-            const size_t before = parts.size();
-            align_pieces(in, o, qlen.p, tlen.p, ch, parts, &deferred);
-            if (in.max_out_bytes && in.n_chunks > 1 && first && acc && parts.size() > before) {     // first batch with output: project the run
-                size_t rows = 0, ops = 0;
-                for (size_t i = before; i < parts.size(); ++i) { rows += parts[i].n_rows; ops += parts[i].n_ops; }
-                const double projected = (double)ava_out_bytes(rows, ops) / (double)acc * (double)total_anchors;
-                if (projected > (double)in.max_out_bytes) {
-                    out.refused_anchors = total_anchors;
-                    out.refused_shrink = 0.8 * (double)in.max_out_bytes / projected;
-                    return;
-                }
+            align_pieces(in, o, qlen.p, tlen.p, ch, parts_of[b], &deferred_of[b]);
+        }
+    };
+    size_t done = 0;
+    bool projected_once = false;
+    // one after the other up to the first batch with output (the projection of the run's size wants it)
+    while (done < nb && !projected_once) {
+        run_batch(done);
+        const auto &first_parts = parts_of[done];
+        const uint64_t acc = batches[done].acc;
+        ++done;
+        if (first_parts.empty()) continue;
+        projected_once = true;
+        if (in.max_out_bytes && in.n_chunks > 1 && acc) {
+            size_t rows = 0, ops = 0;
+            for (const auto &p : first_parts) { rows += p.n_rows; ops += p.n_ops; }
+            const double projected = (double)ava_out_bytes(rows, ops) / (double)acc * (double)total_anchors;
+            if (projected > (double)in.max_out_bytes) {
+                out.refused_anchors = total_anchors;
+                out.refused_shrink = 0.8 * (double)in.max_out_bytes / projected;
+                return;
             }
         }
-        q = hi;
     }
-    if (deferred.n_pieces) {
-        HostTimer ht("align_deferred");
+    // The set-aside pieces (LONG tasks: few waves, each busy for milliseconds) of the batches [b0, b1) aligned together.  With
+    // lanes, the batches are cut into groups and the lane that finishes a group's last batch aligns the group's set at once,
+    // beside the other lane's batches; only the last group's set is left for the end of the pass (a C3 step spent 41 ms there
+    // with the device nearly idle).
+    std::vector<std::vector<AlignOut>> parts_late;          // one per group, in group order
+    auto align_set_aside = [&](size_t b0, size_t b1, std::vector<AlignOut> &outs) {
         ChainOut dc;
-        dc.n_pieces = deferred.n_pieces; dc.n_fp = deferred.n_fp;
+        for (size_t b = b0; b < b1; ++b) { dc.n_pieces += deferred_of[b].n_pieces; dc.n_fp += deferred_of[b].n_fp; }
+        if (!dc.n_pieces) return;
+        if (dc.n_fp >= (1ull << 32)) fail(HLMI_EINVAL, "more than 2^32 fixed points in the set-aside alignment pieces");
+        HostTimer ht("align_deferred");
         dc.pieces.alloc(dc.n_pieces);
         dc.fps.alloc(dc.n_fp);
         size_t p0 = 0, f0 = 0;
-        for (auto &part : deferred.parts) {
-            HIP_CHECK(hipMemcpyAsync(dc.pieces.p + p0, part.pieces.p, part.n_pieces * sizeof(Piece), hipMemcpyDeviceToDevice, stream()));
-            HIP_CHECK(hipMemcpyAsync(dc.fps.p + f0, part.fps.p, part.n_fp * sizeof(FixPt), hipMemcpyDeviceToDevice, stream()));
-            p0 += part.n_pieces; f0 += part.n_fp;
+        for (size_t b = b0; b < b1; ++b) {
+            for (auto &part : deferred_of[b].parts) {
+                HIP_CHECK(hipMemcpyAsync(dc.pieces.p + p0, part.pieces.p, part.n_pieces * sizeof(Piece), hipMemcpyDeviceToDevice, stream()));
+                HIP_CHECK(hipMemcpyAsync(dc.fps.p + f0, part.fps.p, part.n_fp * sizeof(FixPt), hipMemcpyDeviceToDevice, stream()));
+                if (f0 != part.fp_base)       // (Piece::fp_off counts from the start of the batch's own set)
+                    hipLaunchKernelGGL(shift_fp_off_kernel, grid1(part.n_pieces), dim3(WG), 0, stream(), dc.pieces.p + p0, part.n_pieces,
+                                       (uint32_t)(f0 - part.fp_base));
+                p0 += part.n_pieces; f0 += part.n_fp;
+            }
         }
+        HIP_CHECK(hipGetLastError());
         sync();
-        deferred.parts.clear();
-        align_pieces(in, o, qlen.p, tlen.p, dc, parts);
+        for (size_t b = b0; b < b1; ++b) deferred_of[b].parts.clear();
+        align_pieces(in, o, qlen.p, tlen.p, dc, outs);
+    };
+    // the rest in lanes: each lane a host thread with a stream of its own, taking the next batch when it is done with one
+    std::vector<size_t> cut{0};                            // group g = batches [cut[g], cut[g + 1])
+    {
+        const int n_lanes = (int)std::min<size_t>((size_t)(in.max_lanes > 0 ? std::min(in.max_lanes, lane_count()) : lane_count()), nb - done);
+        if (n_lanes > 1) {
+            std::vector<size_t> pcts{40, 70, 90};
+            if (const char *e = hook("HLMI_SET_ASIDE_CUTS")) {               // tuning hook: "50,85"; "" = no groups
+                pcts.clear();
+                size_t v = 0;
+                bool have = false;
+                for (const char *c = e; *c && pcts.size() < 16; ++c) {       // digits and commas; anything else ends the list
+                    if (*c >= '0' && *c <= '9') { v = std::min<size_t>(v * 10 + (size_t)(*c - '0'), 100); have = true; }
+                    else { if (have) pcts.push_back(v); v = 0; have = false; if (*c != ',') break; }
+                }
+                if (have && pcts.size() < 16) pcts.push_back(v);
+            }
+            for (const size_t pct : pcts) {
+                const size_t c = done + (nb - done) * std::min<size_t>(pct, 100) / 100;
+                if (c > done && c > cut.back() && c < nb) cut.push_back(c);      // (every group has a batch the lanes still run)
+            }
+        }
+        cut.push_back(nb);
+        const size_t n_groups = cut.size() - 1;
+        parts_late.resize(n_groups);
+        std::vector<std::atomic<size_t>> left(n_groups);
+        for (size_t g = 0; g < n_groups; ++g) left[g].store(cut[g + 1] - std::max(cut[g], done));
+        std::atomic<size_t> next(done);
+        std::atomic<bool> stop(false);
+        std::exception_ptr errors[MAX_LANES];
+        auto work = [&](int lane_id) {
+            try {
+                std::unique_ptr<LaneScope> scope;
+                if (lane_id) scope.reset(new LaneScope(lane_id));
+                for (;;) {
+                    const size_t b = next.fetch_add(1);
+                    if (b >= nb || stop.load()) break;
+                    run_batch(b);
+                    sync();                                  // (another lane may read what this batch set aside)
+                    const size_t g = (size_t)(std::upper_bound(cut.begin(), cut.end(), b) - cut.begin()) - 1;
+                    if (left[g].fetch_sub(1) == 1 && g + 1 < n_groups) align_set_aside(cut[g], cut[g + 1], parts_late[g]);
+                }
+                if (lane_id) sync();
+            } catch (...) {
+                errors[lane_id] = std::current_exception();
+                stop.store(true);
+            }
+        };
+        std::vector<std::thread> workers;
+        for (int l = 1; l < n_lanes; ++l) workers.emplace_back(work, l);
+        work(0);
+        for (auto &w : workers) w.join();
+        for (int l = 0; l < MAX_LANES; ++l) if (errors[l]) std::rethrow_exception(errors[l]);
+        if (n_lanes > 1) stat_set("ava_lanes", (double)n_lanes);
     }
+    const double w_tail = wall();
+    stat_add("wall_s.ava_batches", w_tail - w_batches);
+    align_set_aside(cut[cut.size() - 2], nb, parts_late.back());      // the last group's (without lanes: everything)
+    stat_add("wall_s.ava_set_aside_tail", wall() - w_tail);
+    for (size_t b = 0; b < nb; ++b) {
+        for (auto &p : parts_of[b]) parts.push_back(std::move(p));
+        st.anchors += st_of[b].anchors; st.groups += st_of[b].groups;
+    }
+    for (auto &late : parts_late) for (auto &p : late) parts.push_back(std::move(p));
+    parts_of.clear(); deferred_of.clear(); parts_late.clear();
     stat_add("index_entries", (double)ix.n);
     stat_add("anchors", (double)st.anchors);
     stat_add("chain_groups", (double)st.groups);
 
     // ---- concatenate + stream order ---------------------------------------------------------------------
+    const double w_concat = wall();
     HostTimer ht_concat("concat_order");
     HostTimer *ht_part = new HostTimer("concat_alloc");
     size_t R = 0, E = 0;
@@ -286,16 +415,18 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     hipLaunchKernelGGL(gather_rows_kernel, grid1(R), dim3(WG), 0, stream(), recs.p, perm.p, out.recs.p, R);
     HIP_CHECK(hipGetLastError());
     delete ht_part; ht_part = new HostTimer("concat_download");
-    std::vector<uint64_t> h_hi = hi_g.download(R);
+    // rows of chunk c: [first row whose key's chunk field is >= c, ...) - found on the device (the keys themselves, 8 bytes per
+    // row, took 21 ms of a C3 step to bring over)
+    DBuf<uint64_t> d_start(in.n_chunks + 1);
+    hipLaunchKernelGGL(chunk_row_start_kernel, grid1(in.n_chunks + 1), dim3(WG), 0, stream(), hi_g.p, R, in.n_chunks, d_start.p);
+    HIP_CHECK(hipGetLastError());
+    const std::vector<uint64_t> h_start = d_start.download(in.n_chunks + 1);
     delete ht_part;
     out.n_rows = R;
     out.n_ops = E;
-    size_t i = 0;
-    for (uint32_t c = 0; c < in.n_chunks; ++c) {
-        out.chunk_row_start[c] = i;
-        while (i < R && (uint32_t)(h_hi[i] >> 32) == c) ++i;
-    }
+    for (uint32_t c = 0; c < in.n_chunks; ++c) out.chunk_row_start[c] = (size_t)h_start[c];
     out.chunk_row_start[in.n_chunks] = R;
+    stat_add("wall_s.ava_concat", wall() - w_concat);
 }
 
 void format_ava_row(const PafRec &r, const uint32_t *ops, const std::string &qname, const std::string &tname,

@@ -3182,7 +3182,7 @@ void align_pieces(const AvaInput &in, const hlmi_ava_opts &o, const uint32_t *d_
             if (defer->n_fp + n_fp_long >= (1ull << 32)) fail(HLMI_EINVAL, "more than 2^32 fixed points in the set-aside alignment pieces");
             hipLaunchKernelGGL(move_fixed_points_kernel, dim3((unsigned)std::min<size_t>(cdiv(n_long, (size_t)WAVES), 256 * 32)), dim3(WG), 0, stream(),
                                part.pieces.p, n_long, off.p, (uint32_t)defer->n_fp, ch_in.fps.p, part.fps.p);
-            part.n_pieces = n_long; part.n_fp = n_fp_long;
+            part.n_pieces = n_long; part.n_fp = n_fp_long; part.fp_base = defer->n_fp;
             defer->n_pieces += n_long; defer->n_fp += n_fp_long;
             defer->parts.push_back(std::move(part));
             // the others, in their order (the fixed points stay where they are)

@@ -81,7 +81,9 @@ struct AlignOut {
 // aside batch after batch: they are aligned together at the end of the run (ava_align.hip: piece_long_flag_kernel).  The
 // fp_off of a set-aside piece counts from the start of the concatenated fixed points of all parts.
 struct DeferredPieces {
-    struct Part { size_t n_pieces = 0, n_fp = 0; DBuf<Piece> pieces; DBuf<FixPt> fps; };
+    // fp_base: where the part's pieces expect their fixed points (Piece::fp_off counts from the start of the set the part was
+    // added to: a batch's own set; ava_device moves the offsets when it puts the batches' sets together)
+    struct Part { size_t n_pieces = 0, n_fp = 0, fp_base = 0; DBuf<Piece> pieces; DBuf<FixPt> fps; };
     std::vector<Part> parts;
     size_t n_pieces = 0, n_fp = 0;
 };

@@ -44,7 +44,7 @@ struct Error : std::runtime_error {
 
 void set_last_error(const std::string &m);
 void require_device();           // throws HLMI_ENODEV when no usable GPU
-hipStream_t stream();            // the library's compute stream
+hipStream_t stream();            // the compute stream of the calling thread's lane (see LaneScope)
 int host_threads();
 
 // stats of the last stage (exported through hlmi_last_stats_json)
@@ -60,8 +60,8 @@ std::map<std::string, double> &stats();
 // ------------------------------------------------------------------------------------------
 // device memory: size-binned pool in front of hipMalloc / hipFree.  The stage works in query batches
 // whose multi-GB scratch buffers have the same sizes batch after batch; hipMalloc + hipFree of those
-// cost more than the kernels between them.  Everything runs on one stream, so a block can be handed
-// out again as soon as its owner releases it.
+// cost more than the kernels between them.  A lane's work runs on one stream, so a block can be handed
+// out again TO THAT LANE as soon as its owner releases it (the cache is kept per lane: runtime.cpp).
 // ------------------------------------------------------------------------------------------
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
@@ -109,6 +109,19 @@ struct DBuf {
 hipStream_t side_stream();       // second stream (runtime.cpp): LONG alignment tasks beside the batch's other DP kernels
 hipStream_t side_stream_if_created();      // the same without creating it (nullptr: never used) - for destructors
 inline void sync() { HIP_CHECK(hipStreamSynchronize(stream())); }
+
+// Lanes: the query batches of a pass are independent of each other, and a batch alternates between kernels that wait on HBM
+// (anchor fill, radix sort) and kernels that wait on the vector units and on dependent loads (chaining, the DP kernels) with
+// dozens of host round trips in between.  Two batches in flight - each driven by its own host thread on its own stream - fill
+// each other's gaps.  stream(), side_stream(), sync(), the kernel timers, pinned_scratch() and the allocator's cache all refer to
+// the lane of the calling thread: lane 0 unless the thread is inside a LaneScope.
+constexpr int MAX_LANES = 4;
+int lane_count();                // batches in flight (HLMI_LANES, default 2; 1: none beside the caller's)
+struct LaneScope {               // the calling thread works on lane `id` while this lives; the lane's stream is drained and its
+    explicit LaneScope(int id);  // kernel timers are folded into the stats at the end
+    ~LaneScope();
+    int prev;
+};
 
 // Scoped HIP-event timer on the library stream: per-kernel device time for bench.py's roofline line
 // (torch.cuda.Event would only see torch's stream).  Durations are summed per name by ktimer_flush()

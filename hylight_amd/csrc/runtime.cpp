@@ -10,12 +10,26 @@ namespace hlmi {
 
 namespace {
 thread_local std::string g_last_error;
-hipStream_t g_stream = nullptr;
-hipStream_t g_side = nullptr;
 bool g_ready = false;
+int g_device = 0;                        // the device the library runs on (worker lanes bind their threads to it)
 int g_threads = 0;                       // 0: not chosen yet (host_threads)
 std::map<std::string, double> g_stats;
-std::mutex g_mu;
+std::mutex g_mu;                         // init / shutdown
+std::mutex g_stat_mu;                    // g_stats (the lanes add to it)
+
+// A lane: one host thread's view of the device - its compute stream, its side stream, its pending kernel timers, its pinned
+// read-back slot, its share of the allocator's cache.  Lane 0 is the calling thread's (everything outside the query-batch loop
+// of ava_device runs there); lanes 1.. belong to the worker threads that loop starts (LaneScope).  A thread that never entered
+// a LaneScope is on lane 0.
+struct KRec { std::string name; hipEvent_t a, b; hipStream_t s; };
+struct Lane {
+    hipStream_t stream = nullptr, side = nullptr;
+    std::vector<KRec> krecs;
+    void *pinned = nullptr;
+};
+Lane g_lanes[MAX_LANES];
+thread_local int t_lane = 0;
+inline Lane &lane() { return g_lanes[t_lane]; }
 }  // namespace
 
 void set_last_error(const std::string &m) { g_last_error = m; }
@@ -34,7 +48,7 @@ int host_threads() {
 }
 
 void *pinned_scratch() {
-    static void *p = nullptr;
+    void *&p = lane().pinned;
     if (!p) HIP_CHECK(hipHostMalloc(&p, PINNED_SCRATCH_BYTES, hipHostMallocDefault));
     return p;
 }
@@ -48,7 +62,8 @@ void init_device(int device, int threads) {
              e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     if (device >= n) fail(HLMI_EINVAL, "device %d out of range (have %d)", device, n);
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
-    if (!g_stream) HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipGetDevice(&g_device));
+    if (!g_lanes[0].stream) HIP_CHECK(hipStreamCreateWithFlags(&g_lanes[0].stream, hipStreamNonBlocking));
     if (threads > 0) g_threads = threads;
     g_ready = true;
 }
@@ -56,16 +71,14 @@ void init_device(int device, int threads) {
 void shutdown_device() {
     std::lock_guard<std::mutex> lk(g_mu);
     dev_pool_trim();
-    if (g_side) {
-        (void)hipStreamSynchronize(g_side);
-        (void)hipStreamDestroy(g_side);
+    for (Lane &l : g_lanes) {
+        for (hipStream_t *st : {&l.side, &l.stream}) {
+            if (!*st) continue;
+            (void)hipStreamSynchronize(*st);
+            (void)hipStreamDestroy(*st);
+            *st = nullptr;
+        }
     }
-    g_side = nullptr;
-    if (g_stream) {
-        (void)hipStreamSynchronize(g_stream);
-        (void)hipStreamDestroy(g_stream);
-    }
-    g_stream = nullptr;
     g_ready = false;
 }
 
@@ -73,11 +86,12 @@ void require_device() {
     if (!g_ready) init_device(-1, 0);
 }
 
-hipStream_t stream() { return g_stream; }
+hipStream_t stream() { return lane().stream; }
 // second stream: the few LONG alignment tasks of a batch (serial rows, a tail of minutes of wave time on a handful of CUs) run
 // here beside the batch's other DP kernels; the caller joins it with an event before anything reads their results
-hipStream_t side_stream_if_created() { return g_side; }
+hipStream_t side_stream_if_created() { return lane().side; }
 hipStream_t side_stream() {
+    hipStream_t &g_side = lane().side;
     if (!g_side) {
         // highest priority: its few waves are the tail of the batch - they should never wait for an issue slot behind the
         // thousands of waves of the kernels they run beside
@@ -88,28 +102,31 @@ hipStream_t side_stream() {
     return g_side;
 }
 
-namespace {
-struct KRec { std::string name; hipEvent_t a, b; hipStream_t s; };
-std::vector<KRec> g_krecs;
-}  // namespace
+// (the timers of a lane are its own: started, ended and read by its thread)
+static void lane_drain() {
+    Lane &l = lane();
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+    if (l.side) (void)hipStreamSynchronize(l.side);
+}
 
 KTimer::KTimer(const char *name, hipStream_t on) {
     KRec r;
     r.name = name;
-    r.s = on ? on : g_stream;
+    r.s = on ? on : lane().stream;
     HIP_CHECK(hipEventCreate(&r.a));
     HIP_CHECK(hipEventCreate(&r.b));
     HIP_CHECK(hipEventRecord(r.a, r.s));
-    slot = g_krecs.size();
-    g_krecs.push_back(r);
+    slot = lane().krecs.size();
+    lane().krecs.push_back(r);
 }
-KTimer::~KTimer() { (void)hipEventRecord(g_krecs[slot].b, g_krecs[slot].s); }
+KTimer::~KTimer() { (void)hipEventRecord(lane().krecs[slot].b, lane().krecs[slot].s); }
 
 void ktimer_flush() {
-    if (g_krecs.empty()) return;
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
-    if (g_side) (void)hipStreamSynchronize(g_side);
-    for (auto &r : g_krecs) {
+    auto &krecs = lane().krecs;
+    if (krecs.empty()) return;
+    lane_drain();
+    std::lock_guard<std::mutex> lk(g_stat_mu);
+    for (auto &r : krecs) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             g_stats["kernel_ms." + r.name] += ms;
@@ -118,24 +135,43 @@ void ktimer_flush() {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
-    g_krecs.clear();
+    krecs.clear();
 }
 
-size_t ktimer_mark() { return g_krecs.size(); }
+size_t ktimer_mark() { return lane().krecs.size(); }
 void ktimer_rollback(size_t mark) {            // forget the timers started after `mark` (a run that was given up)
-    if (mark >= g_krecs.size()) return;
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
-    if (g_side) (void)hipStreamSynchronize(g_side);
-    for (size_t i = mark; i < g_krecs.size(); ++i) { (void)hipEventDestroy(g_krecs[i].a); (void)hipEventDestroy(g_krecs[i].b); }
-    g_krecs.resize(mark);
+    auto &krecs = lane().krecs;
+    if (mark >= krecs.size()) return;
+    lane_drain();
+    for (size_t i = mark; i < krecs.size(); ++i) { (void)hipEventDestroy(krecs[i].a); (void)hipEventDestroy(krecs[i].b); }
+    krecs.resize(mark);
 }
 
 void ktimer_discard() {
-    if (g_krecs.empty()) return;
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
-    if (g_side) (void)hipStreamSynchronize(g_side);
-    for (auto &r : g_krecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    g_krecs.clear();
+    auto &krecs = lane().krecs;
+    if (krecs.empty()) return;
+    lane_drain();
+    for (auto &r : krecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    krecs.clear();
+}
+
+// ---- worker lanes ------------------------------------------------------------------------------------
+// Query batches in flight at the same time: HLMI_LANES (default 2, 1 = one batch after the other as before round 5).
+int lane_count() {
+    int n = 2;
+    if (const char *e = hook("HLMI_LANES")) n = atoi(e);
+    return std::max(1, std::min(n, MAX_LANES));
+}
+LaneScope::LaneScope(int id) : prev(t_lane) {
+    if (id < 0 || id >= MAX_LANES) fail(HLMI_EINVAL, "lane %d out of range", id);
+    t_lane = id;
+    HIP_CHECK(hipSetDevice(g_device));          // a new thread starts on device 0
+    if (!lane().stream) HIP_CHECK(hipStreamCreateWithFlags(&lane().stream, hipStreamNonBlocking));
+}
+LaneScope::~LaneScope() {
+    lane_drain();
+    try { ktimer_flush(); } catch (...) {}
+    t_lane = prev;
 }
 
 // ---- test hooks and tuning switches ------------------------------------------
@@ -152,7 +188,7 @@ const char *const HOOK_NAMES[] = {
     "HLMI_CHAIN_DP16_CHECK",
     "HLMI_CHAIN_NO_DP16",
     "HLMI_CHAIN_NO_SMALL",
-    "HLMI_SEED_GROUP", "HLMI_TEXT_GPU", "HLMI_TEXT_HOST", "HLMI_GRAPH_WINDOW_MB",
+    "HLMI_SEED_GROUP", "HLMI_TEXT_GPU", "HLMI_TEXT_HOST", "HLMI_GRAPH_WINDOW_MB", "HLMI_LANES", "HLMI_SET_ASIDE_CUTS",
     "HLMI_CHAIN_PROF",
     "HLMI_CHAIN_UNPACKED",
     "HLMI_GROUP_HIST",
@@ -192,7 +228,14 @@ const char *hook(const char *name) {
 
 // ---- pooled device allocator -----------------------------------------------------------------------
 namespace {
-std::multimap<size_t, void *> g_free_blocks;            // size -> block
+// A released block may still be in use by kernels queued on the releasing lane's stream: fine for the next owner on the SAME
+// stream, wrong for one on another.  Every cached block remembers the lane that released it; a lane takes its own blocks first,
+// and when it takes another lane's, its stream first waits for everything queued on that lane's stream so far (an event recorded
+// at the hand-over: whatever used the block was queued before its release).  The paths that give blocks back to the driver
+// drain the whole device first.
+struct CachedBlock { void *p; int lane; };
+std::multimap<size_t, CachedBlock> g_free_blocks;        // size -> block
+std::mutex g_pool_mu;
 std::unordered_map<void *, size_t> g_block_size;         // every live or cached block
 size_t g_pooled_bytes = 0;
 size_t g_owned_bytes = 0;                                // every block in g_block_size (in use or cached)
@@ -216,11 +259,37 @@ static size_t size_class(size_t bytes) {
     return want;
 }
 
+static void pool_trim_locked() {
+    (void)hipDeviceSynchronize();
+    for (auto &kv : g_free_blocks) {
+        (void)hipFree(kv.second.p);
+        g_owned_bytes -= kv.first;
+        g_block_size.erase(kv.second.p);
+    }
+    g_free_blocks.clear();
+    g_pooled_bytes = 0;
+}
+
 void *dev_alloc(size_t bytes) {
     const size_t want = size_class(bytes);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_free_blocks.lower_bound(want);
+    {   // a block of this lane among the ones that fit, else the smallest that fits
+        int looked = 0;
+        for (auto own = it; own != g_free_blocks.end() && own->first <= want + want / 2 && looked < 16; ++own, ++looked)
+            if (own->second.lane == t_lane) { it = own; break; }
+    }
     if (it != g_free_blocks.end() && it->first <= want + want / 2) {
-        void *p = it->second;
+        void *p = it->second.p;
+        const int from = it->second.lane;
+        if (from != t_lane && g_lanes[from].stream && lane().stream) {
+            hipEvent_t ev;
+            HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ev, g_lanes[from].stream));
+            HIP_CHECK(hipStreamWaitEvent(lane().stream, ev, 0));
+            if (lane().side) HIP_CHECK(hipStreamWaitEvent(lane().side, ev, 0));
+            HIP_CHECK(hipEventDestroy(ev));
+        }
         g_pooled_bytes -= it->first;
         g_free_blocks.erase(it);
         g_peak_in_use = std::max(g_peak_in_use, g_owned_bytes - g_pooled_bytes);
@@ -233,10 +302,10 @@ void *dev_alloc(size_t bytes) {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             bool drained = false;
             while (free_b < want + (1ull << 30) && !g_free_blocks.empty()) {
-                if (!drained) { if (g_stream) (void)hipStreamSynchronize(g_stream); drained = true; }   // queued kernels may still use a cached block
+                if (!drained) { (void)hipDeviceSynchronize(); drained = true; }   // queued kernels may still use a cached block
                 auto big = std::prev(g_free_blocks.end());
-                (void)hipFree(big->second);
-                g_block_size.erase(big->second);
+                (void)hipFree(big->second.p);
+                g_block_size.erase(big->second.p);
                 g_pooled_bytes -= big->first;
                 g_owned_bytes -= big->first;
                 free_b += big->first;
@@ -248,7 +317,7 @@ void *dev_alloc(size_t bytes) {
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {                                // out of memory: drop the cache and retry once
         (void)hipGetLastError();                          // (the failed call stays "the last error" until it is read: a later
-        dev_pool_trim();                                  //  HIP_CHECK(hipGetLastError()) after a kernel launch would report it)
+        pool_trim_locked();                               //  HIP_CHECK(hipGetLastError()) after a kernel launch would report it)
         e = hipMalloc(&p, want);
         if (e != hipSuccess) (void)hipGetLastError();
     }
@@ -261,6 +330,7 @@ void *dev_alloc(size_t bytes) {
 
 // high-water mark of the device memory in use through dev_alloc since the last reset (the stage reports it per run)
 size_t dev_peak_bytes(bool reset) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     const size_t v = g_peak_in_use;
     if (reset) g_peak_in_use = g_owned_bytes - g_pooled_bytes;
     return v;
@@ -269,10 +339,12 @@ size_t dev_peak_bytes(bool reset) {
 size_t dev_available_bytes() {           // free on the card + cached here: what a run can still take
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     return free_b + g_pooled_bytes;
 }
 
 void dev_free(void *p) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_block_size.find(p);
     if (it == g_block_size.end()) { (void)hipFree(p); return; }
     if (g_pooled_bytes + it->second > POOL_CAP) {
@@ -281,19 +353,13 @@ void dev_free(void *p) {
         g_block_size.erase(it);
         return;
     }
-    g_free_blocks.emplace(it->second, p);
+    g_free_blocks.emplace(it->second, CachedBlock{p, t_lane});
     g_pooled_bytes += it->second;
 }
 
 void dev_pool_trim() {
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
-    for (auto &kv : g_free_blocks) {
-        (void)hipFree(kv.second);
-        g_owned_bytes -= kv.first;
-        g_block_size.erase(kv.second);
-    }
-    g_free_blocks.clear();
-    g_pooled_bytes = 0;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    pool_trim_locked();
 }
 
 static double wall_s() {
@@ -309,18 +375,18 @@ static bool host_timers_on() {
 }
 HostTimer::HostTimer(const char *n) : name(n), t0(0) {
     if (!host_timers_on()) return;
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (lane().stream) (void)hipStreamSynchronize(lane().stream);
     t0 = wall_s();
 }
 HostTimer::~HostTimer() {
     if (!host_timers_on()) return;
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
-    g_stats[std::string("host_s.") + name] += wall_s() - t0;
+    if (lane().stream) (void)hipStreamSynchronize(lane().stream);
+    stat_add(std::string("host_s.") + name, wall_s() - t0);
 }
 
-void stat_reset() { g_stats.clear(); }
-void stat_set(const std::string &k, double v) { g_stats[k] = v; }
-void stat_add(const std::string &k, double v) { g_stats[k] += v; }
+void stat_reset() { std::lock_guard<std::mutex> lk(g_stat_mu); g_stats.clear(); }
+void stat_set(const std::string &k, double v) { std::lock_guard<std::mutex> lk(g_stat_mu); g_stats[k] = v; }
+void stat_add(const std::string &k, double v) { std::lock_guard<std::mutex> lk(g_stat_mu); g_stats[k] += v; }
 std::map<std::string, double> &stats() { return g_stats; }
 
 }  // namespace hlmi

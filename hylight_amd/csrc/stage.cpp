@@ -196,11 +196,16 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
     // query sketch and the seed plan of a million long reads resident (84 GB on the full C4) the usual 64 GB do not fit
     // and the pool thrashes - the budget follows what is free when the pass starts
     double SUBRUN_OUT_BYTES = 52e9;
+    bool lanes_fit = false;
     if (const size_t avail = dev_available_bytes()) {
         const double plan = 12.0 * (m.qmz_off.empty() ? 0.0 : (double)m.qmz_off.back());        // count + run of every query minimizer
         // (round 4: whole-overlap CIGARs of divergent reads - a complete C5 pass peaked at 275 of the 288 GB with 64e9 and a
         //  divisor of 1.3 x 1.5)
         SUBRUN_OUT_BYTES = std::min(52e9, std::max(8e9, ((double)avail - plan - 60e9) / (1.5 * 1.5)));
+        // a second query batch in flight (lanes, runtime.cpp) brings its own ~45 GB of batch buffers: only where that leaves the
+        // budget above untouched with room to spare (C2, C3, the short-read calls; not the full C4 and C5, whose resident
+        // sketches and plans take 50-100 GB)
+        lanes_fit = (double)avail - plan >= 260e9;
     }
     stat_set("subrun_out_budget_gb", SUBRUN_OUT_BYTES / 1e9);
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;
@@ -269,6 +274,7 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         if (m.dT == &m.dQ) in.t_query = sub_tids;     // reads vs themselves: the targets' minimizers are in the query sketch
         in.max_anchors = (uint64_t)subrun_anchors_max;
         in.max_out_bytes = (uint64_t)subrun_out_max;
+        in.max_lanes = lanes_fit ? 0 : 1;
         AvaRows rows;
         const double a0 = stats()["anchors"];
         // a run that is given up (it may already have aligned its first query batch) leaves no trace in the pass's
