@@ -311,7 +311,7 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
     {
         const int n_lanes = (int)std::min<size_t>((size_t)(in.max_lanes > 0 ? std::min(in.max_lanes, lane_count()) : lane_count()), nb - done);
         if (n_lanes > 1) {
-            std::vector<size_t> pcts{40, 70, 90};
+            std::vector<size_t> pcts{60};
             if (const char *e = hook("HLMI_SET_ASIDE_CUTS")) {               // tuning hook: "50,85"; "" = no groups
                 pcts.clear();
                 size_t v = 0;

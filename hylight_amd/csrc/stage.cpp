@@ -202,10 +202,12 @@ void Job::run(int rank, int world, int len_over, int mc, double iden, const char
         // (round 4: whole-overlap CIGARs of divergent reads - a complete C5 pass peaked at 275 of the 288 GB with 64e9 and a
         //  divisor of 1.3 x 1.5)
         SUBRUN_OUT_BYTES = std::min(52e9, std::max(8e9, ((double)avail - plan - 60e9) / (1.5 * 1.5)));
-        // a second query batch in flight (lanes, runtime.cpp) brings its own ~45 GB of batch buffers: only where that leaves the
-        // budget above untouched with room to spare (C2, C3, the short-read calls; not the full C4 and C5, whose resident
-        // sketches and plans take 50-100 GB)
-        lanes_fit = (double)avail - plan >= 260e9;
+        // a second query batch in flight (lanes, runtime.cpp) brings its own batch buffers - ~45 GB, and as much again in LONG
+        // scratch on divergent reads: the full C5 (265e9 left here of the card's 309e9 bytes) peaked at 298e9 with two lanes
+        // against ~240e9 with one.  Lanes only where nearly the whole card is free: C2, C3, the short-read calls; not the full
+        // C4 and C5, whose resident sketches and plans take 40-100 GB.
+        lanes_fit = (double)avail - plan >= 285e9;
+        stat_set("lanes_fit", lanes_fit ? 1 : 0);
     }
     stat_set("subrun_out_budget_gb", SUBRUN_OUT_BYTES / 1e9);
     constexpr uint64_t SUBRUN_MAX_TARGETS = 1u << 20, SUBRUN_MAX_BASES = 3ull << 30;

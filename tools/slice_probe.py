@@ -32,5 +32,5 @@ for k in range(reps):
     print(f"rep {k}: {dt * 1e3:.1f} ms, {n} rows, t_ava {st['t_ava_s']*1e3:.1f} t_filter {st['t_filter_s']*1e3:.1f}", flush=True)
 kms = {k.split(".", 1)[1]: round(v, 2) for k, v in st.items() if k.startswith("kernel_ms.")}
 print(json.dumps(dict(sorted(kms.items(), key=lambda kv: -kv[1]))))
-print(json.dumps({k: v for k, v in st.items() if k.startswith("host_s.") or k.startswith("wall_s.") or k.startswith("chain_") or k in ("anchors", "align_tasks", "align_tasks_dp", "pieces")}))
+print(json.dumps({k: v for k, v in st.items() if k.startswith("host_s.") or k.startswith("wall_s.") or k.startswith("chain_") or k in ("anchors", "align_tasks", "align_tasks_dp", "pieces", "ava_lanes", "lanes_fit", "hbm_peak_in_use_gb")}))
 r.close()
