@@ -66,3 +66,19 @@ def test_c3_fallback_forms_agree_on_a_slice(c3, monkeypatch, var):
     alt = str(d / f"alt_{var}.paf")
     r.run(alt, share=(3, 8), **cfg["stage"])
     assert same_file(alt, str(d / "slice3.paf"))
+
+
+@pytest.mark.parametrize("lanes,cuts", [("1", None), ("3", None), ("4", "25,50,75"), ("2", ""), ("2", "40,70,90")])
+def test_c3_lanes_agree_on_a_slice(c3, monkeypatch, lanes, cuts):
+    """Query batches in flight (runtime.cpp: lanes): one after the other, two (the default the slices above ran with), three or
+    four at a time, the set-aside pieces (LONG tasks) aligned at different points of the pass - the same bytes."""
+    d, cfg, r, out, rows, st = c3
+    monkeypatch.setenv("HLMI_LANES", lanes)
+    if cuts is not None:
+        monkeypatch.setenv("HLMI_SET_ASIDE_CUTS", cuts)
+    alt = str(d / f"alt_lanes_{lanes}_{cuts}.paf")
+    r.run(alt, share=(3, 8), **cfg["stage"])
+    s2 = api.last_stats()
+    assert (s2.get("ava_lanes", 1) == int(lanes)) and s2["lanes_fit"] == 1
+    assert s2["align_pieces_deferred"] > 0            # (there are set-aside pieces to move around)
+    assert same_file(alt, str(d / "slice3.paf"))

@@ -55,3 +55,17 @@ def test_divergent_fallback_forms_agree(div, monkeypatch, var):
     alt = d / f"alt_{var}.paf"
     api.split_reads2(fa, fa, 30, d, alt, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
     assert open(alt).read() == open(out).read()
+
+
+@pytest.mark.parametrize("lanes", ["1", "2", "4"])
+def test_divergent_lanes_agree_with_small_batches(div, monkeypatch, lanes):
+    """Dozens of small query batches taken by 1, 2 or 4 lanes (host threads with a stream each) in whatever order they get to
+    them; every lane runs its LONG tasks on a side stream of its own."""
+    d, fa, out = div
+    monkeypatch.setenv("HLMI_LANES", lanes)
+    monkeypatch.setenv("HLMI_ANCHOR_BATCH_M", "1")
+    alt = d / f"alt_lanes_{lanes}.paf"
+    api.split_reads2(fa, fa, 30, d, alt, len_over=LEN_OVER, mc=MC, iden=IDEN, long=True)
+    st = api.last_stats()
+    assert 1 <= st.get("ava_lanes", 1) <= int(lanes) and (lanes == "1" or st.get("ava_lanes", 1) > 1)
+    assert open(alt).read() == open(out).read()
