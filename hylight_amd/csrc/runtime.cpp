@@ -188,7 +188,7 @@ const char *const HOOK_NAMES[] = {
     "HLMI_CHAIN_DP16_CHECK",
     "HLMI_CHAIN_NO_DP16",
     "HLMI_CHAIN_NO_SMALL",
-    "HLMI_SEED_GROUP", "HLMI_TEXT_GPU", "HLMI_TEXT_HOST", "HLMI_GRAPH_WINDOW_MB", "HLMI_LANES", "HLMI_SET_ASIDE_CUTS",
+    "HLMI_SEED_GROUP", "HLMI_TEXT_GPU", "HLMI_TEXT_HOST", "HLMI_GRAPH_WINDOW_MB", "HLMI_LANES", "HLMI_SET_ASIDE_CUTS", "HLMI_SEED_NO_GUESS",
     "HLMI_CHAIN_PROF",
     "HLMI_CHAIN_UNPACKED",
     "HLMI_GROUP_HIST",
