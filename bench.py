@@ -440,7 +440,7 @@ def main():
     # the waves of the other lane's kernels.  One more step of the last slice, untimed and with one lane, gives every kernel's
     # duration by itself - the figure earlier rounds reported and a serial rocprofv3 trace shows.
     stats_one_lane = None
-    if stats and stats.get("ava_lanes", 0) > 1 and not os.environ.get("HLMI_LANES"):
+    if stats and stats.get("ava_lanes", 0) > len(runners) and not os.environ.get("HLMI_LANES"):
         os.environ["HLMI_LANES"] = "1"
         try:
             step(args.warmup + args.steps - 1)
@@ -528,7 +528,7 @@ def main():
                 stage=dict(bytes_ava=b_ava, bytes_filter=b_flt, step_s=last_s,
                            achieved=(b_ava + b_flt) / last_s / 1e9, frac=(b_ava + b_flt) / last_s / 1e9 / HBM_PEAK_GBS),
                 kernel_ms_per_step={k: round(v, 3) for k, v in sorted(kms.items(), key=lambda kv: -kv[1])})
-    roof["lanes"] = int(stats.get("ava_lanes", 1))
+    roof["lanes"] = int(stats.get("ava_lanes", len(runners)) / len(runners))       # (the counts of a step are summed over its calls)
     if kms1:
         l1 = max(stats_one_lane.get("kernel_launches." + dom, 1.0), 1.0)
         a1 = (algo.get(dom, 0.0) / l1) / (kms1[dom] / l1 * 1e-3) / 1e9 if kms1.get(dom, 0) > 0 else 0.0
