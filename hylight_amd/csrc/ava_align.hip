@@ -182,6 +182,8 @@ struct AlignArgs {
                             // certificates do not settle are compared along the diagonal (align_ungapped_kernel)
     int kmax;               // fast path: max substitutions for which the diagonal is provably the unique optimum
     int kgap1;              // 1: blocks with |n - m| = 1 and one substitution finish in the classifier (fifth certificate)
+    int kgap2;              // 1: ... and with two substitutions, when no path with a two-base gap one way and a one-base gap the
+                            // other way avoids them all (seventh certificate)
     int one_ok;             // 1: extensions may be certified for the one-piece rows (HLMI_NO_ONE_PIECE_CERT: test hook)
     int kext_plain;         // 1: an extension with ONE substitution and no bonus row finishes in the classifier (sixth certificate)
     int kext_bonus;         // extensions whose end cell lies in the bonus row finish there with up to this many substitutions
@@ -650,8 +652,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
             //     avoiding ONE substitution cannot pay for (checked on the host) - so the optimal alignments are the
             //     placements with s(p) = 1: p in (b2, a1] with the substitution at b1, or p in (b1, a2] with it at a1;
             //     the first range lies left of the second and the traceback takes the leftmost p, as above.
-            const int want = a.kgap1 && gap == 1 ? 2 : 1;
-            int found_a = 0, found_b = 0, a1 = mn, a2 = mn, b1 = -1, b2 = -1;
+            const int want = a.kgap1 && gap == 1 ? (a.kgap2 ? 3 : 2) : 1;
+            int found_a = 0, found_b = 0, a1 = mn, a2 = mn, a3 = mn, b1 = -1, b2 = -1, b3 = -1;
             bool amb = false;
             // both scans in one loop: the start diagonal forwards, the end diagonal backwards, their four loads of a trip in
             // flight together (one after the other the kernel waited 80 % of its time on a chain of dependent trips)
@@ -671,7 +673,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                     while (d && found_a < want) {
                         const int y = (__ffsll((long long)d) - 1) >> 3;
                         d &= d - 1;
-                        if (found_a++ == 0) a1 = x + y; else a2 = x + y;
+                        if (found_a == 0) a1 = x + y; else if (found_a == 1) a2 = x + y; else a3 = x + y;
+                        ++found_a;
                     }
                 }
                 if (db) {
@@ -682,29 +685,76 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 
                     while (d && found_b < want) {
                         const int z = 7 - (__clzll((long long)d) >> 3);      // highest set byte
                         d &= ~(0xffull << (8 * z));
-                        if (found_b++ == 0) b1 = e0 + z; else b2 = e0 + z;
+                        if (found_b == 0) b1 = e0 + z; else if (found_b == 1) b2 = e0 + z; else b3 = e0 + z;
+                        ++found_b;
                     }
                 }
             }
-            int p_star = -1, xpos = -1;
+            int p_star = -1, xpos = -1, xpos2 = -1;
             if (!amb) {
                 if (b1 < a1) p_star = b1 + 1;                                             // s* = 0
-                else if (want == 2 && b2 < a1) { p_star = b2 + 1; xpos = b1; }            // s* = 1, substitution in the suffix
-                else if (want == 2 && b1 < a2) { p_star = b1 + 1; xpos = a1; }   // ... in the prefix
+                else if (want >= 2 && b2 < a1) { p_star = b2 + 1; xpos = b1; }            // s* = 1, substitution in the suffix
+                else if (want >= 2 && b1 < a2) { p_star = b1 + 1; xpos = a1; }   // ... in the prefix
+            }
+            // Seventh certificate, |n - m| = 1 and s* = 2 (a1 < b1 here: with b1 <= a1 a placement had s <= 1).  U = match +
+            // mismatch, c(L) = cost of a gap of L bases.  Against "prefix, one gap base, suffix" with two substitutions - score
+            // match mn - 2 U - c(1) - a path with k further inserted and k further deleted bases has k diagonal moves fewer and
+            // more gap cost: with k = 1 and the two deleted (inserted) bases in ONE gap it pays match + c(2) and scores HIGHER
+            // if it meets no mismatch at all (2 U > match + c(2) with the usual constants), every other arrangement - a
+            // mismatch on the way, three separate gaps, k >= 2 - stays below (the host checks U < match + c(2),
+            // 2 U < match + 2 c(1), 2 U < 2 match + c(2) + c(3) - c(1)).  A path without a mismatch follows the start diagonal up
+            // to row a1 at the latest and the end diagonal from row b1 + 1 at the earliest; in between it runs on the diagonal
+            // two to the far side of the end diagonal (long gap first: rows [a1, b1) at least) or on the one before the start
+            // diagonal (short gap first: rows [a1 + 1, b1] at least).  A mismatch of the block with itself shifted that way in
+            // each of the two ranges rules both out: the optimal alignments are then the placements with s(p) = 2 - p in
+            // (b3, min(a1, b2)] with the substitutions at b2, b1, or in (max(a1, b2), min(a2, b1)] with a1, b1, or in
+            // (max(a2, b1), a3] with a1, a2; the ranges lie left to right in this order and the traceback takes the leftmost p.
+            if (p_star < 0 && !amb && want == 3) {
+                int ps = -1, x1 = -1, x2 = -1;
+                const int mab = a1 < b2 ? a1 : b2, Mab = a1 > b2 ? a1 : b2, m2 = a2 < b1 ? a2 : b1, M2 = a2 > b1 ? a2 : b1;
+                if (b2 >= 0 && b3 < mab) { ps = b3 + 1; x1 = b2; x2 = b1; }
+                else if (a1 < mn && b1 >= 0 && Mab < m2) { ps = Mab + 1; x1 = a1; x2 = b1; }
+                else if (a2 < mn && M2 < a3) { ps = M2 + 1; x1 = a1; x2 = a2; }
+                if (ps >= 0 && a1 < b1) {
+                    // S = the shorter sequence (rows of the argument above), L = the longer one
+                    auto load_s = [&](int x) { return del ? load_window8p(a.qcodes, (long long)tk.qa, rev, rev, x) : load_window8p(a.tcodes, (long long)tk.ta, false, false, x); };
+                    auto load_l = [&](int x) { return del ? load_window8p(a.tcodes, (long long)tk.ta, false, false, x) : load_window8p(a.qcodes, (long long)tk.qa, rev, rev, x); };
+                    bool far_ne = false, near_ne = false, ambx = false;
+                    for (int x = a1; x < b1 && !far_ne; x += 8) {                 // S[i] vs L[i + 2], i in [a1, b1)
+                        const uint64_t s8 = load_s(x), l8 = load_l(x + 2);
+                        const int left = b1 - x;
+                        const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
+                        ambx |= ((s8 | l8) & keep & 0x0404040404040404ull) != 0;
+                        far_ne = ((s8 ^ l8) & keep) != 0;
+                    }
+                    for (int x = a1 + 1; x <= b1 && !near_ne; x += 8) {           // S[i] vs L[i - 1], i in [a1 + 1, b1]
+                        const uint64_t s8 = load_s(x), l8 = load_l(x - 1);
+                        const int left = b1 + 1 - x;
+                        const uint64_t keep = left >= 8 ? ~0ull : (1ull << (8 * left)) - 1ull;
+                        ambx |= ((s8 | l8) & keep & 0x0404040404040404ull) != 0;
+                        near_ne = ((s8 ^ l8) & keep) != 0;
+                    }
+                    if (far_ne && near_ne && !ambx) { p_star = ps; xpos = x1; xpos2 = x2; }
+                }
             }
             if (p_star < 0 && !amb && b1 >= 0) last_x = b1;     // (suffix trim below; positions count along the shorter sequence)
             if (p_star >= 0) {
-                auto seg = [&](int from, int to) {            // [from, to) of one diagonal, with the substitution if it lies inside
-                    if (xpos >= from && xpos < to) {
-                        if (xpos > from) runs[nr++] = (uint32_t)(xpos - from) << 4 | OP_EQ;
-                        runs[nr++] = 1u << 4 | OP_X;
-                        if (to > xpos + 1) runs[nr++] = (uint32_t)(to - xpos - 1) << 4 | OP_EQ;
-                    } else if (to > from) runs[nr++] = (uint32_t)(to - from) << 4 | OP_EQ;
+                auto seg = [&](int from, int to) {            // [from, to) of one diagonal, with the substitutions that lie inside
+                    int prev = from;                          // (xpos < xpos2 when both are set; neighbours share a run)
+                    for (int k = 0; k < 2; ++k) {
+                        const int xp = k ? xpos2 : xpos;
+                        if (xp < from || xp >= to) continue;
+                        if (xp > prev) runs[nr++] = (uint32_t)(xp - prev) << 4 | OP_EQ;
+                        if (nr && xp == prev && prev > from && (runs[nr - 1] & 15u) == OP_X) runs[nr - 1] += 1u << 4;
+                        else runs[nr++] = 1u << 4 | OP_X;
+                        prev = xp + 1;
+                    }
+                    if (to > prev) runs[nr++] = (uint32_t)(to - prev) << 4 | OP_EQ;
                 };
                 seg(0, p_star);
                 runs[nr++] = (uint32_t)gap << 4 | (del ? OP_D : OP_I);
                 seg(p_star, mn);
-                const int subs = xpos >= 0 ? 1 : 0;
+                const int subs = (xpos >= 0 ? 1 : 0) + (xpos2 >= 0 ? 1 : 0);
                 int gap_cost = a.go + a.ge * gap;
                 if (a.go2 && a.go2 + a.ge2 * gap < gap_cost) gap_cost = a.go2 + a.ge2 * gap;       // the cheaper piece
                 fast_score = a.match * (mn - subs) - a.mismatch * subs - gap_cost;
@@ -2735,6 +2785,11 @@ static void align_span(const AvaInput &in, const hlmi_ava_opts &o, const uint32_
             const int k = aa.kmax + 1, U = den, T = num;
             // fifth certificate: one substitution gains less than a further inserted + deleted base costs
             aa.kgap1 = aa.kmax >= 0 && U < o.gap_open + 2 * o.gap_ext + o.match && !hook("HLMI_NO_GAP1_CERT") ? 1 : 0;
+            {   // seventh certificate: see classify_kernel (c(L) = the cheaper piece's cost of a gap of L bases)
+                auto c = [&](int L) { int v = o.gap_open + o.gap_ext * L; if (o.gap_open2 > 0) v = std::min(v, o.gap_open2 + o.gap_ext2 * L); return v; };
+                aa.kgap2 = aa.kgap1 && U < o.match + c(2) && 2 * U < o.match + 2 * c(1) && 2 * U < 2 * o.match + c(2) + c(3) - c(1) &&
+                           c(2) == o.gap_open + 2 * o.gap_ext && c(1) == o.gap_open + o.gap_ext && !hook("HLMI_NO_GAP2_CERT") ? 1 : 0;
+            }
             aa.kshift = aa.kmax >= 0 && k <= 3 && k * U > T && k * U < T + o.match + std::min(2 * o.gap_ext, o.gap_open + o.gap_ext) &&
                         !hook("HLMI_NO_SHIFT_CERT") ? 1 : 0;
         }

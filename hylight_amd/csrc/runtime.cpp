@@ -198,6 +198,7 @@ const char *const HOOK_NAMES[] = {
     "HLMI_NARROW_UNPACKED",
     "HLMI_NO_EXT_CERT",
     "HLMI_NO_GAP1_CERT",
+    "HLMI_NO_GAP2_CERT",
     "HLMI_NO_ONE_PIECE_CERT",
     "HLMI_NO_RANK_WORD",
     "HLMI_NO_SHIFT_CERT",

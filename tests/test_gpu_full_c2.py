@@ -68,7 +68,7 @@ def test_full_size_rows_satisfy_pass2_and_order(c2):
     assert n > 40_000
 
 
-@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_ANCHOR_SPLIT", "HLMI_NO_RANK_WORD", "HLMI_SNP_SORT", "HLMI_NO_SHIFT_CERT", "HLMI_NO_GAP1_CERT", "HLMI_NO_SUFFIX_TRIM", "HLMI_NO_ONE_PIECE_CERT", "HLMI_NO_EXT_CERT", "HLMI_CHAIN_NO_DP16", "HLMI_CHAIN_NO_SMALL"])
+@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_ANCHOR_SPLIT", "HLMI_NO_RANK_WORD", "HLMI_SNP_SORT", "HLMI_NO_SHIFT_CERT", "HLMI_NO_GAP1_CERT", "HLMI_NO_GAP2_CERT", "HLMI_NO_SUFFIX_TRIM", "HLMI_NO_ONE_PIECE_CERT", "HLMI_NO_EXT_CERT", "HLMI_CHAIN_NO_DP16", "HLMI_CHAIN_NO_SMALL"])
 def test_full_size_fallback_forms_agree(c2, monkeypatch, var):
     """The forms of the kernels that unusual inputs take (32-bit DP, two-register chain state, key + value anchors,
     two-array index search) give the same file at full size."""

@@ -59,7 +59,7 @@ def test_c3_slices_merge_to_the_full_pass_and_pass_is_deterministic(c3):
     assert same_file(merged, out)
 
 
-@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_NO_RANK_WORD", "HLMI_SNP_SORT", "HLMI_NO_SHIFT_CERT", "HLMI_NO_GAP1_CERT", "HLMI_NO_SUFFIX_TRIM", "HLMI_NO_ONE_PIECE_CERT", "HLMI_NO_EXT_CERT", "HLMI_CHAIN_NO_DP16", "HLMI_CHAIN_NO_SMALL", "HLMI_SEED_NO_GUESS"])
+@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_NO_RANK_WORD", "HLMI_SNP_SORT", "HLMI_NO_SHIFT_CERT", "HLMI_NO_GAP1_CERT", "HLMI_NO_GAP2_CERT", "HLMI_NO_SUFFIX_TRIM", "HLMI_NO_ONE_PIECE_CERT", "HLMI_NO_EXT_CERT", "HLMI_CHAIN_NO_DP16", "HLMI_CHAIN_NO_SMALL", "HLMI_SEED_NO_GUESS"])
 def test_c3_fallback_forms_agree_on_a_slice(c3, monkeypatch, var):
     d, cfg, r, out, rows, st = c3
     monkeypatch.setenv(var, "1")

@@ -48,7 +48,7 @@ def test_divergent_pass_is_deterministic_and_shardable(div):
     assert open(merged).read() == ref
 
 
-@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_NARROW_LONG_UNPACKED", "HLMI_STUB_FULL_ROWS", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_ANCHOR_SPLIT", "HLMI_NO_RANK_WORD", "HLMI_SNP_SORT", "HLMI_NO_SHIFT_CERT", "HLMI_NO_GAP1_CERT", "HLMI_NO_SUFFIX_TRIM", "HLMI_NO_ONE_PIECE_CERT", "HLMI_NO_EXT_CERT", "HLMI_CHAIN_NO_DP16", "HLMI_CHAIN_NO_SMALL", "HLMI_SEED_NO_GUESS"])
+@pytest.mark.parametrize("var", ["HLMI_NARROW_UNPACKED", "HLMI_NARROW_LONG_UNPACKED", "HLMI_STUB_FULL_ROWS", "HLMI_CHAIN_UNPACKED", "HLMI_ANCHOR_PAIRS", "HLMI_ANCHOR_SPLIT", "HLMI_NO_RANK_WORD", "HLMI_SNP_SORT", "HLMI_NO_SHIFT_CERT", "HLMI_NO_GAP1_CERT", "HLMI_NO_GAP2_CERT", "HLMI_NO_SUFFIX_TRIM", "HLMI_NO_ONE_PIECE_CERT", "HLMI_NO_EXT_CERT", "HLMI_CHAIN_NO_DP16", "HLMI_CHAIN_NO_SMALL", "HLMI_SEED_NO_GUESS"])
 def test_divergent_fallback_forms_agree(div, monkeypatch, var):
     d, fa, out = div
     monkeypatch.setenv(var, "1")
