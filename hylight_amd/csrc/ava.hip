@@ -354,7 +354,11 @@ void ava_device(const AvaInput &in, const hlmi_ava_opts &o, AvaRows &out) {
             }
         };
         std::vector<std::thread> workers;
-        for (int l = 1; l < n_lanes; ++l) workers.emplace_back(work, l);
+        try {
+            for (int l = 1; l < n_lanes; ++l) workers.emplace_back(work, l);
+        } catch (...) {                                   // no thread to be had: the caller's lane does what the others would have
+            stat_add("ava_lane_threads_refused", 1);
+        }
         work(0);
         for (auto &w : workers) w.join();
         for (int l = 0; l < MAX_LANES; ++l) if (errors[l]) std::rethrow_exception(errors[l]);
