@@ -7,6 +7,7 @@ Object files are cached under hylight_amd/csrc/build/ keyed by source mtime.
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -17,6 +18,10 @@ OUT = os.path.join(HERE, "libhylight_mi.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
+# A kernel that runs out of registers still builds: it spills to scratch and runs several times slower (round 5: a dozen lines
+# more in classify_kernel<1>, pinned to 128 registers for its occupancy, spilled 305 of them and cost the C3 step 170 ms).  The
+# build reads hipcc's resource remarks and refuses a kernel with more spilled vector registers than this.
+MAX_VGPR_SPILL = 16
 if os.environ.get("HLMI_INSTRUMENT"):            # kernel phase counters / self-checks (tuning builds only, never benched)
     FLAGS.append("-DHLMI_INSTRUMENT")
 
@@ -46,13 +51,30 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def cc(job):
         src, obj = job
         cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        if src.endswith(".hip"):
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print("[build]", os.path.basename(src), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
-        if r.stderr.strip() and verbose:
-            print(r.stderr, file=sys.stderr)
+        name, spilled, other = "?", [], []
+        for line in r.stderr.splitlines():
+            if "-Rpass-analysis=kernel-resource-usage" in line or "remark:" in line:
+                if "Function Name:" in line:
+                    name = line.split("Function Name:")[1].split("[")[0].strip()
+                elif "VGPRs Spill:" in line:
+                    n = int(line.split("VGPRs Spill:")[1].split("[")[0])
+                    if n > MAX_VGPR_SPILL:
+                        spilled.append((name, n))
+            elif not re.match(r"^\s*(\d+\s*)?\|", line) and not re.match(r"^\d+ (remark|warning)s? generated", line):
+                other.append(line)                 # (not the source excerpt under a remark)
+        if spilled:
+            os.remove(obj)
+            raise RuntimeError(f"{os.path.basename(src)}: kernels spill vector registers to scratch: " +
+                               ", ".join(f"{k} ({n})" for k, n in spilled))
+        if "\n".join(other).strip() and verbose:
+            print("\n".join(other), file=sys.stderr)
 
     if todo:
         with ThreadPoolExecutor(max_workers=min(6, len(todo))) as ex:
