@@ -26,6 +26,23 @@ if os.environ.get("HLMI_INSTRUMENT"):            # kernel phase counters / self-
     FLAGS.append("-DHLMI_INSTRUMENT")
 
 
+def resource_remarks(stderr: str):
+    """hipcc's -Rpass-analysis=kernel-resource-usage output -> ([(kernel, spilled vector registers)] above MAX_VGPR_SPILL,
+    the other lines: warnings and errors worth showing)."""
+    name, spilled, other = "?", [], []
+    for line in stderr.splitlines():
+        if "-Rpass-analysis=kernel-resource-usage" in line or "remark:" in line:
+            if "Function Name:" in line:
+                name = line.split("Function Name:")[1].split("[")[0].strip()
+            elif "VGPRs Spill:" in line:
+                n = int(line.split("VGPRs Spill:")[1].split("[")[0])
+                if n > MAX_VGPR_SPILL:
+                    spilled.append((name, n))
+        elif not re.match(r"^\s*(\d+\s*)?\|", line) and not re.match(r"^\d+ (remark|warning)s? generated", line):
+            other.append(line)                 # (not the source excerpt under a remark)
+    return spilled, other
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -58,17 +75,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
-        name, spilled, other = "?", [], []
-        for line in r.stderr.splitlines():
-            if "-Rpass-analysis=kernel-resource-usage" in line or "remark:" in line:
-                if "Function Name:" in line:
-                    name = line.split("Function Name:")[1].split("[")[0].strip()
-                elif "VGPRs Spill:" in line:
-                    n = int(line.split("VGPRs Spill:")[1].split("[")[0])
-                    if n > MAX_VGPR_SPILL:
-                        spilled.append((name, n))
-            elif not re.match(r"^\s*(\d+\s*)?\|", line) and not re.match(r"^\d+ (remark|warning)s? generated", line):
-                other.append(line)                 # (not the source excerpt under a remark)
+        spilled, other = resource_remarks(r.stderr)
         if spilled:
             os.remove(obj)
             raise RuntimeError(f"{os.path.basename(src)}: kernels spill vector registers to scratch: " +
