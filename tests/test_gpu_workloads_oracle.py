@@ -57,6 +57,7 @@ def test_one_whole_chunk_of_c3_matches_the_oracle(tmp_path):
     cf = str(tmp_path / f"sub{c:05d}")
     with open(cf, "w") as f:
         f.write("\n".join(lines[lo:hi]) + "\n")
+    all_lines, ranges2 = (lines, ranges) if os.environ.get("HL_TEST_C3_MORE_CHUNKS") else (None, None)
     del lines
     p = _oracle_proc(cf, fa, cf + ".oracle.paf")
     api.ava(cf, fa, cf + ".gpu.paf")
@@ -71,6 +72,18 @@ def test_one_whole_chunk_of_c3_matches_the_oracle(tmp_path):
     # supported keys of slr2:370-405 all along every alignment, and -thre 0.0025 drops nearly every pair): the comparison
     # above says little about the pair counts.  So the same chunk's rows go through the filter chain with -thre swept across the
     # distribution of count / matchcount and -len 1000: the survivors - tens of thousands - depend on every pair's count.
+    # more chunks on request (HL_TEST_C3_MORE_CHUNKS="7,140,198": a minute of the box's host cores each), raw rows only
+    for c2 in [int(x) for x in os.environ.get("HL_TEST_C3_MORE_CHUNKS", "").split(",") if x.strip()]:
+        lo2, hi2 = ranges2[c2]
+        cf2 = str(tmp_path / f"sub{c2:05d}")
+        with open(cf2, "w") as f:
+            f.write("\n".join(all_lines[lo2:hi2]) + "\n")
+        p2 = _oracle_proc(cf2, fa, cf2 + ".oracle.paf")
+        api.ava(cf2, fa, cf2 + ".gpu.paf")
+        assert p2.wait(timeout=1500) == 0
+        w2, g2 = _lines(cf2 + ".oracle.paf"), _lines(cf2 + ".gpu.paf")
+        print(f"C3 chunk {c2}: {len(w2)} candidate rows compared")
+        assert g2 == w2, f"whole C3 chunk {c2}, raw overlapper rows: " + _first_difference(g2, w2)
     thresholds = [0.0025, 0.004, 0.008, 0.02, 1.0]
     sweep = F.worker_sweep(want, True, 1000, stage["mc"], stage["iden"], thresholds)
     w = F.sort_scored(F.worker(want, True, stage["len_over"], stage["mc"], stage["iden"]))
