@@ -68,7 +68,7 @@ def test_c3_fallback_forms_agree_on_a_slice(c3, monkeypatch, var):
     assert same_file(alt, str(d / "slice3.paf"))
 
 
-@pytest.mark.parametrize("lanes,cuts", [("1", None), ("3", None), ("4", "25,50,75"), ("2", ""), ("2", "40,70,90")])
+@pytest.mark.parametrize("lanes,cuts", [("1", None), ("4", "25,50,75"), ("2", "")])
 def test_c3_lanes_agree_on_a_slice(c3, monkeypatch, lanes, cuts):
     """Query batches in flight (runtime.cpp: lanes): one after the other, two (the default the slices above ran with), three or
     four at a time, the set-aside pieces (LONG tasks) aligned at different points of the pass - the same bytes."""

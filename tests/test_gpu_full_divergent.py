@@ -57,7 +57,7 @@ def test_divergent_fallback_forms_agree(div, monkeypatch, var):
     assert open(alt).read() == open(out).read()
 
 
-@pytest.mark.parametrize("lanes", ["1", "2", "4"])
+@pytest.mark.parametrize("lanes", ["1", "3"])
 def test_divergent_lanes_agree_with_small_batches(div, monkeypatch, lanes):
     """Dozens of small query batches taken by 1, 2 or 4 lanes (host threads with a stream each) in whatever order they get to
     them; every lane runs its LONG tasks on a side stream of its own."""
